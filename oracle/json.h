@@ -1,0 +1,137 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see field.h header).
+// serde_json-compatible (compact) writer/reader for BrainfuckProof, following the derive(Serialize) shapes at
+// crates/brainfuck_prover/src/brainfuck_air/mod.rs:71-99,170-185 and components/mod.rs:71-93 (Claim{log_size,_marker},
+// InteractionClaim{claimed_sum}); the stwo StarkProof/CommitmentSchemeProof/FriProof field order is recalled (UNPINNED).
+#pragma once
+#include "prover.h"
+#include <cstdlib>
+#include <memory>
+
+namespace orc {
+
+static const char* const CLAIM_KEYS[N_COMPONENTS] = {"memory", "instruction", "program", "processor", "jump_if_not_zero", "jump_if_zero",
+    "input_instruction", "left_instruction", "minus_instruction", "output_instruction", "plus_instruction", "right_instruction", "end_of_execution"};
+
+struct JsonWriter {
+    std::string s;
+    void num(u64 v) { s += std::to_string(v); }
+    void qm31(const QM31& q) { auto a = q.to_u32(); s += "[["; num(a[0]); s += ","; num(a[1]); s += "],["; num(a[2]); s += ","; num(a[3]); s += "]]"; }
+    void hash(const Hash32& h) { s += "["; for (int i = 0; i < 32; i++) { if (i) s += ","; num(h.b[i]); } s += "]"; }
+    template <class T, class Fn> void arr(const std::vector<T>& v, Fn f) { s += "["; for (size_t i = 0; i < v.size(); i++) { if (i) s += ","; f(v[i]); } s += "]"; }
+    void decommitment(const MerkleDecommitment& d) {
+        s += "{\"hash_witness\":"; arr(d.hash_witness, [&](const Hash32& h) { hash(h); });
+        s += ",\"column_witness\":"; arr(d.column_witness, [&](u32 v) { num(v); }); s += "}";
+    }
+    void fri_layer(const FriLayerProof& l) {
+        s += "{\"fri_witness\":"; arr(l.fri_witness, [&](const QM31& q) { qm31(q); });
+        s += ",\"decommitment\":"; decommitment(l.decommitment);
+        s += ",\"commitment\":"; hash(l.commitment); s += "}";
+    }
+};
+
+static inline std::string proof_to_json(const BrainfuckProof& bp) {
+    JsonWriter w;
+    w.s += "{\"claim\":{";
+    for (int c = 0; c < N_COMPONENTS; c++) { if (c) w.s += ","; w.s += "\""; w.s += CLAIM_KEYS[c]; w.s += "\":{\"log_size\":"; w.num(bp.log_sizes[c]); w.s += ",\"_marker\":null}"; }
+    w.s += "},\"interaction_claim\":{";
+    for (int c = 0; c < N_COMPONENTS; c++) { if (c) w.s += ","; w.s += "\""; w.s += CLAIM_KEYS[c]; w.s += "\":{\"claimed_sum\":"; w.qm31(bp.claimed_sums[c]); w.s += "}"; }
+    const StarkProof& p = bp.proof;
+    w.s += "},\"proof\":{\"commitments\":"; w.arr(p.commitments, [&](const Hash32& h) { w.hash(h); });
+    w.s += ",\"sampled_values\":";
+    w.arr(p.sampled_values, [&](const std::vector<std::vector<QM31>>& t) { w.arr(t, [&](const std::vector<QM31>& c) { w.arr(c, [&](const QM31& q) { w.qm31(q); }); }); });
+    w.s += ",\"decommitments\":"; w.arr(p.decommitments, [&](const MerkleDecommitment& d) { w.decommitment(d); });
+    w.s += ",\"queried_values\":"; w.arr(p.queried_values, [&](const std::vector<u32>& v) { w.arr(v, [&](u32 x) { w.num(x); }); });
+    w.s += ",\"proof_of_work\":"; w.num(p.proof_of_work);
+    w.s += ",\"fri_proof\":{\"first_layer\":"; w.fri_layer(p.fri_proof.first_layer);
+    w.s += ",\"inner_layers\":"; w.arr(p.fri_proof.inner_layers, [&](const FriLayerProof& l) { w.fri_layer(l); });
+    w.s += ",\"last_layer_poly\":{\"coeffs\":"; w.arr(p.fri_proof.last_layer_coeffs, [&](const QM31& q) { w.qm31(q); });
+    w.s += ",\"log_size\":"; w.num(p.fri_proof.last_layer_log_size); w.s += "}}}}";
+    return w.s;
+}
+
+// Minimal JSON value tree (numbers are unsigned integers; null supported).
+struct JVal {
+    enum Kind { NUM, ARR, OBJ, NUL } kind = NUL;
+    u64 num = 0;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;
+    const JVal& get(const char* k) const { for (auto& kv : obj) if (kv.first == k) return kv.second; throw std::runtime_error(std::string("missing key ") + k); }
+};
+struct JsonParser {
+    const char* p; const char* end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    JVal parse() {
+        ws();
+        if (p >= end) throw std::runtime_error("json: eof");
+        JVal v;
+        if (*p == '[') {
+            v.kind = JVal::ARR; p++; ws();
+            if (p < end && *p == ']') { p++; return v; }
+            for (;;) { v.arr.push_back(parse()); ws(); if (p < end && *p == ',') { p++; continue; } if (p < end && *p == ']') { p++; break; } throw std::runtime_error("json: array"); }
+        } else if (*p == '{') {
+            v.kind = JVal::OBJ; p++; ws();
+            if (p < end && *p == '}') { p++; return v; }
+            for (;;) {
+                ws(); if (p >= end || *p != '"') throw std::runtime_error("json: key");
+                p++; const char* s = p; while (p < end && *p != '"') p++; std::string k(s, p); p++;
+                ws(); if (p >= end || *p != ':') throw std::runtime_error("json: colon"); p++;
+                v.obj.push_back({k, parse()}); ws();
+                if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
+            }
+        } else if (*p == 'n') { if (end - p < 4) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
+        else if (*p >= '0' && *p <= '9') { v.kind = JVal::NUM; u64 x = 0; while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (u64)(*p - '0'); p++; } v.num = x; }
+        else throw std::runtime_error("json: unexpected char");
+        return v;
+    }
+};
+
+static inline u32 j_m31(const JVal& v) { if (v.kind != JVal::NUM || v.num >= P) throw std::runtime_error("bad M31"); return (u32)v.num; }
+static inline QM31 j_qm31(const JVal& v) {
+    if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
+    return QM31::from_u32(j_m31(v.arr[0].arr[0]), j_m31(v.arr[0].arr[1]), j_m31(v.arr[1].arr[0]), j_m31(v.arr[1].arr[1]));
+}
+static inline Hash32 j_hash(const JVal& v) {
+    if (v.kind != JVal::ARR || v.arr.size() != 32) throw std::runtime_error("bad hash");
+    Hash32 h; for (int i = 0; i < 32; i++) { if (v.arr[i].num > 255) throw std::runtime_error("bad hash byte"); h.b[i] = (u8)v.arr[i].num; } return h;
+}
+static inline MerkleDecommitment j_decommitment(const JVal& v) {
+    MerkleDecommitment d;
+    for (auto& h : v.get("hash_witness").arr) d.hash_witness.push_back(j_hash(h));
+    for (auto& x : v.get("column_witness").arr) d.column_witness.push_back(j_m31(x));
+    return d;
+}
+static inline FriLayerProof j_fri_layer(const JVal& v) {
+    FriLayerProof l;
+    for (auto& q : v.get("fri_witness").arr) l.fri_witness.push_back(j_qm31(q));
+    l.decommitment = j_decommitment(v.get("decommitment"));
+    l.commitment = j_hash(v.get("commitment"));
+    return l;
+}
+static inline BrainfuckProof proof_from_json(const char* s, size_t len) {
+    JsonParser jp{s, s + len};
+    JVal root = jp.parse();
+    BrainfuckProof bp;
+    for (int c = 0; c < N_COMPONENTS; c++) {
+        bp.log_sizes[c] = (u32)root.get("claim").get(CLAIM_KEYS[c]).get("log_size").num;
+        bp.claimed_sums[c] = j_qm31(root.get("interaction_claim").get(CLAIM_KEYS[c]).get("claimed_sum"));
+    }
+    const JVal& p = root.get("proof");
+    StarkProof& sp = bp.proof;
+    for (auto& h : p.get("commitments").arr) sp.commitments.push_back(j_hash(h));
+    for (auto& t : p.get("sampled_values").arr) {
+        std::vector<std::vector<QM31>> tv;
+        for (auto& c : t.arr) { std::vector<QM31> cv; for (auto& q : c.arr) cv.push_back(j_qm31(q)); tv.push_back(cv); }
+        sp.sampled_values.push_back(tv);
+    }
+    for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(j_decommitment(d));
+    for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(j_m31(x)); sp.queried_values.push_back(v); }
+    sp.proof_of_work = p.get("proof_of_work").num;
+    const JVal& f = p.get("fri_proof");
+    sp.fri_proof.first_layer = j_fri_layer(f.get("first_layer"));
+    for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(j_fri_layer(l));
+    for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(j_qm31(q));
+    sp.fri_proof.last_layer_log_size = (u32)f.get("last_layer_poly").get("log_size").num;
+    return bp;
+}
+
+}  // namespace orc

@@ -1,0 +1,238 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see field.h header).
+// C ABI over the CPU restatement so that tests/ (ctypes), __graft_entry__.smoke() and bench.py's cpu_baseline leg can call it.
+// Nothing in the shipped product links or loads this library.
+#include "json.h"
+#include <chrono>
+#include <cstdio>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown"; return -1; }
+
+static std::vector<Registers> run_program(const char* code, const u8* input, size_t n_in, std::vector<u32>* code_out, std::vector<u8>* output) {
+    std::vector<u32> ins = compile(code);
+    Machine m(ins, std::vector<u8>(input, input + n_in));
+    m.execute();
+    if (code_out) *code_out = ins;
+    if (output) *output = m.output;
+    return m.trace;
+}
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+void orc_free(void* p) { free(p); }
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n); return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
+
+// ---- fields ------------------------------------------------------------------------------------------------------------
+// op: 0 add, 1 sub, 2 mul, 3 inv(a)
+int orc_m31_op(int op, const u32* a, const u32* b, u32* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        M31 x(a[i]), y(b ? b[i] : 0);
+        out[i] = (op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : inv(x)).v;
+    }
+    return 0;
+}
+int orc_qm31_op(int op, const u32* a, const u32* b, u32* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        QM31 x = QM31::from_u32(a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]);
+        QM31 y = b ? QM31::from_u32(b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]) : QM31::zero();
+        QM31 r = op == 0 ? x + y : op == 1 ? x - y : op == 2 ? x * y : inv(x);
+        auto o = r.to_u32();
+        for (int k = 0; k < 4; k++) out[4 * i + k] = o[k];
+    }
+    return 0;
+}
+
+// ---- circle / FFT ------------------------------------------------------------------------------------------------------------
+int orc_domain_point(u32 log_size, u32 index, u32 out_xy[2]) { PointM p = CanonicCoset{log_size}.circle_domain().at(index); out_xy[0] = p.x.v; out_xy[1] = p.y.v; return 0; }
+// twiddle buffer of Coset::half_odds(log)  (length 2^log), and its inverse
+int orc_twiddles(u32 root_log, u32* tw, u32* itw) {
+    ORC_TRY
+    TwiddleTree t = precompute_twiddles(Coset::half_odds(root_log));
+    for (size_t i = 0; i < t.twiddles.size(); i++) { tw[i] = t.twiddles[i].v; if (itw) itw[i] = t.itwiddles[i].v; }
+    return 0;
+    ORC_CATCH
+}
+// in-place on n_cols contiguous columns of 2^log_size
+int orc_circle_interpolate(u32* values, u32 log_size, size_t n_cols) {
+    ORC_TRY
+    TwiddleTree t = precompute_twiddles(CanonicCoset{log_size}.circle_domain().half_coset);
+#pragma omp parallel for
+    for (size_t c = 0; c < n_cols; c++) circle_interpolate(reinterpret_cast<M31*>(values + (c << log_size)), log_size, t);
+    return 0;
+    ORC_CATCH
+}
+// coeffs (2^log_size per column) -> evals (2^eval_log per column) on CanonicCoset(eval_log).circle_domain()
+int orc_circle_evaluate(const u32* coeffs, u32 log_size, u32 eval_log, size_t n_cols, u32* out) {
+    ORC_TRY
+    TwiddleTree t = precompute_twiddles(CanonicCoset{eval_log}.circle_domain().half_coset);
+#pragma omp parallel for
+    for (size_t c = 0; c < n_cols; c++) {
+        u32* o = out + (c << eval_log);
+        memcpy(o, coeffs + (c << log_size), sizeof(u32) << log_size);
+        memset(o + (size_t(1) << log_size), 0, (sizeof(u32) << eval_log) - (sizeof(u32) << log_size));
+        circle_evaluate(reinterpret_cast<M31*>(o), eval_log, t);
+    }
+    return 0;
+    ORC_CATCH
+}
+int orc_eval_at_point(const u32* coeffs, u32 log_size, const u32 point[8], u32 out[4]) {
+    PointQ p(QM31::from_u32(point[0], point[1], point[2], point[3]), QM31::from_u32(point[4], point[5], point[6], point[7]));
+    auto r = eval_at_point(reinterpret_cast<const M31*>(coeffs), log_size, p).to_u32();
+    for (int k = 0; k < 4; k++) out[k] = r[k];
+    return 0;
+}
+
+// ---- hashing / channel / Merkle ---------------------------------------------------------------------------------------------
+int orc_blake2s(const u8* data, size_t len, u8 out[32]) { Hash32 h = Blake2s::hash(data, len); memcpy(out, h.b, 32); return 0; }
+// cols: n pointers, logs: n log sizes. Writes every layer's hashes contiguously, deepest layer first, if layers_out != NULL.
+int orc_merkle_commit(const u32* const* cols, const u32* logs, size_t n, u8 root[32], u8* layers_out) {
+    ORC_TRY
+    std::vector<ColRef> r;
+    for (size_t i = 0; i < n; i++) r.push_back({cols[i], logs[i]});
+    MerkleProver mp = MerkleProver::commit(r);
+    memcpy(root, mp.root().b, 32);
+    if (layers_out) { u8* o = layers_out; for (int l = (int)mp.layers.size() - 1; l >= 0; l--) { memcpy(o, mp.layers[l].data(), 32 * mp.layers[l].size()); o += 32 * mp.layers[l].size(); } }
+    return 0;
+    ORC_CATCH
+}
+// Channel scripting for tests: ops encoded as a byte stream is overkill; expose the primitives on an opaque handle.
+void* orc_channel_new() { return new Channel(); }
+void orc_channel_free(void* c) { delete (Channel*)c; }
+void orc_channel_digest(void* c, u8 out[32]) { memcpy(out, ((Channel*)c)->digest.b, 32); }
+void orc_channel_mix_root(void* c, const u8 root[32]) { Hash32 h; memcpy(h.b, root, 32); ((Channel*)c)->mix_root(h); }
+void orc_channel_mix_u64(void* c, u64 v) { ((Channel*)c)->mix_u64(v); }
+void orc_channel_mix_felts(void* c, const u32* f, size_t n) { std::vector<QM31> v; for (size_t i = 0; i < n; i++) v.push_back(QM31::from_u32(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3])); ((Channel*)c)->mix_felts(v.data(), n); }
+void orc_channel_draw_felt(void* c, u32 out[4]) { auto a = ((Channel*)c)->draw_felt().to_u32(); for (int k = 0; k < 4; k++) out[k] = a[k]; }
+u64 orc_channel_grind(void* c, u32 pow_bits) { return grind(*(Channel*)c, pow_bits); }
+u32 orc_channel_trailing_zeros(void* c) { return ((Channel*)c)->trailing_zeros(); }
+
+// ---- VM / tables ------------------------------------------------------------------------------------------------------------
+int orc_compile(const char* code, u32* out, size_t cap, size_t* n) {
+    ORC_TRY
+    auto ins = compile(code);
+    *n = ins.size();
+    if (ins.size() > cap) { g_err = "cap"; return -2; }
+    memcpy(out, ins.data(), 4 * ins.size());
+    return 0;
+    ORC_CATCH
+}
+// trace_out: 7 u32 per row (clk, ip, ci, ni, mp, mv, mvi)
+int orc_run(const char* code, const u8* input, size_t n_in, u8* out, size_t out_cap, size_t* n_out, u32* trace_out, size_t trace_cap_rows, size_t* n_rows) {
+    ORC_TRY
+    std::vector<u8> output;
+    auto tr = run_program(code, input, n_in, nullptr, &output);
+    if (n_out) *n_out = output.size();
+    if (out && output.size() <= out_cap) memcpy(out, output.data(), output.size());
+    if (n_rows) *n_rows = tr.size();
+    if (trace_out && tr.size() <= trace_cap_rows)
+        for (size_t i = 0; i < tr.size(); i++) { u32 v[7] = {tr[i].clk, tr[i].ip, tr[i].ci, tr[i].ni, tr[i].mp, tr[i].mv, tr[i].mvi}; memcpy(trace_out + 7 * i, v, 28); }
+    return 0;
+    ORC_CATCH
+}
+// Component table in row-major form (n_rows x n_cols). Pass out == NULL to query the shape.
+int orc_table(const char* code, const u8* input, size_t n_in, int component, u32* out, size_t cap, size_t* n_rows, size_t* n_cols) {
+    ORC_TRY
+    std::vector<u32> ins;
+    auto tr = run_program(code, input, n_in, &ins, nullptr);
+    auto tables = build_tables(tr, ins);
+    const Table& t = tables.at(component);
+    *n_rows = t.n_rows; *n_cols = t.cols.size();
+    if (out) {
+        if (t.n_rows * t.cols.size() > cap) { g_err = "cap"; return -2; }
+        for (size_t r = 0; r < t.n_rows; r++) for (size_t c = 0; c < t.cols.size(); c++) out[r * t.cols.size() + c] = t.cols[c][r];
+    }
+    return 0;
+    ORC_CATCH
+}
+int orc_log_sizes(const char* code, const u8* input, size_t n_in, u32 out[13], u64* n_steps) {
+    ORC_TRY
+    std::vector<u32> ins;
+    auto tr = run_program(code, input, n_in, &ins, nullptr);
+    auto tables = build_tables(tr, ins);
+    for (int c = 0; c < N_COMPONENTS; c++) out[c] = tables[c].log_size();
+    if (n_steps) *n_steps = tr.size();
+    return 0;
+    ORC_CATCH
+}
+
+// AIR satisfiability on the trace domain (stwo assert_constraints analogue) with given lookup elements (z, alpha per relation:
+// memory, instruction, processor; 8 u32 each). Returns 0 if all rows satisfy all constraints; else 1 and (*bad_row, *bad_constraint).
+int orc_assert_constraints(const char* code, const u8* input, size_t n_in, int component, const u32* elems24, int corrupt_col, size_t corrupt_row, u32 corrupt_val,
+                           size_t* bad_row, int* bad_constraint) {
+    ORC_TRY
+    std::vector<u32> ins;
+    auto tr = run_program(code, input, n_in, &ins, nullptr);
+    auto tables = build_tables(tr, ins);
+    Table& t = tables.at(component);
+    if (corrupt_col >= 0) t.cols.at(corrupt_col).at(corrupt_row) = corrupt_val;
+    InteractionElements el;
+    auto q = [&](int i) { return QM31::from_u32(elems24[4 * i], elems24[4 * i + 1], elems24[4 * i + 2], elems24[4 * i + 3]); };
+    el.memory = LookupElements::make(q(0), q(1)); el.instruction = LookupElements::make(q(2), q(3)); el.processor = LookupElements::make(q(4), q(5));
+    u32 log = t.log_size();
+    std::vector<std::vector<u32>> main_cols;
+    for (auto& c : t.cols) main_cols.push_back(broadcast16(c));
+    QM31 claimed;
+    auto inter = gen_interaction_trace(component, t, el, &claimed);
+    std::vector<u32> isf(size_t(1) << log, 0); isf[0] = 1;
+    std::vector<const u32*> tc, ic;
+    for (auto& c : main_cols) tc.push_back(c.data());
+    for (auto& c : inter) ic.push_back(c.data());
+    for (size_t row = 0; row < (size_t(1) << log); row++) {
+        AssertEvaluator ae;
+        ae.is_first_col = isf.data(); ae.trace_cols = tc.data(); ae.inter_cols = ic.data(); ae.row = row; ae.log_size = log; ae.total_sum = claimed;
+        eval_component(component, ae, el);
+        if (ae.failed >= 0) { if (bad_row) *bad_row = row; if (bad_constraint) *bad_constraint = ae.failed; return 1; }
+    }
+    return 0;
+    ORC_CATCH
+}
+
+// ---- prove / verify -----------------------------------------------------------------------------------------------------
+// Returns a malloc'd JSON string (free with orc_free). transcript_out (optional, malloc'd): "name:hexdigest\n" per tap.
+int orc_prove(const char* code, const u8* input, size_t n_in, u32 log_max_rows, char** json_out, size_t* json_len, char** transcript_out, double* seconds) {
+    ORC_TRY
+    std::vector<u32> ins;
+    auto tr = run_program(code, input, n_in, &ins, nullptr);
+    Prover pv; pv.log_max_rows = log_max_rows;
+    std::string transcript;
+    pv.trace_hook = [&](const char* name, const Channel& ch) {
+        char buf[80]; transcript += name; transcript += ":";
+        for (int i = 0; i < 32; i++) { snprintf(buf, sizeof buf, "%02x", ch.digest.b[i]); transcript += buf; }
+        transcript += "\n";
+    };
+    auto t0 = std::chrono::steady_clock::now();
+    BrainfuckProof bp = pv.prove(tr, ins);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    std::string js = proof_to_json(bp);
+    *json_out = (char*)malloc(js.size() + 1); memcpy(*json_out, js.c_str(), js.size() + 1); *json_len = js.size();
+    if (transcript_out) { *transcript_out = (char*)malloc(transcript.size() + 1); memcpy(*transcript_out, transcript.c_str(), transcript.size() + 1); }
+    return 0;
+    ORC_CATCH
+}
+// 0 = verified; 1 = rejected (reason in err); -1 = malformed input
+int orc_verify(const char* json, size_t len, u32 log_max_rows, char* err, size_t errcap) {
+    ORC_TRY
+    BrainfuckProof bp;
+    try { bp = proof_from_json(json, len); } catch (const std::exception& e) { if (err) snprintf(err, errcap, "InvalidStructure: %s", e.what()); return 1; }
+    Verifier v; v.log_max_rows = log_max_rows;
+    std::string e = v.verify(bp);
+    if (err) snprintf(err, errcap, "%s", e.c_str());
+    return e.empty() ? 0 : 1;
+    ORC_CATCH
+}
+
+}  // extern "C"
