@@ -1,0 +1,99 @@
+"""MI355X-native Circle-STARK prover backend for the Brainfuck zkVM — Python host mirror over the C ABI (include/bfhip.h).
+
+The product path is libbfhip.so (hand-written gfx950 kernels). There is no CPU fallback: if the library or a GPU is missing,
+every entry point raises.  Reference interface mirrored: crates/brainfuck_prover/src/brainfuck_air/mod.rs:471 (prove_brainfuck),
+:738 (verify_brainfuck) and stwo's PolyOps/MerkleOps/FriOps/QuotientOps trait surface (SURVEY.md §8 b).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbfhip.so")
+_lib = None
+
+P = (1 << 31) - 1
+
+
+class BfhipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libbfhip.so (built in-tree by `make -C stwo-brainfuck_amd/csrc`). Fails loudly when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise BfhipError(f"{_LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.bfhip_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BfhipError(lib().bfhip_last_error().decode())
+
+
+def device_count():
+    return lib().bfhip_device_count()
+
+
+class Context:
+    """One GPU + one HIP stream + the twiddle tree (mod.rs:480-487: twiddles, channel and commitment scheme setup)."""
+
+    def __init__(self, device_id=0, max_log_domain=22):
+        self._h = ctypes.c_void_p()
+        _check(lib().bfhip_ctx_create(device_id, max_log_domain, ctypes.byref(self._h)))
+        self.max_log_domain = max_log_domain
+
+    def close(self):
+        if self._h:
+            lib().bfhip_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().bfhip_ctx_sync(self._h))
+
+    # -- buffers ---------------------------------------------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(lib().bfhip_malloc(self._h, ctypes.c_size_t(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        _check(lib().bfhip_free(self._h, ctypes.c_void_p(ptr)))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        ptr = self.malloc(arr.nbytes)
+        _check(lib().bfhip_upload(self._h, ctypes.c_void_p(ptr), arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(arr.nbytes)))
+        return ptr
+
+    def download(self, ptr, n, dtype=np.uint32):
+        out = np.empty(n, dtype=dtype)
+        _check(lib().bfhip_download(self._h, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(out.nbytes)))
+        return out
+
+    @staticmethod
+    def _ptr_array(ptrs):
+        return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+    # -- PolyOps ---------------------------------------------------------------------------------------------------
+    def interpolate(self, src_ptrs, dst_ptrs, log_size, replicated=False):
+        _check(lib().bfhip_interpolate(self._h, self._ptr_array(src_ptrs), self._ptr_array(dst_ptrs), len(src_ptrs), log_size, int(replicated)))
+
+    def evaluate(self, coeff_ptrs, dst_ptrs, log_size, log_eval, replicated=False):
+        _check(lib().bfhip_evaluate(self._h, self._ptr_array(coeff_ptrs), self._ptr_array(dst_ptrs), len(coeff_ptrs), log_size, log_eval, int(replicated)))
+
+    def twiddles(self):
+        tw, itw, rl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+        _check(lib().bfhip_twiddles(self._h, ctypes.byref(tw), ctypes.byref(itw), ctypes.byref(rl)))
+        return tw.value, itw.value, rl.value

@@ -1,0 +1,62 @@
+// Device context: stream, twiddle tree, arena allocator, small staging helpers. Internal to the library.
+#pragma once
+#include "kernels.h"
+#include <vector>
+#include <string>
+#include <stdexcept>
+#include <cstring>
+
+namespace bf {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define BF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) throw bf::HipError(std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+
+// Bump allocator over large HBM chunks: the prover allocates hundreds of columns per proof and frees them all at once.
+struct Arena {
+    struct Chunk { char* base; size_t size, used; };
+    std::vector<Chunk> chunks;
+    size_t chunk_bytes = size_t(1) << 30;
+    size_t total_used = 0, peak = 0;
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~size_t(255);
+        for (auto& c : chunks) if (c.size - c.used >= bytes) { void* p = c.base + c.used; c.used += bytes; total_used += bytes; if (total_used > peak) peak = total_used; return p; }
+        size_t sz = bytes > chunk_bytes ? bytes : chunk_bytes;
+        char* p = nullptr;
+        BF_HIP(hipMalloc((void**)&p, sz));
+        chunks.push_back({p, sz, bytes});
+        total_used += bytes; if (total_used > peak) peak = total_used;
+        return p;
+    }
+    void reset() { for (auto& c : chunks) c.used = 0; total_used = 0; }
+    void release() { for (auto& c : chunks) (void)hipFree(c.base); chunks.clear(); total_used = 0; }
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
+    u32* d_tw = nullptr; u32* d_itw = nullptr;
+    uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
+    Arena arena;
+    // pinned staging for pointer arrays / small parameter blocks
+    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 1 << 20, stage_used = 0;
+
+    void init(int dev, u32 max_log_domain);
+    void destroy();
+    void sync() { BF_HIP(hipStreamSynchronize(stream)); }
+    // Copy a small host block to device scratch (valid until the next stage_reset()). Stream-ordered.
+    template <class T>
+    T* stage(const T* host, size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (stage_used + bytes > stage_bytes) { sync(); stage_used = 0; }
+        if (bytes > stage_bytes) throw HipError("stage block too large");
+        memcpy(h_stage + stage_used, host, n * sizeof(T));
+        BF_HIP(hipMemcpyAsync(d_stage + stage_used, h_stage + stage_used, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        T* r = reinterpret_cast<T*>(d_stage + stage_used);
+        stage_used += bytes;
+        return r;
+    }
+    u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
+};
+
+}  // namespace bf

@@ -1,0 +1,82 @@
+// M31 / CM31 / QM31 arithmetic shared by host code and gfx950 kernels.
+// Replaces stwo's `core/fields/{m31,cm31,qm31}.rs` + SIMD `PackedM31/PackedQM31` as used by the reference at
+// crates/brainfuck_prover/src/components/mod.rs:13-19 and memory/table.rs:9-18.
+// Storage is a canonical u32 in [0, P); QM31 columns are 4 x u32 SoA (SecureColumnByCoords).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BF_HD __host__ __device__ __forceinline__
+#else
+#define BF_HD inline
+#endif
+
+namespace bf {
+
+using u8 = uint8_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+
+constexpr u32 P31 = 0x7fffffffu;
+
+BF_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; u32 t = s - P31; return t < s ? t : s; }           // min(s, s-P) with wraparound
+BF_HD u32 m_sub(u32 a, u32 b) { u32 s = a - b; u32 t = s + P31; return t < s ? t : s; }           // a-b or a-b+P
+BF_HD u32 m_neg(u32 a) { return a ? P31 - a : 0; }
+BF_HD u32 m_reduce64(u64 x) {  // x < P^2 -> [0, P)
+    u32 lo = (u32)x & P31, hi = (u32)(x >> 31);
+    u32 s = lo + hi; u32 t = s - P31; return t < s ? t : s;
+}
+BF_HD u32 m_mul(u32 a, u32 b) { return m_reduce64((u64)a * b); }
+BF_HD u32 m_sqr(u32 a) { return m_mul(a, a); }
+BF_HD u32 m_pow(u32 b, u32 e) { u32 r = 1; while (e) { if (e & 1) r = m_mul(r, b); b = m_mul(b, b); e >>= 1; } return r; }
+// x^(P-2) with the 2^31-3 addition chain (37 multiplications)
+BF_HD u32 m_sqn(u32 x, int n) { for (int i = 0; i < n; i++) x = m_sqr(x); return x; }
+BF_HD u32 m_inv(u32 x) {
+    u32 t0 = m_mul(m_sqn(x, 2), x);            // x^5
+    u32 t1 = m_mul(m_sqr(t0), t0);             // x^15
+    u32 t2 = m_mul(m_sqn(t1, 3), t0);          // x^125
+    u32 t3 = m_mul(m_sqr(t2), t0);             // x^255
+    u32 t4 = m_mul(m_sqn(t3, 8), t3);          // x^65535
+    u32 t5 = m_mul(m_sqn(t4, 8), t3);          // x^16777215
+    return m_mul(m_sqn(t5, 7), t2);            // x^2147483645
+}
+
+struct C31 { u32 a, b; };
+BF_HD C31 c_add(C31 x, C31 y) { return {m_add(x.a, y.a), m_add(x.b, y.b)}; }
+BF_HD C31 c_sub(C31 x, C31 y) { return {m_sub(x.a, y.a), m_sub(x.b, y.b)}; }
+BF_HD C31 c_neg(C31 x) { return {m_neg(x.a), m_neg(x.b)}; }
+BF_HD C31 c_mul(C31 x, C31 y) { return {m_sub(m_mul(x.a, y.a), m_mul(x.b, y.b)), m_add(m_mul(x.a, y.b), m_mul(x.b, y.a))}; }
+BF_HD C31 c_mulm(C31 x, u32 y) { return {m_mul(x.a, y), m_mul(x.b, y)}; }
+BF_HD C31 c_mulR(C31 x) { return {m_sub(m_add(x.a, x.a), x.b), m_add(x.a, m_add(x.b, x.b))}; }  // * (2 + i)
+BF_HD C31 c_inv(C31 x) { u32 n = m_inv(m_add(m_sqr(x.a), m_sqr(x.b))); return {m_mul(x.a, n), m_neg(m_mul(x.b, n))}; }
+
+struct Q31 { C31 a, b; };
+BF_HD Q31 q_make(u32 a0, u32 a1, u32 a2, u32 a3) { return {{a0, a1}, {a2, a3}}; }
+BF_HD Q31 q_zero() { return {{0, 0}, {0, 0}}; }
+BF_HD Q31 q_one() { return {{1, 0}, {0, 0}}; }
+BF_HD Q31 q_from_m(u32 x) { return {{x, 0}, {0, 0}}; }
+BF_HD Q31 q_add(Q31 x, Q31 y) { return {c_add(x.a, y.a), c_add(x.b, y.b)}; }
+BF_HD Q31 q_sub(Q31 x, Q31 y) { return {c_sub(x.a, y.a), c_sub(x.b, y.b)}; }
+BF_HD Q31 q_neg(Q31 x) { return {c_neg(x.a), c_neg(x.b)}; }
+BF_HD Q31 q_mul(Q31 x, Q31 y) { return {c_add(c_mul(x.a, y.a), c_mulR(c_mul(x.b, y.b))), c_add(c_mul(x.a, y.b), c_mul(x.b, y.a))}; }
+BF_HD Q31 q_mulm(Q31 x, u32 y) { return {c_mulm(x.a, y), c_mulm(x.b, y)}; }
+BF_HD Q31 q_mulc(Q31 x, C31 y) { return {c_mul(x.a, y), c_mul(x.b, y)}; }
+BF_HD Q31 q_addm(Q31 x, u32 y) { x.a.a = m_add(x.a.a, y); return x; }
+BF_HD Q31 q_subm(Q31 x, u32 y) { x.a.a = m_sub(x.a.a, y); return x; }
+BF_HD Q31 q_conj(Q31 x) { return {x.a, c_neg(x.b)}; }
+BF_HD Q31 q_inv(Q31 x) { C31 d = c_inv(c_sub(c_mul(x.a, x.a), c_mulR(c_mul(x.b, x.b)))); return {c_mul(x.a, d), c_neg(c_mul(x.b, d))}; }
+BF_HD bool q_eq(Q31 x, Q31 y) { return x.a.a == y.a.a && x.a.b == y.a.b && x.b.a == y.b.a && x.b.b == y.b.b; }
+BF_HD bool q_is_zero(Q31 x) { return (x.a.a | x.a.b | x.b.a | x.b.b) == 0; }
+BF_HD Q31 q_pow(Q31 b, u64 e) { Q31 r = q_one(); while (e) { if (e & 1) r = q_mul(r, b); b = q_mul(b, b); e >>= 1; } return r; }
+
+BF_HD u32 bit_rev(u32 i, u32 log) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return log ? (__brev(i) >> (32 - log)) : 0;
+#else
+    u32 r = 0; for (u32 k = 0; k < log; k++) r |= ((i >> k) & 1u) << (log - 1 - k); return r;
+#endif
+}
+
+}  // namespace bf

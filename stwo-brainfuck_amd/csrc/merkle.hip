@@ -1,0 +1,135 @@
+// Blake2s mixed-degree Merkle layers for gfx950 — SURVEY.md §8 row a4.
+// Replaces stwo `MerkleOps<Blake2sMerkleHasher>::commit_on_layer` reached from tree_builder.commit(channel),
+// crates/brainfuck_prover/src/brainfuck_air/mod.rs:500,583,723 (and the composition / FRI layer trees inside prover::prove, :732).
+// node(i) = Blake2s-256( left(32B) || right(32B) || LE-u32 value of every column of this layer's size at row i ).
+//
+// One lane hashes one node. The message is streamed 64 bytes at a time through a fully unrolled compression (the sigma
+// schedule is compile-time, so the 16 message words and the 16 state words stay in VGPRs; rotations by 16/8 lower to
+// v_perm/v_alignbit). This kernel is integer-VALU bound (~1.0 k ops per 64-byte block), not HBM bound: see DESIGN.md.
+// Column reads are coalesced (lane i reads cell i of each column; replicated columns read cell i >> 4), child hashes are read as
+// 4 x 16 B per lane, hashes are stored as 2 x 16 B per lane in AoS [node][8 x u32] order (the order decommitment needs).
+#include "kernels.h"
+
+namespace bf {
+
+__device__ __constant__ const u32 B2S_IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+__device__ __forceinline__ u32 rotr(u32 x, int r) { return __builtin_amdgcn_alignbit(x, x, r); }
+
+#define B2S_G(a, b, c, d, x, y) \
+    a = a + b + (x); d = rotr(d ^ a, 16); c = c + d; b = rotr(b ^ c, 12); \
+    a = a + b + (y); d = rotr(d ^ a, 8);  c = c + d; b = rotr(b ^ c, 7);
+
+#define B2S_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    B2S_G(v0, v4, v8, v12, m[s0], m[s1]) B2S_G(v1, v5, v9, v13, m[s2], m[s3])           \
+    B2S_G(v2, v6, v10, v14, m[s4], m[s5]) B2S_G(v3, v7, v11, v15, m[s6], m[s7])         \
+    B2S_G(v0, v5, v10, v15, m[s8], m[s9]) B2S_G(v1, v6, v11, v12, m[s10], m[s11])       \
+    B2S_G(v2, v7, v8, v13, m[s12], m[s13]) B2S_G(v3, v4, v9, v14, m[s14], m[s15])
+
+__device__ __forceinline__ void blake2s_compress(u32 h[8], const u32 m[16], u32 t0, u32 f0) {
+    u32 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
+    u32 v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
+    u32 v12 = 0x510E527Fu ^ t0, v13 = 0x9B05688Cu, v14 = 0x1F83D9ABu ^ f0, v15 = 0x5BE0CD19u;
+    B2S_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    B2S_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    B2S_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    B2S_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    B2S_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    B2S_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    B2S_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    B2S_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    B2S_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    B2S_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    h[0] ^= v0 ^ v8; h[1] ^= v1 ^ v9; h[2] ^= v2 ^ v10; h[3] ^= v3 ^ v11;
+    h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
+}
+
+// One Merkle layer of 2^log nodes. prev == nullptr for the deepest layer. Requires has_prev || ncols > 0 ... or hashes the empty string.
+__global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
+    h[0] ^= 0x01010020u;
+    const u32 total_bytes = (prev ? 64u : 0u) + 4u * ncols;
+    u32 m[16];
+    u32 done = 0;   // bytes compressed so far
+    u32 c0 = 0;     // next column to absorb
+    if (prev) {
+        uint4 a = prev[4 * (size_t)i], b = prev[4 * (size_t)i + 1], c = prev[4 * (size_t)i + 2], d = prev[4 * (size_t)i + 3];
+        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+        m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+        done = 64;
+        bool last = total_bytes == 64;
+        blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
+        if (last) { out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]); return; }
+    }
+    // remaining message: column values, 16 words per block (zero padded)
+    for (;;) {
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            u32 c = c0 + w;
+            u32 v = 0;
+            if (c < ncols) { ColDesc cd = cols[c]; v = cd.ptr[i >> cd.shift]; }
+            m[w] = v;
+        }
+        u32 take = min(64u, total_bytes - done);
+        done += take; c0 += 16;
+        bool last = done == total_bytes;
+        blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
+        if (last) break;
+    }
+    out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]);
+    out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+
+// Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
+__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log) {
+    for (int lg = (int)top_log - 1; lg >= 0; lg--) {
+        const uint4* prev = layers[lg + 1];
+        uint4* out = layers[lg];
+        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
+            u32 h[8], m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
+            h[0] ^= 0x01010020u;
+            uint4 a = prev[4 * i], b = prev[4 * i + 1], c = prev[4 * i + 2], d = prev[4 * i + 3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+            blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+            out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log) {
+    u32 n = 1u << log;
+    u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
+    hipLaunchKernelGGL(k_merkle_layer, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n);
+}
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log);
+}
+
+// Proof-of-work search (GrindOps::grind): smallest nonce whose mix_u64 digest has >= pow_bits trailing zero bits
+// (trailing_zeros of the first 16 digest bytes as LE u128). Each launch scans `span` nonces from `base`; the minimum hit is kept.
+__global__ void k_grind(const u32* __restrict__ digest, u64 base, u32 pow_bits, unsigned long long* __restrict__ best) {
+    u64 nonce = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 h[8], m[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = digest[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = 0;
+    m[0] = (u32)nonce; m[1] = (u32)(nonce >> 32);
+    blake2s_compress(h, m, 0, 0);
+    u32 tz = h[0] ? __ffs(h[0]) - 1 : h[1] ? 32 + __ffs(h[1]) - 1 : h[2] ? 64 + __ffs(h[2]) - 1 : h[3] ? 96 + __ffs(h[3]) - 1 : 128;
+    if (tz >= pow_bits) atomicMin(best, (unsigned long long)nonce);
+}
+void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best) {
+    hipLaunchKernelGGL(k_grind, dim3(span / 256), dim3(256), 0, stream, d_digest, base, pow_bits, d_best);
+}
+
+}  // namespace bf
