@@ -55,6 +55,17 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
  * CanonicCoset(log_eval).circle_domain(), log_eval >= log_size. replicated as above (output is row-granular, 2^(log_eval-4) cells). */
 int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* const* dst_cols_h, uint32_t n_cols, uint32_t log_size, uint32_t log_eval, int32_t replicated);
 
+/* prove_brainfuck (crates/brainfuck_prover/src/brainfuck_air/mod.rs:471-735), device resident: compiles and runs `code` on the
+ * host VM (crates/brainfuck_vm), builds the 13 component tables, then commits, evaluates constraints, samples, builds the FRI
+ * quotients, runs FRI, grinds and decommits on the GPU. *proof_json receives the serde_json form of BrainfuckProof (mod.rs:71-76),
+ * malloc'd — release with bfhip_free_host. log_max_rows = LOG_MAX_ROWS (mod.rs:428: 24; 20 under cfg(test), mod.rs:433); the
+ * context must have been created with max_log_domain >= log_max_rows + 2.
+ * transcript (optional): channel digests after each stage, "name:hex\n". phase_seconds (optional): 10 doubles
+ * {preprocessed, tables(host), main_trace, interaction, composition, oods, quotients, fri(+pow+decommit), decommit, total}. */
+int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
+                              char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
+void bfhip_free_host(void* p);
+
 #ifdef __cplusplus
 }
 #endif

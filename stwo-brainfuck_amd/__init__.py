@@ -97,3 +97,31 @@ class Context:
         tw, itw, rl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
         _check(lib().bfhip_twiddles(self._h, ctypes.byref(tw), ctypes.byref(itw), ctypes.byref(rl)))
         return tw.value, itw.value, rl.value
+
+
+PHASES = ("preprocessed", "tables_host", "main_trace", "interaction", "composition", "oods", "quotients", "fri", "decommit", "total")
+
+
+def prove_brainfuck(code, input_bytes=b"", ctx=None, log_max_rows=24, with_transcript=False, with_timings=False):
+    """prove_brainfuck (mod.rs:471): returns the proof as serde_json bytes of BrainfuckProof. GPU only."""
+    own = ctx is None
+    if own:
+        ctx = Context(0, max_log_domain=log_max_rows + 2)
+    try:
+        js, n, tr = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_void_p()
+        times = (ctypes.c_double * 10)()
+        _check(lib().bfhip_prove_brainfuck(ctx._h, code.encode(), input_bytes, ctypes.c_size_t(len(input_bytes)), log_max_rows,
+                                           ctypes.byref(js), ctypes.byref(n), ctypes.byref(tr) if with_transcript else None, times))
+        proof = ctypes.string_at(js, n.value)
+        lib().bfhip_free_host(js)
+        out = [proof]
+        if with_transcript:
+            t = ctypes.string_at(tr).decode()
+            lib().bfhip_free_host(tr)
+            out.append(dict(line.split(":") for line in t.strip().split("\n")))
+        if with_timings:
+            out.append(dict(zip(PHASES, list(times))))
+        return out[0] if len(out) == 1 else tuple(out)
+    finally:
+        if own:
+            ctx.close()

@@ -1,0 +1,212 @@
+// The 13 Brainfuck AIRs as host/device templates over an "EvalAtRow"-shaped evaluator — SURVEY.md §8 row a6.
+// Mirrors `FrameworkEval::evaluate` of crates/brainfuck_prover/src/components/**/component.rs (cited per function) and the
+// logUp bookkeeping stwo's `EvalAtRow::{add_to_relation, finalize_logup}` performs for them (is_first variant: the first
+// fraction of a row fetches IsFirst(log_size); the last logUp column carries mask offsets {0, -1}).
+// Two evaluators use these bodies: the gfx950 constraint kernels (air.hip, F = M31 at an LDE row) and the host-side
+// out-of-domain evaluator (host/prover.h, F = QM31 at the OODS point; stwo's PointEvaluator).
+#pragma once
+#include "m31.h"
+
+namespace bf {
+
+enum ComponentId { C_MEMORY = 0, C_INSTRUCTION, C_PROGRAM, C_PROCESSOR, C_JNZ, C_JZ, C_INPUT, C_LEFT, C_MINUS, C_OUTPUT, C_PLUS, C_RIGHT, C_EOE, N_COMPONENTS };
+enum : u32 { OP_RIGHT = '>', OP_LEFT = '<', OP_PLUS = '+', OP_MINUS = '-', OP_PUTCHAR = '.', OP_READCHAR = ',', OP_JZ = '[', OP_JNZ = ']' };
+
+// (main columns, logUp columns) per component — TraceColumn::count() in each table.rs
+BF_HD u32 n_main_cols(int c) { const u32 t[N_COMPONENTS] = {8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7}; return t[c]; }
+BF_HD u32 n_logup_cols(int c) { return c == C_PROCESSOR ? 3 : 1; }
+// own constraints + one per logUp column
+BF_HD u32 n_constraints(int c) { const u32 t[N_COMPONENTS] = {12, 11, 5, 10, 9, 9, 7, 7, 8, 8, 8, 7, 2}; return t[c]; }
+// components whose evaluate() fetches IsFirst itself (a second fetch always happens inside the logUp finalisation)
+BF_HD bool uses_is_first(int c) { return c <= C_PROCESSOR; }
+
+// ---- thin operator layer so the AIR bodies read like the reference -------------------------------------------------------
+struct Fm { u32 v; };
+BF_HD Fm operator+(Fm a, Fm b) { return {m_add(a.v, b.v)}; }
+BF_HD Fm operator-(Fm a, Fm b) { return {m_sub(a.v, b.v)}; }
+BF_HD Fm operator*(Fm a, Fm b) { return {m_mul(a.v, b.v)}; }
+struct Fq { Q31 v; };
+BF_HD Fq operator+(Fq a, Fq b) { return {q_add(a.v, b.v)}; }
+BF_HD Fq operator-(Fq a, Fq b) { return {q_sub(a.v, b.v)}; }
+BF_HD Fq operator*(Fq a, Fq b) { return {q_mul(a.v, b.v)}; }
+BF_HD Fq operator*(Fq a, Fm b) { return {q_mulm(a.v, b.v)}; }
+BF_HD Fq to_ef(Fm a) { return {q_from_m(a.v)}; }
+BF_HD Fq to_ef(Fq a) { return a; }
+
+// LookupElements<N>: z, alpha^0..alpha^6 (memory/table.rs:426-454, instruction/table.rs:391, processor/table.rs:393)
+struct Lookup { Q31 z; Q31 alpha_pow[7]; };
+struct Lookups { Lookup memory, instruction, processor; };
+BF_HD Lookup make_lookup(Q31 z, Q31 alpha) { Lookup l; l.z = z; Q31 cur = q_one(); for (int i = 0; i < 7; i++) { l.alpha_pow[i] = cur; cur = q_mul(cur, alpha); } return l; }
+
+template <class F> BF_HD Fq combine3(const Lookup& l, F a, F b, F c) {
+    return Fq{l.alpha_pow[0]} * a + Fq{l.alpha_pow[1]} * b + Fq{l.alpha_pow[2]} * c - Fq{l.z};
+}
+template <class F> BF_HD Fq combine7(const Lookup& l, F a, F b, F c, F d, F e, F f, F g) {
+    return Fq{l.alpha_pow[0]} * a + Fq{l.alpha_pow[1]} * b + Fq{l.alpha_pow[2]} * c + Fq{l.alpha_pow[3]} * d + Fq{l.alpha_pow[4]} * e +
+           Fq{l.alpha_pow[5]} * f + Fq{l.alpha_pow[6]} * g - Fq{l.z};
+}
+
+// Evaluator concept E:
+//   typename E::F;  F is_first();  F trace();  F cst(u32);
+//   void constraint(F) / constraint(Fq);
+//   void logup(Fq numerator, Fq denominator)   — one per add_to_relation, in order
+//   void finalize()                            — finalize_logup()
+
+// memory/component.rs:62-137
+template <class E> BF_HD void air_memory(E& e, const Lookups& el) {
+    typedef typename E::F F;
+    F is_first = e.is_first();
+    F clk = e.trace(), mp = e.trace(), mv = e.trace(), d = e.trace(), next_clk = e.trace(), next_mp = e.trace(), next_mv = e.trace(), next_d = e.trace();
+    F one = e.cst(1);
+    e.constraint(is_first * clk);
+    e.constraint(is_first * mp);
+    e.constraint(is_first * mv);
+    e.constraint(is_first * d);
+    e.constraint(d * (d - one));
+    e.constraint(next_d * (next_d - one));
+    e.constraint((next_mp - mp) * (next_mp - mp - one));
+    e.constraint((next_mp - mp - one) * (next_clk - clk - one));
+    e.constraint((next_mp - mp) * next_mv);
+    e.constraint(d * (next_mp - mp));
+    e.constraint(d * (next_mv - mv));
+    e.logup(to_ef(d - one), combine3(el.memory, clk, mp, mv));
+    e.finalize();
+}
+// instruction/component.rs:65-142
+template <class E> BF_HD void air_instruction(E& e, const Lookups& el) {
+    typedef typename E::F F;
+    F is_first = e.is_first();
+    F ip = e.trace(), ci = e.trace(), ni = e.trace(), d = e.trace(), next_ip = e.trace(), next_ci = e.trace(), next_ni = e.trace(), next_d = e.trace();
+    F one = e.cst(1);
+    e.constraint(is_first * ip);
+    e.constraint(d * (d - one));
+    e.constraint(next_d * (next_d - one));
+    e.constraint(d * ci);
+    e.constraint(d * ni);
+    e.constraint(next_d * next_ci);
+    e.constraint(next_d * next_ni);
+    e.constraint((next_ip - ip) * (next_ip - ip - one));
+    e.constraint((next_ip - ip - one) * (next_ci - ci));
+    e.constraint((next_ip - ip - one) * (next_ni - ni));
+    e.logup(to_ef(d - one), combine3(el.instruction, ip, ci, ni));
+    e.finalize();
+}
+// program/component.rs:60-104
+template <class E> BF_HD void air_program(E& e, const Lookups& el) {
+    typedef typename E::F F;
+    F is_first = e.is_first();
+    F ip = e.trace(), ci = e.trace(), ni = e.trace(), d = e.trace();
+    F one = e.cst(1);
+    e.constraint(is_first * ip);
+    e.constraint(d * (d - one));
+    e.constraint(d * ci);
+    e.constraint(d * ni);
+    e.logup(to_ef(one - d), combine3(el.instruction, ip, ci, ni));
+    e.finalize();
+}
+// processor/component.rs:79-153 — three relation entries in the order Processor, Instruction, Memory
+template <class E> BF_HD void air_processor(E& e, const Lookups& el) {
+    typedef typename E::F F;
+    F is_first = e.is_first();
+    F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace(), d = e.trace(), next_clk = e.trace();
+    F one = e.cst(1);
+    e.constraint(is_first * clk);
+    e.constraint(is_first * ip);
+    e.constraint(is_first * mp);
+    e.constraint(is_first * mv);
+    e.constraint(mv * (mv * mvi - one));
+    e.constraint(mvi * (mv * mvi - one));
+    e.constraint(next_clk - clk - one);
+    Fq num = Fq{q_one()} - to_ef(d);
+    e.logup(num, combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
+    e.logup(num, combine3(el.instruction, ip, ci, ni));
+    e.logup(num, combine3(el.memory, clk, mp, mv));
+    e.finalize();
+}
+// jump/jump_if_not_zero_component.rs:61-130, jump/jump_if_zero_component.rs:61-130
+template <class E> BF_HD void air_jump(E& e, const Lookups& el, bool if_zero) {
+    typedef typename E::F F;
+    F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace();
+    F next_clk = e.trace(), next_ip = e.trace(), next_mp = e.trace(), next_mv = e.trace(), d = e.trace(), is_mv_zero = e.trace();
+    F one = e.cst(1), two = e.cst(2);
+    e.constraint(ci * (ci - e.cst(if_zero ? OP_JZ : OP_JNZ)));
+    e.constraint(next_clk - clk - one);
+    e.constraint(d * (d - one));
+    e.constraint(d * mv);
+    e.constraint(d * ci);
+    if (if_zero) e.constraint((d - one) * (mv * (next_ip - ip - two) + is_mv_zero * (next_ip - (ni + one))));
+    else e.constraint((d - one) * (is_mv_zero * (next_ip - ip - two) + mv * (next_ip - ni)));
+    e.constraint(next_mp - mp);
+    e.constraint(next_mv - mv);
+    e.logup(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
+    e.finalize();
+}
+// processor/instructions/{input,left,minus,output,plus,right}_component.rs:62-122
+template <class E> BF_HD void air_instr(E& e, const Lookups& el, u32 opcode) {
+    typedef typename E::F F;
+    F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace(), d = e.trace();
+    F next_ip = e.trace(), next_mp = e.trace(), next_mv = e.trace();
+    F one = e.cst(1);
+    e.constraint(ci * (ci - e.cst(opcode)));
+    e.constraint(d * (d - one));
+    e.constraint(d * mv);
+    e.constraint(d * ci);
+    e.constraint((one - d) * (next_ip - ip - one));
+    if (opcode == OP_PLUS) { e.constraint(next_mp - mp); e.constraint((one - d) * (next_mv - mv - one)); }
+    else if (opcode == OP_MINUS) { e.constraint(next_mp - mp); e.constraint((one - d) * (next_mv - mv + one)); }
+    else if (opcode == OP_LEFT) e.constraint((one - d) * (next_mp - mp + one));
+    else if (opcode == OP_RIGHT) e.constraint((one - d) * (next_mp - mp - one));
+    else if (opcode == OP_READCHAR) e.constraint(next_mp - mp);
+    else { e.constraint(next_mp - mp); e.constraint(next_mv - mv); }   // OP_PUTCHAR
+    e.logup(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
+    e.finalize();
+}
+// end_of_execution/component.rs:61-90
+template <class E> BF_HD void air_eoe(E& e, const Lookups& el) {
+    typedef typename E::F F;
+    F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace();
+    e.constraint(ci);
+    e.logup(Fq{q_neg(q_one())}, combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
+    e.finalize();
+}
+
+template <int COMP, class E> BF_HD void air_eval(E& e, const Lookups& el) {
+    if (COMP == C_MEMORY) air_memory(e, el);
+    else if (COMP == C_INSTRUCTION) air_instruction(e, el);
+    else if (COMP == C_PROGRAM) air_program(e, el);
+    else if (COMP == C_PROCESSOR) air_processor(e, el);
+    else if (COMP == C_JNZ) air_jump(e, el, false);
+    else if (COMP == C_JZ) air_jump(e, el, true);
+    else if (COMP == C_INPUT) air_instr(e, el, OP_READCHAR);
+    else if (COMP == C_LEFT) air_instr(e, el, OP_LEFT);
+    else if (COMP == C_MINUS) air_instr(e, el, OP_MINUS);
+    else if (COMP == C_OUTPUT) air_instr(e, el, OP_PUTCHAR);
+    else if (COMP == C_PLUS) air_instr(e, el, OP_PLUS);
+    else if (COMP == C_RIGHT) air_instr(e, el, OP_RIGHT);
+    else air_eoe(e, el);
+}
+
+// logUp row machinery shared by evaluators (stwo LogupAtRow): up to 3 fractions; all but the last become `cur - prev_col`
+// constraints on single-offset columns, the last uses the {0,-1} masks and the IsFirst-corrected previous row.
+template <class D, class F_>
+struct LogupState {
+    Fq num[3], den[3]; int nf = 0; F_ lu_is_first; Q31 total_sum;
+    BF_HD D& self() { return *static_cast<D*>(this); }
+    BF_HD void logup(Fq n, Fq d) { if (nf == 0) lu_is_first = self().is_first(); num[nf] = n; den[nf] = d; nf++; }
+    BF_HD void finalize() {
+        Fq prev_col{q_zero()};
+        for (int k = 0; k + 1 < nf; k++) {
+            Fq cur = self().inter_cur();
+            Fq diff = cur - prev_col;
+            prev_col = cur;
+            self().constraint(diff * den[k] - num[k]);
+        }
+        Fq cur, prev_row;
+        self().inter_cur_prev(cur, prev_row);
+        Fq fixed_prev = prev_row - Fq{total_sum} * lu_is_first;
+        Fq diff = cur - fixed_prev - prev_col;
+        self().constraint(diff * den[nf - 1] - num[nf - 1]);
+    }
+};
+
+}  // namespace bf

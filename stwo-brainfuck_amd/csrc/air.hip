@@ -1,0 +1,269 @@
+// Constraint-quotient evaluation on the LDE domain and logUp interaction-trace generation (row a5).
+//
+// Constraint kernels replace stwo's `FrameworkComponent::evaluate_constraint_quotients_on_domain` (SimdBackend only upstream)
+// driven from prover::prove, crates/brainfuck_prover/src/brainfuck_air/mod.rs:732, over the 13 evals of
+// crates/brainfuck_prover/src/components/**/component.rs. One fused kernel per AIR: a lane owns one LDE row, reads every column of
+// the component exactly once (coalesced; 16x-replicated main columns are read row-granular), evaluates all constraints in M31,
+// the logUp constraints in QM31, combines them with the random-coefficient powers, multiplies by 1/vanishing and accumulates
+// into the per-size QM31 accumulator (4 x u32 SoA).
+//
+// logUp kernels replace `LogupTraceGenerator::{new_col, write_frac, finalize_col, finalize_last}` as used by the
+// interaction_trace_evaluation functions (memory/table.rs:485-518, instruction/table.rs:456, program/table.rs:233,
+// processor/table.rs:456-529, instructions/table.rs:466, jump/table.rs:436, end_of_execution/table.rs:220).
+#include "kernels.h"
+#include "air.h"
+
+namespace bf {
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Constraint evaluation
+// ------------------------------------------------------------------------------------------------------------------------------
+struct ConstraintArgs {
+    const u32* is_first;        // IsFirst(log_size) LDE column (2^(log_size+1) cells)
+    ColDesc trace[13];          // main LDE columns
+    ColDesc inter[12];          // interaction LDE columns, 4 per logUp column
+    u32* acc[4];                // accumulator (2^(log_size+1) cells per coordinate)
+    Q31 coeff[12];              // random-coefficient power for constraint j (already in "reversed" order)
+    Lookups el;
+    Q31 total_sum;
+    u32 denom_inv[2];           // 1/coset_vanishing on the two cosets of the LDE domain, indexed by row >> log_size
+    u32 log_size;
+};
+
+struct DomainEval : LogupState<DomainEval, Fm> {
+    typedef Fm F;
+    const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0; Q31 res;
+    __device__ DomainEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { res = q_zero(); total_sum = a_.total_sum; }
+    __device__ __forceinline__ Fm is_first() { return {a.is_first[row]}; }
+    __device__ __forceinline__ Fm trace() { ColDesc c = a.trace[ti++]; return {c.ptr[row >> c.shift]}; }
+    __device__ __forceinline__ Fm cst(u32 k) { return {k}; }
+    __device__ __forceinline__ Q31 rd(int i0, u32 r) {
+        return q_make(a.inter[i0].ptr[r >> a.inter[i0].shift], a.inter[i0 + 1].ptr[r >> a.inter[i0 + 1].shift],
+                      a.inter[i0 + 2].ptr[r >> a.inter[i0 + 2].shift], a.inter[i0 + 3].ptr[r >> a.inter[i0 + 3].shift]);
+    }
+    __device__ __forceinline__ Fq inter_cur() { Fq v{rd(ii, row)}; ii += 4; return v; }
+    __device__ __forceinline__ void inter_cur_prev(Fq& cur, Fq& prev) {
+        // previous trace row = point - trace_step: on the 2x LDE domain (bit-reversed storage) this is d-1 cyclic in the first
+        // half-coset and d+1 cyclic in the conjugate half (stwo offset_bit_reversed_circle_domain_index with offset -1).
+        u32 el = a.log_size + 1, half = 1u << a.log_size;
+        u32 d = bit_rev(row, el);
+        u32 pd = d < half ? ((d + half - 1) & (half - 1)) : (((d - half + 1) & (half - 1)) + half);
+        u32 pr = bit_rev(pd, el);
+        cur.v = rd(ii, row); prev.v = rd(ii, pr); ii += 4;
+    }
+    __device__ __forceinline__ void constraint(Fm c) { res = q_add(res, q_mulm(a.coeff[ci++], c.v)); }
+    __device__ __forceinline__ void constraint(Fq c) { res = q_add(res, q_mul(a.coeff[ci++], c.v)); }
+};
+
+template <int COMP>
+__global__ void __launch_bounds__(256) k_constraints(ConstraintArgs a) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (2u << a.log_size)) return;
+    DomainEval e(a, row);
+    air_eval<COMP>(e, a.el);
+    Q31 r = q_mulm(e.res, a.denom_inv[row >> a.log_size]);
+    a.acc[0][row] = m_add(a.acc[0][row], r.a.a);
+    a.acc[1][row] = m_add(a.acc[1][row], r.a.b);
+    a.acc[2][row] = m_add(a.acc[2][row], r.b.a);
+    a.acc[3][row] = m_add(a.acc[3][row], r.b.b);
+}
+
+template <int COMP>
+static void launch_c(hipStream_t s, const ConstraintArgs& a) {
+    u32 n = 2u << a.log_size;
+    hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch& L) {
+    ConstraintArgs a;
+    a.is_first = L.is_first;
+    for (int i = 0; i < 13; i++) a.trace[i] = L.trace[i];
+    for (int i = 0; i < 12; i++) a.inter[i] = L.inter[i];
+    for (int i = 0; i < 4; i++) a.acc[i] = L.acc[i];
+    for (int i = 0; i < 12; i++) a.coeff[i] = L.coeff[i];
+    a.el = L.el; a.total_sum = L.total_sum; a.denom_inv[0] = L.denom_inv[0]; a.denom_inv[1] = L.denom_inv[1]; a.log_size = L.log_size;
+    switch (comp) {
+        case C_MEMORY: launch_c<C_MEMORY>(stream, a); break;
+        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a); break;
+        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a); break;
+        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a); break;
+        case C_JNZ: launch_c<C_JNZ>(stream, a); break;
+        case C_JZ: launch_c<C_JZ>(stream, a); break;
+        case C_INPUT: launch_c<C_INPUT>(stream, a); break;
+        case C_LEFT: launch_c<C_LEFT>(stream, a); break;
+        case C_MINUS: launch_c<C_MINUS>(stream, a); break;
+        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a); break;
+        case C_PLUS: launch_c<C_PLUS>(stream, a); break;
+        case C_RIGHT: launch_c<C_RIGHT>(stream, a); break;
+        default: launch_c<C_EOE>(stream, a); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// logUp interaction trace
+// ------------------------------------------------------------------------------------------------------------------------------
+// Stage 1 — one lane per table row: fractions num/denom of every logUp column, running sum over columns.
+// Columns before the last are written row-granular (they are 16x-replicated like the main trace); the last column's
+// per-row value goes to `vrow` for the coset-order prefix sum.
+struct LogupArgs {
+    const u32* cols[13];        // row-granular main columns of the component
+    u32* out[8];                // row-granular coordinate columns of the non-last logUp columns (4 each)
+    uint4* vrow;                // per-row value of the last logUp column
+    Lookups el;
+    u32 n_rows;
+    int comp;
+};
+
+__device__ __forceinline__ Q31 logup_denominator(const LogupArgs& a, int rel, const u32* v) {
+    const Lookup& l = rel == 0 ? a.el.memory : rel == 1 ? a.el.instruction : a.el.processor;
+    int n = rel == 2 ? 7 : 3;
+    Q31 acc = q_zero();
+    for (int i = 0; i < n; i++) acc = q_add(acc, q_mulm(l.alpha_pow[i], v[i]));
+    return q_sub(acc, l.z);
+}
+
+__global__ void __launch_bounds__(256) k_logup_rows(LogupArgs a) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const int comp = a.comp;
+    u32 v[7];
+    Q31 cur = q_zero();
+    if (comp == C_PROCESSOR) {
+        // processor/table.rs:479-529: columns Processor(7), Instruction(3), Memory(3); numerator 1 - d
+        u32 reg[8];
+        for (int i = 0; i < 8; i++) reg[i] = a.cols[i][r];
+        Q31 num = q_subm(q_one(), reg[7]);
+        Q31 d0 = logup_denominator(a, 2, reg);
+        v[0] = reg[1]; v[1] = reg[2]; v[2] = reg[3];
+        Q31 d1 = logup_denominator(a, 1, v);
+        v[0] = reg[0]; v[1] = reg[4]; v[2] = reg[5];
+        Q31 d2 = logup_denominator(a, 0, v);
+        // one shared inversion (Montgomery trick) — results equal the three separate inverses
+        Q31 d01 = q_mul(d0, d1), inv_all = q_inv(q_mul(d01, d2));
+        Q31 i2 = q_mul(inv_all, d01), i01 = q_mul(inv_all, d2);
+        Q31 i0 = q_mul(i01, d1), i1 = q_mul(i01, d0);
+        cur = q_mul(num, i0);
+        a.out[0][r] = cur.a.a; a.out[1][r] = cur.a.b; a.out[2][r] = cur.b.a; a.out[3][r] = cur.b.b;
+        cur = q_add(cur, q_mul(num, i1));
+        a.out[4][r] = cur.a.a; a.out[5][r] = cur.a.b; a.out[6][r] = cur.b.a; a.out[7][r] = cur.b.b;
+        cur = q_add(cur, q_mul(num, i2));
+    } else {
+        int rel, dcol, mode;   // mode 0: d - 1, 1: 1 - d, 2: -1
+        if (comp == C_MEMORY) { rel = 0; dcol = 3; mode = 0; }
+        else if (comp == C_INSTRUCTION) { rel = 1; dcol = 3; mode = 0; }
+        else if (comp == C_PROGRAM) { rel = 1; dcol = 3; mode = 1; }
+        else if (comp == C_JNZ || comp == C_JZ) { rel = 2; dcol = 11; mode = 0; }
+        else if (comp == C_EOE) { rel = 2; dcol = -1; mode = 2; }
+        else { rel = 2; dcol = 7; mode = 0; }
+        int n = rel == 2 ? 7 : 3;
+        for (int i = 0; i < n; i++) v[i] = a.cols[i][r];
+        Q31 den = logup_denominator(a, rel, v);
+        Q31 num;
+        if (mode == 2) num = q_neg(q_one());
+        else { u32 d = a.cols[dcol][r]; num = mode == 0 ? q_subm(q_from_m(d), 1) : q_subm(q_one(), d); }
+        cur = q_mul(num, q_inv(den));
+    }
+    a.vrow[r] = make_uint4(cur.a.a, cur.a.b, cur.b.a, cur.b.b);
+}
+
+__device__ __forceinline__ Q31 q_ld(const uint4* p, u32 i) { uint4 v = p[i]; return q_make(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void q_st(uint4* p, u32 i, Q31 q) { p[i] = make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); }
+
+// Stage 2 — inclusive scan over R = bit_reverse(row) of w[R] = v[R] + v[M-1-R]  (M rows; see DESIGN.md "coset-order prefix sum").
+// Block-local scan of SCAN_TILE entries; block totals are scanned by k_scan_totals.
+static constexpr u32 SCAN_TILE = 1024;
+__global__ void __launch_bounds__(256) k_logup_scan_local(const uint4* __restrict__ vrow, uint4* __restrict__ wloc, uint4* __restrict__ totals, u32 log_rows) {
+    __shared__ uint4 s[SCAN_TILE];
+    u32 M = 1u << log_rows;
+    u32 base = blockIdx.x * SCAN_TILE;
+    for (u32 i = threadIdx.x; i < SCAN_TILE; i += blockDim.x) {
+        u32 R = base + i;
+        Q31 w = q_zero();
+        if (R < M) w = q_add(q_ld(vrow, bit_rev(R, log_rows)), q_ld(vrow, bit_rev(M - 1 - R, log_rows)));
+        q_st(s, i, w);
+    }
+    __syncthreads();
+    // Hillis-Steele over 1024 entries, 4 per thread
+    for (u32 off = 1; off < SCAN_TILE; off <<= 1) {
+        Q31 t[4];
+        for (u32 k = 0; k < 4; k++) { u32 i = threadIdx.x + k * 256; t[k] = i >= off ? q_add(q_ld(s, i), q_ld(s, i - off)) : q_ld(s, i); }
+        __syncthreads();
+        for (u32 k = 0; k < 4; k++) q_st(s, threadIdx.x + k * 256, t[k]);
+        __syncthreads();
+    }
+    for (u32 i = threadIdx.x; i < SCAN_TILE; i += blockDim.x) if (base + i < M) wloc[base + i] = s[i];
+    if (threadIdx.x == 0) totals[blockIdx.x] = s[SCAN_TILE - 1];
+}
+// Exclusive scan of the block totals (single workgroup, serial over chunks of 256); totals[nb] receives the grand total.
+__global__ void __launch_bounds__(256) k_scan_totals(uint4* __restrict__ totals, u32 nb) {
+    __shared__ uint4 s[256];
+    Q31 carry = q_zero();
+    for (u32 base = 0; base < nb; base += 256) {
+        u32 i = base + threadIdx.x;
+        Q31 v = i < nb ? q_ld(totals, i) : q_zero();
+        q_st(s, threadIdx.x, v);
+        __syncthreads();
+        for (u32 off = 1; off < 256; off <<= 1) {
+            Q31 t = threadIdx.x >= off ? q_add(q_ld(s, threadIdx.x), q_ld(s, threadIdx.x - off)) : q_ld(s, threadIdx.x);
+            __syncthreads();
+            q_st(s, threadIdx.x, t);
+            __syncthreads();
+        }
+        Q31 incl = q_ld(s, threadIdx.x);
+        Q31 excl = q_add(carry, q_sub(incl, v));
+        Q31 chunk_total = q_ld(s, 255);
+        __syncthreads();
+        if (i < nb) q_st(totals, i, excl);
+        carry = q_add(carry, chunk_total);
+    }
+    if (threadIdx.x == 0) q_st(totals, nb, carry);
+}
+// Stage 3 — write the last logUp column (4 coordinate columns of N = 16 M cells) and the claimed sum.
+// cell s = 16 r + l, R = bit_reverse(r), L = bit_reverse4(l):
+//   L <  8: S = L*Wtot + W[R] - v[M-1-R]     (even coset position 2q, q = L*M + R)
+//   L >= 8: S = (15-L)*Wtot + W[M-1-R]       (odd coset position)
+__global__ void __launch_bounds__(256) k_logup_last(const uint4* __restrict__ vrow, const uint4* __restrict__ wloc, const uint4* __restrict__ totals, u32 nb,
+                                                    u32 log_rows, u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3, uint4* __restrict__ claimed) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 M = 1u << log_rows;
+    if (s >= 16 * M) return;
+    u32 r = s >> 4, l = s & 15;
+    u32 R = bit_rev(r, log_rows), L = bit_rev(l, 4);
+    Q31 wtot = q_ld(totals, nb);
+    Q31 res;
+    if (L < 8) {
+        Q31 W = q_add(q_ld(wloc, R), q_ld(totals, R / SCAN_TILE));
+        res = q_sub(q_add(q_mulm(wtot, L), W), q_ld(vrow, bit_rev(M - 1 - R, log_rows)));
+    } else {
+        u32 X = M - 1 - R;
+        Q31 W = q_add(q_ld(wloc, X), q_ld(totals, X / SCAN_TILE));
+        res = q_add(q_mulm(wtot, 15 - L), W);
+    }
+    o0[s] = res.a.a; o1[s] = res.a.b; o2[s] = res.b.a; o3[s] = res.b.b;
+    if (s == 0) q_st(claimed, 0, q_mulm(wtot, 8));
+}
+
+void logup_generate(hipStream_t stream, const LogupLaunch& L) {
+    LogupArgs a;
+    for (int i = 0; i < 13; i++) a.cols[i] = L.cols[i];
+    for (int i = 0; i < 8; i++) a.out[i] = L.out_rep[i];
+    a.vrow = (uint4*)L.vrow; a.el = L.el; a.n_rows = 1u << L.log_rows; a.comp = L.comp;
+    u32 M = a.n_rows;
+    hipLaunchKernelGGL(k_logup_rows, dim3((M + 255) / 256), dim3(256), 0, stream, a);
+    u32 nb = (M + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_logup_scan_local, dim3(nb), dim3(256), 0, stream, (const uint4*)L.vrow, (uint4*)L.wloc, (uint4*)L.totals, L.log_rows);
+    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, stream, (uint4*)L.totals, nb);
+    hipLaunchKernelGGL(k_logup_last, dim3((16 * M + 255) / 256), dim3(256), 0, stream, (const uint4*)L.vrow, (const uint4*)L.wloc, (const uint4*)L.totals, nb, L.log_rows,
+                       L.out_last[0], L.out_last[1], L.out_last[2], L.out_last[3], (uint4*)L.claimed);
+}
+
+// Broadcast upload helper (a14): rows -> 16 consecutive cells. Only used by the C-ABI when a caller wants the full-size column.
+__global__ void k_broadcast16(const u32* __restrict__ rows, u32* __restrict__ out, u32 n_cells) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cells) out[i] = rows[i >> 4];
+}
+void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells) {
+    hipLaunchKernelGGL(k_broadcast16, dim3((n_cells + 255) / 256), dim3(256), 0, stream, d_rows, d_out, n_cells);
+}
+
+}  // namespace bf

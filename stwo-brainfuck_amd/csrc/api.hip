@@ -6,7 +6,7 @@
 using namespace bf;
 
 static thread_local std::string g_err;
-struct bfhip_ctx { Ctx c; };
+void bfhip_set_error(const std::string& s) { g_err = s; }
 
 #define API_TRY try {
 #define API_CATCH } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -1; }
@@ -91,6 +91,7 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
     if (!replicated && log_size < 3) throw HipError("circle transforms need log_size >= 3");
     if (log_size > c.tw_root_log + 1) throw HipError("log_size exceeds the context's twiddle tree");
     u32 log = replicated ? log_size - 4 : log_size;
+    c.stage_checkpoint();
     auto* s = c.stage(src_cols_h, n_cols);
     auto* d = c.stage(dst_cols_h, n_cols);
     fft_batch(c.stream, true, (const u32* const*)s, (u32* const*)d, n_cols, log, log, !replicated, c.d_tw, c.d_itw, c.tw_root_log);
@@ -107,6 +108,7 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
     if (!replicated && log_eval < 3) throw HipError("circle transforms need log_eval >= 3");
     if (log_eval > c.tw_root_log + 1) throw HipError("log_eval exceeds the context's twiddle tree");
     u32 sh = replicated ? 4 : 0;
+    c.stage_checkpoint();
     auto* s = c.stage(coeff_cols_h, n_cols);
     auto* d = c.stage(dst_cols_h, n_cols);
     fft_batch(c.stream, false, (const u32* const*)s, (u32* const*)d, n_cols, log_eval - sh, log_size - sh, !replicated, c.d_tw, c.d_itw, c.tw_root_log);

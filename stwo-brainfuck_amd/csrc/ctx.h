@@ -39,7 +39,7 @@ struct Ctx {
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
     Arena arena;
     // pinned staging for pointer arrays / small parameter blocks
-    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 1 << 20, stage_used = 0;
+    char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
 
     void init(int dev, u32 max_log_domain);
     void destroy();
@@ -48,15 +48,20 @@ struct Ctx {
     template <class T>
     T* stage(const T* host, size_t n) {
         size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
-        if (stage_used + bytes > stage_bytes) { sync(); stage_used = 0; }
-        if (bytes > stage_bytes) throw HipError("stage block too large");
+        if (stage_used + bytes > stage_bytes) throw HipError("staging buffer exhausted (call stage_checkpoint() between operations)");
         memcpy(h_stage + stage_used, host, n * sizeof(T));
         BF_HIP(hipMemcpyAsync(d_stage + stage_used, h_stage + stage_used, n * sizeof(T), hipMemcpyHostToDevice, stream));
         T* r = reinterpret_cast<T*>(d_stage + stage_used);
         stage_used += bytes;
         return r;
     }
+    // Called at the start of every high-level operation: recycles the staging ring once it is half full (after a sync, so no
+    // in-flight kernel still reads parameter blocks from it).
+    void stage_checkpoint() { if (stage_used > stage_bytes / 2) { sync(); stage_used = 0; } }
     u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
 };
 
 }  // namespace bf
+
+struct bfhip_ctx { bf::Ctx c; };
+void bfhip_set_error(const std::string& s);

@@ -1,0 +1,94 @@
+// Host-side Blake2s-256 and the Fiat–Shamir channel (the transcript is tiny and serial, so it stays on the host; only roots,
+// sampled values and the FRI last layer cross PCIe). Mirrors stwo `Blake2sChannel` / `Blake2sMerkleChannel` as used at
+// crates/brainfuck_prover/src/brainfuck_air/mod.rs:485 (default()), :581/:721 (claim mixing via components/mod.rs:82,133),
+// :591 (draw_felts through LookupElements::draw) and inside prover::prove (:732).
+#pragma once
+#include "../m31.h"
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace bf {
+
+struct Hash32 { u8 b[32]; bool operator==(const Hash32& o) const { return memcmp(b, o.b, 32) == 0; } };
+
+namespace b2s {
+static const u32 IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+static const u8 SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+inline u32 ror(u32 x, int r) { return (x >> r) | (x << (32 - r)); }
+inline void compress(u32 h[8], const u32 m[16], u32 t0, u32 t1, u32 f0, u32 f1) {
+    u32 v[16];
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+    v[12] ^= t0; v[13] ^= t1; v[14] ^= f0; v[15] ^= f1;
+    auto G = [&](int a, int b, int c, int d, u32 x, u32 y) {
+        v[a] += v[b] + x; v[d] = ror(v[d] ^ v[a], 16); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 12);
+        v[a] += v[b] + y; v[d] = ror(v[d] ^ v[a], 8); v[c] += v[d]; v[b] = ror(v[b] ^ v[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+        const u8* s = SIGMA[r];
+        G(0, 4, 8, 12, m[s[0]], m[s[1]]); G(1, 5, 9, 13, m[s[2]], m[s[3]]); G(2, 6, 10, 14, m[s[4]], m[s[5]]); G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        G(0, 5, 10, 15, m[s[8]], m[s[9]]); G(1, 6, 11, 12, m[s[10]], m[s[11]]); G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+}
+// one-shot hash of a byte string
+inline Hash32 hash(const u8* data, size_t len) {
+    u32 h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010020u;
+    u64 t = 0;
+    u32 m[16];
+    while (len > 64) { memcpy(m, data, 64); t += 64; compress(h, m, (u32)t, (u32)(t >> 32), 0, 0); data += 64; len -= 64; }
+    u8 last[64] = {0};
+    memcpy(last, data, len);
+    memcpy(m, last, 64);
+    t += len;
+    compress(h, m, (u32)t, (u32)(t >> 32), 0xFFFFFFFFu, 0);
+    Hash32 out; memcpy(out.b, h, 32);
+    return out;
+}
+}  // namespace b2s
+
+struct Channel {
+    Hash32 digest; u32 n_sent = 0;
+    Channel() { memset(digest.b, 0, 32); }
+    void update(const Hash32& d) { digest = d; n_sent = 0; }
+    void mix_root(const Hash32& root) { u8 buf[64]; memcpy(buf, digest.b, 32); memcpy(buf + 32, root.b, 32); update(b2s::hash(buf, 64)); }
+    void mix_felts(const Q31* f, size_t n) {
+        std::vector<u8> buf(32 + 16 * n);
+        memcpy(buf.data(), digest.b, 32);
+        for (size_t i = 0; i < n; i++) { u32 w[4] = {f[i].a.a, f[i].a.b, f[i].b.a, f[i].b.b}; memcpy(buf.data() + 32 + 16 * i, w, 16); }
+        update(b2s::hash(buf.data(), buf.size()));
+    }
+    void mix_u64(u64 v) {
+        u32 h[8]; memcpy(h, digest.b, 32);
+        u32 m[16] = {0}; m[0] = (u32)v; m[1] = (u32)(v >> 32);
+        b2s::compress(h, m, 0, 0, 0, 0);
+        Hash32 d; memcpy(d.b, h, 32); update(d);
+    }
+    Hash32 draw_random_bytes() { u8 buf[64] = {0}; memcpy(buf, digest.b, 32); memcpy(buf + 32, &n_sent, 4); n_sent++; return b2s::hash(buf, 64); }
+    void draw_base_felts(u32 out[8]) {
+        for (;;) {
+            Hash32 r = draw_random_bytes();
+            u32 w[8]; memcpy(w, r.b, 32);
+            bool ok = true;
+            for (int i = 0; i < 8; i++) ok = ok && w[i] < 2 * P31;
+            if (!ok) continue;
+            for (int i = 0; i < 8; i++) out[i] = w[i] >= P31 ? w[i] - P31 : w[i];
+            return;
+        }
+    }
+    Q31 draw_felt() { u32 f[8]; draw_base_felts(f); return q_make(f[0], f[1], f[2], f[3]); }
+    void draw_two_felts(Q31& a, Q31& b) { u32 f[8]; draw_base_felts(f); a = q_make(f[0], f[1], f[2], f[3]); b = q_make(f[4], f[5], f[6], f[7]); }
+    u32 trailing_zeros() const {
+        u64 lo, hi; memcpy(&lo, digest.b, 8); memcpy(&hi, digest.b + 8, 8);
+        return lo ? (u32)__builtin_ctzll(lo) : hi ? 64 + (u32)__builtin_ctzll(hi) : 128;
+    }
+};
+
+}  // namespace bf

@@ -1,0 +1,63 @@
+// Proof object and its serde_json-compatible (compact) serialisation — the "proof bytes" of the metric.
+// Shapes follow the derives at crates/brainfuck_prover/src/brainfuck_air/mod.rs:71-99 (BrainfuckProof, BrainfuckClaim),
+// :170-185 (BrainfuckInteractionClaim), components/mod.rs:71-93 (Claim{log_size,_marker}, InteractionClaim{claimed_sum}) and
+// stwo's StarkProof(CommitmentSchemeProof{commitments, sampled_values, decommitments, queried_values, proof_of_work, fri_proof}).
+#pragma once
+#include "hash.h"
+#include "tables.h"
+#include <string>
+
+namespace bf {
+
+struct MerkleDecommitment { std::vector<Hash32> hash_witness; std::vector<u32> column_witness; };
+struct FriLayerProof { std::vector<Q31> fri_witness; MerkleDecommitment decommitment; Hash32 commitment; };
+struct FriProof { FriLayerProof first_layer; std::vector<FriLayerProof> inner_layers; std::vector<Q31> last_layer_coeffs; u32 last_layer_log_size = 0; };
+struct StarkProof {
+    std::vector<Hash32> commitments;
+    std::vector<std::vector<std::vector<Q31>>> sampled_values;
+    std::vector<MerkleDecommitment> decommitments;
+    std::vector<std::vector<u32>> queried_values;
+    u64 proof_of_work = 0;
+    FriProof fri_proof;
+};
+struct BrainfuckProof { u32 log_sizes[N_COMPONENTS]; Q31 claimed_sums[N_COMPONENTS]; StarkProof proof; };
+
+namespace json {
+inline void num(std::string& s, u64 v) { char buf[24]; int n = 0; if (!v) buf[n++] = '0'; while (v) { buf[n++] = (char)('0' + v % 10); v /= 10; } while (n) s.push_back(buf[--n]); }
+inline void qm31(std::string& s, const Q31& q) { s += "[["; num(s, q.a.a); s += ','; num(s, q.a.b); s += "],["; num(s, q.b.a); s += ','; num(s, q.b.b); s += "]]"; }
+inline void hash(std::string& s, const Hash32& h) { s += '['; for (int i = 0; i < 32; i++) { if (i) s += ','; num(s, h.b[i]); } s += ']'; }
+template <class T, class Fn> void arr(std::string& s, const std::vector<T>& v, Fn f) { s += '['; for (size_t i = 0; i < v.size(); i++) { if (i) s += ','; f(v[i]); } s += ']'; }
+inline void decommitment(std::string& s, const MerkleDecommitment& d) {
+    s += "{\"hash_witness\":"; arr(s, d.hash_witness, [&](const Hash32& h) { hash(s, h); });
+    s += ",\"column_witness\":"; arr(s, d.column_witness, [&](u32 v) { num(s, v); }); s += '}';
+}
+inline void fri_layer(std::string& s, const FriLayerProof& l) {
+    s += "{\"fri_witness\":"; arr(s, l.fri_witness, [&](const Q31& q) { qm31(s, q); });
+    s += ",\"decommitment\":"; decommitment(s, l.decommitment);
+    s += ",\"commitment\":"; hash(s, l.commitment); s += '}';
+}
+}  // namespace json
+
+inline std::string proof_to_json(const BrainfuckProof& bp) {
+    using namespace json;
+    std::string s;
+    s.reserve(1 << 17);
+    s += "{\"claim\":{";
+    for (int c = 0; c < N_COMPONENTS; c++) { if (c) s += ','; s += '"'; s += COMPONENT_NAMES[c]; s += "\":{\"log_size\":"; num(s, bp.log_sizes[c]); s += ",\"_marker\":null}"; }
+    s += "},\"interaction_claim\":{";
+    for (int c = 0; c < N_COMPONENTS; c++) { if (c) s += ','; s += '"'; s += COMPONENT_NAMES[c]; s += "\":{\"claimed_sum\":"; qm31(s, bp.claimed_sums[c]); s += '}'; }
+    const StarkProof& p = bp.proof;
+    s += "},\"proof\":{\"commitments\":"; arr(s, p.commitments, [&](const Hash32& h) { hash(s, h); });
+    s += ",\"sampled_values\":";
+    arr(s, p.sampled_values, [&](const std::vector<std::vector<Q31>>& t) { arr(s, t, [&](const std::vector<Q31>& c) { arr(s, c, [&](const Q31& q) { qm31(s, q); }); }); });
+    s += ",\"decommitments\":"; arr(s, p.decommitments, [&](const MerkleDecommitment& d) { decommitment(s, d); });
+    s += ",\"queried_values\":"; arr(s, p.queried_values, [&](const std::vector<u32>& v) { arr(s, v, [&](u32 x) { num(s, x); }); });
+    s += ",\"proof_of_work\":"; num(s, p.proof_of_work);
+    s += ",\"fri_proof\":{\"first_layer\":"; fri_layer(s, p.fri_proof.first_layer);
+    s += ",\"inner_layers\":"; arr(s, p.fri_proof.inner_layers, [&](const FriLayerProof& l) { fri_layer(s, l); });
+    s += ",\"last_layer_poly\":{\"coeffs\":"; arr(s, p.fri_proof.last_layer_coeffs, [&](const Q31& q) { qm31(s, q); });
+    s += ",\"log_size\":"; num(s, p.fri_proof.last_layer_log_size); s += "}}}}";
+    return s;
+}
+
+}  // namespace bf

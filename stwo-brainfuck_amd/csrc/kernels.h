@@ -2,8 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "m31.h"
+#include "air.h"
 
 namespace bf {
+
+// A column in HBM. shift = 0: one u32 per domain cell. shift = 4: one u32 per table row, standing for a column whose values
+// are broadcast into 16 consecutive cells (reference: memory/table.rs:95-104) — cell i reads ptr[i >> 4].
+struct ColDesc { const u32* ptr; u32 shift; u32 pad_; };
 
 // fft.hip
 void gen_twiddles(hipStream_t stream, u32* d_tw, u32* d_itw, u32 R, const uint2* d_tlo, const uint2* d_thi);
@@ -12,5 +17,40 @@ void gen_twiddles(hipStream_t stream, u32* d_tw, u32* d_itw, u32 R, const uint2*
 // circle = false selects "line mode" (no circle layer) used for 16x-replicated columns stored row-granular.
 void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* const* d_dst, u32 ncols, u32 log, u32 src_log, bool circle,
                const u32* tw, const u32* itw, u32 tw_root_log);
+
+// merkle.hip
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log);
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
+void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
+
+// air.hip
+struct ConstraintLaunch {
+    const u32* is_first; ColDesc trace[13]; ColDesc inter[12]; u32* acc[4]; Q31 coeff[12]; Lookups el; Q31 total_sum; u32 denom_inv[2]; u32 log_size;
+};
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch& L);
+struct LogupLaunch {
+    const u32* cols[13];   // row-granular main columns
+    u32* out_rep[8];       // row-granular coordinate columns of the non-last logUp columns
+    u32* out_last[4];      // full-size coordinate columns of the last logUp column (16 * 2^log_rows cells)
+    void* vrow; void* wloc; void* totals; void* claimed;   // scratch: uint4[M], uint4[M], uint4[M/1024 + 2], uint4[1]
+    Lookups el; u32 log_rows; int comp;
+};
+void logup_generate(hipStream_t stream, const LogupLaunch& L);
+void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells);
+
+// quotient.hip
+struct EvalJob { const u32* coeffs; u32 log_n; u32 point; u32 factor_shift; u32 partial_off; };
+void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 max_log_n, const void* d_factors, void* d_partials, void* d_out);
+struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; u32 pad_[3]; };
+struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
+struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; };
+void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log);
+void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log);
+struct GatherReq { const u32* base; u64 index; };
+void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
+void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);
+void bit_reverse(hipStream_t stream, const u32* src, u32* dst, u32 log);
+void one_hot(hipStream_t stream, u32* dst, u32 n);
 
 }  // namespace bf

@@ -1,0 +1,717 @@
+// Device-resident counterpart of prove_brainfuck (crates/brainfuck_prover/src/brainfuck_air/mod.rs:471-735) and of the stwo
+// driver code it calls (CommitmentSchemeProver / TreeBuilder / prover::prove / FriProver). Everything that touches a column runs
+// in the gfx950 kernels; the host keeps only the Fiat–Shamir channel, the sample/batch bookkeeping and the decommitment control
+// flow (which depends on query positions, never on column data). There is no CPU fallback for any column operation.
+#include "../../include/bfhip.h"
+#include "ctx.h"
+#include "host/circle.h"
+#include "host/proof.h"
+#include <map>
+#include <set>
+#include <chrono>
+#include <algorithm>
+#include <cstdio>
+
+namespace bf {
+
+struct PcsConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_bound = 0, n_queries = 3; };  // PcsConfig::default() (mod.rs:479)
+
+struct DCol {
+    u32* ptr = nullptr; u32 log_size = 0; u32 shift = 0;   // 2^log_size domain cells, stored as 2^(log_size - shift) u32
+    size_t stored() const { return size_t(1) << (log_size - shift); }
+    ColDesc desc() const { return ColDesc{ptr, shift, 0}; }
+};
+struct DevMerkle { std::vector<u32*> layers; u32 max_log = 0; Hash32 root; };
+struct DTree { std::vector<DCol> polys, evals; DevMerkle mk; };
+struct DSecure { u32* c[4]; u32 log_size; };
+
+struct Gather {
+    std::vector<GatherReq> reqs;
+    size_t add(const u32* base, u64 idx) { reqs.push_back({base, idx}); return reqs.size() - 1; }
+    size_t add_col(const DCol& col, u64 cell) { return add(col.ptr, cell >> col.shift); }
+    std::vector<u32> run(Ctx& c) {
+        std::vector<u32> out(reqs.size());
+        const size_t CH = 32768;
+        for (size_t o = 0; o < reqs.size(); o += CH) {
+            size_t n = std::min(CH, reqs.size() - o);
+            c.stage_checkpoint();
+            GatherReq* d = c.stage(reqs.data() + o, n);
+            u32* dout = c.alloc_u32(n);
+            gather_u32(c.stream, d, (u32)n, dout);
+            BF_HIP(hipMemcpyAsync(out.data() + o, dout, n * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+            c.sync();
+        }
+        return out;
+    }
+};
+
+struct PhaseTimes { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, decommit = 0, tables = 0, total = 0; };
+
+struct HipProver {
+    Ctx& c;
+    PcsConfig cfg;
+    u32 log_max_rows;
+    Channel ch;
+    PhaseTimes tm;
+    std::string transcript;   // "name:hexdigest\n" per stage, for divergence hunting against the oracle
+    bool want_transcript = false;
+
+    HipProver(Ctx& ctx, u32 lmr) : c(ctx), log_max_rows(lmr) {}
+
+    void tap(const char* name) {
+        if (!want_transcript) return;
+        char buf[3]; transcript += name; transcript += ':';
+        for (int i = 0; i < 32; i++) { snprintf(buf, sizeof buf, "%02x", ch.digest.b[i]); transcript += buf; }
+        transcript += '\n';
+    }
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // ---- batched FFT over heterogeneous columns: group by (size, storage) --------------------------------------------------
+    void fft_cols(bool inverse, const std::vector<DCol>& src, const std::vector<DCol>& dst) {
+        c.stage_checkpoint();
+        std::map<std::pair<u32, u32>, std::vector<size_t>> groups;   // (dst log_size, shift) -> indices
+        for (size_t i = 0; i < dst.size(); i++) groups[{dst[i].log_size, dst[i].shift}].push_back(i);
+        for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
+            const auto& idx = it->second;
+            u32 log = it->first.first, sh = it->first.second;
+            // split further by source size (forward transforms may extend from different coefficient sizes)
+            std::map<u32, std::vector<size_t>> by_src;
+            for (size_t i : idx) by_src[src[i].log_size].push_back(i);
+            for (auto& kv : by_src) {
+                std::vector<const u32*> s; std::vector<u32*> d;
+                for (size_t i : kv.second) { s.push_back(src[i].ptr); d.push_back(dst[i].ptr); }
+                const u32* const* ds = c.stage(s.data(), s.size());
+                u32* const* dd = c.stage(d.data(), d.size());
+                fft_batch(c.stream, inverse, ds, dd, (u32)s.size(), log - sh, kv.first - sh, sh == 0, c.d_tw, c.d_itw, c.tw_root_log);
+            }
+        }
+        BF_HIP(hipGetLastError());
+    }
+
+    // ---- Merkle (a4) -----------------------------------------------------------------------------------------------------------
+    DevMerkle merkle_commit(const std::vector<DCol>& cols_in) {
+        std::vector<DCol> cols = cols_in;
+        std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
+        c.stage_checkpoint();
+        DevMerkle mk;
+        mk.max_log = cols[0].log_size;
+        mk.layers.resize(mk.max_log + 1);
+        for (u32 l = 0; l <= mk.max_log; l++) mk.layers[l] = (u32*)c.arena.alloc(size_t(32) << l);
+        u32 min_col_log = cols.back().log_size;
+        size_t ci = 0;
+        u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
+        for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
+            std::vector<ColDesc> lc;
+            while (ci < cols.size() && cols[ci].log_size == (u32)log) lc.push_back(cols[ci++].desc());
+            const ColDesc* d = lc.empty() ? nullptr : c.stage(lc.data(), lc.size());
+            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, d, (u32)lc.size(), (u32)log);
+        }
+        if (fused_top > 0) {
+            void* const* dl = (void* const*)c.stage(mk.layers.data(), mk.layers.size());
+            merkle_top(c.stream, dl, fused_top);
+        }
+        BF_HIP(hipGetLastError());
+        BF_HIP(hipMemcpyAsync(mk.root.b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        return mk;
+    }
+
+    // MerkleProver::decommit — control flow on the host, data through one gather.
+    void decommit(const DevMerkle& mk, const std::vector<DCol>& cols_in, const std::map<u32, std::vector<size_t>>& queries_per_log,
+                  std::vector<u32>& queried_values, MerkleDecommitment& dec) {
+        std::vector<DCol> cols = cols_in;
+        std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
+        Gather g;
+        struct Slot { int kind; size_t first; };   // kind 0: hash witness (8 words), 1: column witness, 2: queried value
+        std::vector<Slot> slots;
+        size_t ci = 0;
+        std::vector<size_t> last;
+        static const std::vector<size_t> empty;
+        for (int log = (int)mk.max_log; log >= 0; log--) {
+            std::vector<DCol> lc;
+            while (ci < cols.size() && cols[ci].log_size == (u32)log) lc.push_back(cols[ci++]);
+            const u32* prev_hashes = log < (int)mk.max_log ? mk.layers[log + 1] : nullptr;
+            auto it = queries_per_log.find((u32)log);
+            const std::vector<size_t>& colq = it == queries_per_log.end() ? empty : it->second;
+            std::vector<size_t> total;
+            size_t pi = 0, qi = 0;
+            while (pi < last.size() || qi < colq.size()) {
+                size_t node;
+                if (pi < last.size() && qi < colq.size()) node = std::min(last[pi] / 2, colq[qi]);
+                else if (pi < last.size()) node = last[pi] / 2;
+                else node = colq[qi];
+                if (prev_hashes) {
+                    for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
+                        if (pi < last.size() && last[pi] == child) pi++;
+                        else { size_t f = g.reqs.size(); for (u32 w = 0; w < 8; w++) g.add(prev_hashes, child * 8 + w); slots.push_back({0, f}); }
+                    }
+                }
+                bool queried = qi < colq.size() && colq[qi] == node;
+                if (queried) qi++;
+                for (auto& col : lc) { size_t f = g.add_col(col, node); slots.push_back({queried ? 2 : 1, f}); }
+                total.push_back(node);
+            }
+            last = total;
+        }
+        std::vector<u32> data = g.run(c);
+        for (auto& s : slots) {
+            if (s.kind == 0) { Hash32 h; memcpy(h.b, &data[s.first], 32); dec.hash_witness.push_back(h); }
+            else if (s.kind == 1) dec.column_witness.push_back(data[s.first]);
+            else queried_values.push_back(data[s.first]);
+        }
+    }
+
+    // CommitmentTreeProver::new: LDE by the blowup factor, Merkle, mix_root.
+    void commit_tree(DTree& t) {
+        t.evals.resize(t.polys.size());
+        for (size_t i = 0; i < t.polys.size(); i++) {
+            DCol e; e.log_size = t.polys[i].log_size + cfg.log_blowup; e.shift = t.polys[i].shift;
+            e.ptr = c.alloc_u32(e.stored());
+            t.evals[i] = e;
+        }
+        fft_cols(false, t.polys, t.evals);
+        t.mk = merkle_commit(t.evals);
+        ch.mix_root(t.mk.root);
+    }
+
+    // ---- host-side OODS evaluation of the constraints (stwo PointEvaluator) -------------------------------------------------------
+    struct PointEval : LogupState<PointEval, Fq> {
+        typedef Fq F;
+        Q31 preproc; const std::vector<Q31>* tvals; const std::vector<Q31>* ivals; int ti = 0, ii = 0;
+        Q31 denom_inverse, random_coeff; Q31* acc;
+        Fq is_first() { return {preproc}; }
+        Fq trace() { return {tvals[ti++][0]}; }
+        Fq cst(u32 k) { return {q_from_m(k)}; }
+        static Q31 combine(const std::vector<Q31>* v, int off) {
+            // SecureField::from_partial_evals: e0 + e1*i + e2*u + e3*iu
+            Q31 r = v[0][off];
+            r = q_add(r, q_mul(v[1][off], q_make(0, 1, 0, 0)));
+            r = q_add(r, q_mul(v[2][off], q_make(0, 0, 1, 0)));
+            r = q_add(r, q_mul(v[3][off], q_make(0, 0, 0, 1)));
+            return r;
+        }
+        Fq inter_cur() { Fq v{combine(ivals + ii, 0)}; ii += 4; return v; }
+        void inter_cur_prev(Fq& cur, Fq& prev) { cur.v = combine(ivals + ii, 0); prev.v = combine(ivals + ii, 1); ii += 4; }
+        void constraint(Fq cv) { *acc = q_add(q_mul(*acc, random_coeff), q_mul(denom_inverse, cv.v)); }
+    };
+    template <int COMP> static void point_eval_one(PointEval& pe, const Lookups& el) { air_eval<COMP>(pe, el); }
+    static void point_eval(int comp, PointEval& pe, const Lookups& el) {
+        switch (comp) {
+            case C_MEMORY: point_eval_one<C_MEMORY>(pe, el); break;
+            case C_INSTRUCTION: point_eval_one<C_INSTRUCTION>(pe, el); break;
+            case C_PROGRAM: point_eval_one<C_PROGRAM>(pe, el); break;
+            case C_PROCESSOR: point_eval_one<C_PROCESSOR>(pe, el); break;
+            case C_JNZ: point_eval_one<C_JNZ>(pe, el); break;
+            case C_JZ: point_eval_one<C_JZ>(pe, el); break;
+            case C_INPUT: point_eval_one<C_INPUT>(pe, el); break;
+            case C_LEFT: point_eval_one<C_LEFT>(pe, el); break;
+            case C_MINUS: point_eval_one<C_MINUS>(pe, el); break;
+            case C_OUTPUT: point_eval_one<C_OUTPUT>(pe, el); break;
+            case C_PLUS: point_eval_one<C_PLUS>(pe, el); break;
+            case C_RIGHT: point_eval_one<C_RIGHT>(pe, el); break;
+            default: point_eval_one<C_EOE>(pe, el); break;
+        }
+    }
+
+    struct PointLess {
+        bool operator()(const PtQ& a, const PtQ& b) const {
+            u32 av[8] = {a.x.a.a, a.x.a.b, a.x.b.a, a.x.b.b, a.y.a.a, a.y.a.b, a.y.b.a, a.y.b.b};
+            u32 bv[8] = {b.x.a.a, b.x.a.b, b.x.b.a, b.x.b.b, b.y.a.a, b.y.a.b, b.y.b.a, b.y.b.b};
+            for (int i = 0; i < 8; i++) if (av[i] != bv[i]) return av[i] < bv[i];
+            return false;
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    BrainfuckProof prove(const std::vector<Registers>& vm_trace, const std::vector<u32>& code) {
+        double t_start = now();
+        c.arena.reset();
+        ch = Channel();
+        if (log_max_rows + cfg.log_blowup + 1 > c.tw_root_log + 1) throw HipError("context twiddle tree too small for log_max_rows");
+        std::vector<DTree> trees(4);
+        BrainfuckProof bp;
+
+        // ---- Phase 0: preprocessed IsFirst(LOG_MAX_ROWS ..= LOG_N_LANES) (mod.rs:495-500) ---------------------------------
+        double t0 = now();
+        for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
+            DCol p; p.log_size = log; p.shift = 0; p.ptr = c.alloc_u32(p.stored());
+            one_hot(c.stream, p.ptr, 1u << log);
+            trees[0].polys.push_back(p);
+        }
+        fft_cols(true, trees[0].polys, trees[0].polys);
+        commit_tree(trees[0]);
+        tap("root0");
+        tm.preprocessed = now() - t0;
+
+        // ---- Phase 1: main trace (mod.rs:506-583) -----------------------------------------------------------------------------
+        t0 = now();
+        std::vector<Table> tables = build_tables(vm_trace, code);
+        tm.tables = now() - t0;
+        std::vector<std::vector<DCol>> rows(N_COMPONENTS);   // row-granular table columns (kept for the logUp pass)
+        size_t main_off[N_COMPONENTS], inter_off[N_COMPONENTS];
+        {
+            size_t mo = 0, io = 0;
+            for (int k = 0; k < N_COMPONENTS; k++) { main_off[k] = mo; inter_off[k] = io; mo += n_main_cols(k); io += 4 * n_logup_cols(k); }
+        }
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            bp.log_sizes[k] = tables[k].log_size();
+            if (bp.log_sizes[k] > log_max_rows) throw HipError("a component exceeds LOG_MAX_ROWS");
+            for (u32 j = 0; j < n_main_cols(k); j++) {
+                DCol r; r.log_size = bp.log_sizes[k]; r.shift = LOG_N_LANES; r.ptr = c.alloc_u32(r.stored());
+                BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+                rows[k].push_back(r);
+                DCol p = r; p.ptr = c.alloc_u32(p.stored());
+                trees[1].polys.push_back(p);
+            }
+        }
+        {
+            std::vector<DCol> src;
+            for (int k = 0; k < N_COMPONENTS; k++) for (auto& r : rows[k]) src.push_back(r);
+            fft_cols(true, src, trees[1].polys);
+        }
+        for (int k = 0; k < N_COMPONENTS; k++) ch.mix_u64(bp.log_sizes[k]);   // claim.mix_into (mod.rs:102-116)
+        commit_tree(trees[1]);
+        tap("root1");
+        tm.main_trace = now() - t0 - tm.tables;
+
+        // ---- Phase 2: interaction trace (mod.rs:589-723) ------------------------------------------------------------------------
+        t0 = now();
+        Lookups el;
+        { Q31 z, a; ch.draw_two_felts(z, a); el.memory = make_lookup(z, a); }         // MemoryElements::draw
+        { Q31 z, a; ch.draw_two_felts(z, a); el.instruction = make_lookup(z, a); }    // InstructionElements::draw
+        { Q31 z, a; ch.draw_two_felts(z, a); el.processor = make_lookup(z, a); }      // ProcessorElements::draw
+        uint4* d_claimed = (uint4*)c.arena.alloc(sizeof(uint4) * N_COMPONENTS);
+        std::vector<DCol> inter_vals;
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
+            size_t M = size_t(1) << log_rows;
+            LogupLaunch L{};
+            for (u32 j = 0; j < n_main_cols(k); j++) L.cols[j] = rows[k][j].ptr;
+            u32 nl = n_logup_cols(k);
+            for (u32 q = 0; q + 1 < nl; q++)
+                for (int w = 0; w < 4; w++) {
+                    DCol col; col.log_size = log; col.shift = LOG_N_LANES; col.ptr = c.alloc_u32(col.stored());
+                    L.out_rep[4 * q + w] = col.ptr; inter_vals.push_back(col);
+                }
+            for (int w = 0; w < 4; w++) {
+                DCol col; col.log_size = log; col.shift = 0; col.ptr = c.alloc_u32(col.stored());
+                L.out_last[w] = col.ptr; inter_vals.push_back(col);
+            }
+            L.vrow = c.arena.alloc(sizeof(uint4) * M);
+            L.wloc = c.arena.alloc(sizeof(uint4) * M);
+            L.totals = c.arena.alloc(sizeof(uint4) * (M / 1024 + 2));
+            L.claimed = d_claimed + k;
+            L.el = el; L.log_rows = log_rows; L.comp = k;
+            logup_generate(c.stream, L);
+        }
+        BF_HIP(hipGetLastError());
+        {
+            uint4 h_claimed[N_COMPONENTS];
+            BF_HIP(hipMemcpyAsync(h_claimed, d_claimed, sizeof(h_claimed), hipMemcpyDeviceToHost, c.stream));
+            c.sync();
+            for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
+        }
+        trees[2].polys = inter_vals;          // interpolate in place
+        fft_cols(true, inter_vals, trees[2].polys);
+        for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
+        commit_tree(trees[2]);
+        tap("root2");
+        tm.interaction = now() - t0;
+
+        // ---- prover::prove (mod.rs:732): composition polynomial -----------------------------------------------------------------
+        t0 = now();
+        Q31 random_coeff = ch.draw_felt();
+        compute_composition(trees, bp, main_off, inter_off, el, random_coeff);
+        commit_tree(trees[3]);
+        tap("root3");
+        tm.composition = now() - t0;
+
+        // ---- OODS sampling (a8) ------------------------------------------------------------------------------------------------------
+        t0 = now();
+        PtQ oods;
+        {
+            Q31 t = ch.draw_felt();
+            Q31 t2 = q_mul(t, t);
+            Q31 d = q_inv(q_addm(t2, 1));
+            oods.x = q_mul(q_sub(q_one(), t2), d);
+            oods.y = q_mul(q_add(t, t), d);
+        }
+        // sample points: index 0 = P, 1 + k = P - trace_step(component k)
+        std::vector<PtQ> points(1 + N_COMPONENTS);
+        points[0] = oods;
+        for (int k = 0; k < N_COMPONENTS; k++) points[1 + k] = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
+        // per tree, per column: list of point indices (Components::mask_points + composition mask)
+        std::vector<std::vector<std::vector<u32>>> mask(4);
+        mask[0].assign(trees[0].polys.size(), {});
+        for (int k = 0; k < N_COMPONENTS; k++) mask[0][log_max_rows - bp.log_sizes[k]] = {0};
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
+            u32 ni = 4 * n_logup_cols(k);
+            for (u32 j = 0; j < ni; j++) { if (j + 4 >= ni) mask[2].push_back({0, (u32)(1 + k)}); else mask[2].push_back({0}); }
+        }
+        mask[3].assign(4, {0});
+        sample(trees, mask, points, bp.proof);
+        {
+            std::vector<Q31> flat;
+            for (auto& t : bp.proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v);
+            ch.mix_felts(flat.data(), flat.size());
+        }
+        tap("sampled");
+        tm.oods = now() - t0;
+
+        // ---- FRI quotients (a9) --------------------------------------------------------------------------------------------------------
+        t0 = now();
+        Q31 q_coeff = ch.draw_felt();
+        std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff);
+        c.sync();
+        tm.quotients = now() - t0;
+
+        // ---- FRI commit (a10), proof of work (a11), decommitment (a12) -------------------------------------------------------------------
+        t0 = now();
+        fri_and_decommit(trees, quotients, bp.proof);
+        tm.fri = now() - t0;
+
+        // Sanity check of prover::prove: composition OODS value == constraints evaluated on the sampled mask values.
+        {
+            Q31 acc = q_zero();
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                PointEval pe;
+                const auto& pv = bp.proof.sampled_values[0][log_max_rows - bp.log_sizes[k]];
+                pe.preproc = pv[0];
+                pe.tvals = &bp.proof.sampled_values[1][main_off[k]];
+                pe.ivals = &bp.proof.sampled_values[2][inter_off[k]];
+                pe.denom_inverse = q_inv(coset_vanishing_q(bp.log_sizes[k], oods));
+                pe.random_coeff = random_coeff; pe.acc = &acc; pe.total_sum = bp.claimed_sums[k];
+                point_eval(k, pe, el);
+            }
+            const auto& cv = bp.proof.sampled_values[3];
+            std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
+            if (!q_eq(PointEval::combine(ce, 0), acc)) throw HipError("ConstraintsNotSatisfied");
+        }
+        tm.total = now() - t_start;
+        return bp;
+    }
+
+    // ComponentProvers::compute_composition_polynomial + DomainEvaluationAccumulator::finalize
+    void compute_composition(std::vector<DTree>& trees, const BrainfuckProof& bp, const size_t* main_off, const size_t* inter_off, const Lookups& el, Q31 random_coeff) {
+        u32 total = 0, max_log = 0;
+        for (int k = 0; k < N_COMPONENTS; k++) { total += n_constraints(k); max_log = std::max(max_log, bp.log_sizes[k] + 1); }
+        std::vector<Q31> powers(total);
+        { Q31 cur = q_one(); for (u32 i = 0; i < total; i++) { powers[i] = cur; cur = q_mul(cur, random_coeff); } }
+        std::vector<DSecure> acc(max_log + 1);
+        std::vector<bool> have(max_log + 1, false);
+        u32 remaining = total;
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            u32 log = bp.log_sizes[k], eval_log = log + 1, nc = n_constraints(k);
+            if (!have[eval_log]) {
+                acc[eval_log].log_size = eval_log;
+                for (int w = 0; w < 4; w++) { acc[eval_log].c[w] = c.alloc_u32(size_t(1) << eval_log); BF_HIP(hipMemsetAsync(acc[eval_log].c[w], 0, sizeof(u32) << eval_log, c.stream)); }
+                have[eval_log] = true;
+            }
+            ConstraintLaunch L{};
+            // accum.columns(): this component takes the LAST nc remaining powers and uses them reversed (constraint 0 <-> highest)
+            for (u32 j = 0; j < nc; j++) L.coeff[j] = powers[remaining - 1 - j];
+            remaining -= nc;
+            L.is_first = trees[0].evals[log_max_rows - log].ptr;
+            for (u32 j = 0; j < n_main_cols(k); j++) L.trace[j] = trees[1].evals[main_off[k] + j].desc();
+            for (u32 j = 0; j < 4 * n_logup_cols(k); j++) L.inter[j] = trees[2].evals[inter_off[k] + j].desc();
+            for (int w = 0; w < 4; w++) L.acc[w] = acc[eval_log].c[w];
+            L.el = el; L.total_sum = bp.claimed_sums[k]; L.log_size = log;
+            // denom_inv[i] = 1 / coset_vanishing(CanonicCoset(log).coset, eval_domain.at(i)), i in {0, 1} (bit-reversal of 2 entries = identity)
+            for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log, canonic_domain_at(eval_log, i)));
+            eval_constraints(c.stream, k, L);
+        }
+        BF_HIP(hipGetLastError());
+        // finalize: ascending sizes; evaluate the running polynomial on the next populated size, add, interpolate
+        bool cur_have = false; std::vector<DCol> cur(4);
+        for (u32 log = 1; log <= max_log; log++) {
+            if (!have[log]) continue;
+            std::vector<DCol> vals(4);
+            for (int w = 0; w < 4; w++) { vals[w].ptr = acc[log].c[w]; vals[w].log_size = log; vals[w].shift = 0; }
+            if (cur_have) {
+                std::vector<DCol> tmp(4);
+                for (int w = 0; w < 4; w++) { tmp[w].log_size = log; tmp[w].shift = 0; tmp[w].ptr = c.alloc_u32(size_t(1) << log); }
+                fft_cols(false, cur, tmp);
+                for (int w = 0; w < 4; w++) accumulate(c.stream, vals[w].ptr, tmp[w].ptr, 1u << log);
+            }
+            fft_cols(true, vals, vals);
+            cur = vals; cur_have = true;
+        }
+        trees[3].polys = cur;
+    }
+
+    // PolyOps::eval_at_point for every (column, mask point)
+    void sample(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, StarkProof& pf) {
+        // factor tables: F[0] = y, F[1] = x, F[b] = double_x^(b-1)(x); 32 entries per point
+        std::vector<uint4> factors(points.size() * 32, make_uint4(0, 0, 0, 0));
+        for (size_t p = 0; p < points.size(); p++) {
+            Q31 x = points[p].x;
+            auto pk = [](Q31 q) { return make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); };
+            factors[p * 32 + 0] = pk(points[p].y);
+            for (u32 b = 1; b < 32; b++) { factors[p * 32 + b] = pk(x); x = q_double_x(x); }
+        }
+        std::vector<EvalJob> jobs;
+        u32 max_log_n = 0, partial_off = 0;
+        for (size_t t = 0; t < trees.size(); t++)
+            for (size_t col = 0; col < trees[t].polys.size(); col++)
+                for (u32 pt : mask[t][col]) {
+                    const DCol& p = trees[t].polys[col];
+                    EvalJob j; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = partial_off;
+                    partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
+                    max_log_n = std::max(max_log_n, j.log_n);
+                    jobs.push_back(j);
+                }
+        uint4* d_factors = (uint4*)c.arena.alloc(factors.size() * sizeof(uint4));
+        BF_HIP(hipMemcpyAsync(d_factors, factors.data(), factors.size() * sizeof(uint4), hipMemcpyHostToDevice, c.stream));
+        EvalJob* d_jobs = (EvalJob*)c.arena.alloc(jobs.size() * sizeof(EvalJob));
+        BF_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(EvalJob), hipMemcpyHostToDevice, c.stream));
+        void* d_partials = c.arena.alloc(size_t(partial_off) * sizeof(uint4));
+        uint4* d_out = (uint4*)c.arena.alloc(jobs.size() * sizeof(uint4));
+        eval_at_points(c.stream, d_jobs, (u32)jobs.size(), max_log_n, d_factors, d_partials, d_out);
+        BF_HIP(hipGetLastError());
+        std::vector<uint4> out(jobs.size());
+        BF_HIP(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(uint4), hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        pf.sampled_values.resize(trees.size());
+        size_t ji = 0;
+        for (size_t t = 0; t < trees.size(); t++) {
+            pf.sampled_values[t].resize(trees[t].polys.size());
+            for (size_t col = 0; col < trees[t].polys.size(); col++)
+                for (size_t k = 0; k < mask[t][col].size(); k++, ji++) pf.sampled_values[t][col].push_back(q_make(out[ji].x, out[ji].y, out[ji].z, out[ji].w));
+        }
+    }
+
+    // compute_fri_quotients: one secure column per distinct LDE size, descending.
+    std::vector<DSecure> compute_quotients(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points,
+                                           const StarkProof& pf, Q31 random_coeff) {
+        struct FlatCol { DCol col; size_t tree, idx; };
+        std::vector<FlatCol> flat;
+        for (size_t t = 0; t < trees.size(); t++) for (size_t i = 0; i < trees[t].evals.size(); i++) flat.push_back({trees[t].evals[i], t, i});
+        std::stable_sort(flat.begin(), flat.end(), [](const FlatCol& a, const FlatCol& b) { return a.col.log_size > b.col.log_size; });
+        std::vector<DSecure> out;
+        for (size_t i = 0; i < flat.size();) {
+            size_t j = i; u32 log = flat[i].col.log_size;
+            while (j < flat.size() && flat[j].col.log_size == log) j++;
+            // ColumnSampleBatch::new_vec: group (column index in group, value) by point, ordered like BTreeMap<CirclePoint<QM31>, _>
+            std::map<PtQ, std::vector<std::pair<u32, Q31>>, PointLess> by_point;
+            std::vector<ColDesc> descs;
+            for (size_t k = i; k < j; k++) {
+                descs.push_back(flat[k].col.desc());
+                const auto& pts = mask[flat[k].tree][flat[k].idx];
+                for (size_t s = 0; s < pts.size(); s++) by_point[points[pts[s]]].push_back({(u32)(k - i), pf.sampled_values[flat[k].tree][flat[k].idx][s]});
+            }
+            std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
+            for (auto& kv : by_point) {
+                const PtQ& pt = kv.first;
+                QuotientBatch qb{};
+                qb.prx = pt.x.a; qb.pry = pt.y.a; qb.pix = pt.x.b; qb.piy = pt.y.b;
+                qb.a_sum = q_zero(); qb.b_sum = q_zero();
+                Q31 alpha = q_one();
+                for (auto& cv : kv.second) {
+                    alpha = q_mul(alpha, random_coeff);
+                    // complex_conjugate_line_coeffs: a = conj(v) - v, c = conj(P.y) - P.y, b = v*c - a*P.y; all scaled by alpha
+                    Q31 a = q_sub(q_conj(cv.second), cv.second);
+                    Q31 cc = q_sub(q_conj(pt.y), pt.y);
+                    Q31 b = q_sub(q_mul(cv.second, cc), q_mul(a, pt.y));
+                    qb.a_sum = q_add(qb.a_sum, q_mul(alpha, a));
+                    qb.b_sum = q_add(qb.b_sum, q_mul(alpha, b));
+                    QuotientEntry qe{}; qe.c = q_mul(alpha, cc); qe.col = cv.first;
+                    entries.push_back(qe);
+                }
+                qb.batch_coeff = q_pow(random_coeff, kv.second.size());
+                qb.n_cols = (u32)kv.second.size();
+                batches.push_back(qb);
+            }
+            c.stage_checkpoint();
+            DSecure q; q.log_size = log;
+            for (int w = 0; w < 4; w++) q.c[w] = c.alloc_u32(size_t(1) << log);
+            QuotientArgs a{};
+            a.cols = c.stage(descs.data(), descs.size());
+            a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
+            a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
+            a.n_batches = (u32)batches.size(); a.log = log; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;
+            for (int w = 0; w < 4; w++) a.out[w] = q.c[w];
+            accumulate_quotients(c.stream, a);
+            out.push_back(q);
+            i = j;
+        }
+        BF_HIP(hipGetLastError());
+        return out;
+    }
+
+    static std::vector<size_t> fold_queries(const std::vector<size_t>& q, u32 n) {
+        std::vector<size_t> o;
+        for (size_t x : q) { size_t y = x >> n; if (o.empty() || o.back() != y) o.push_back(y); }
+        return o;
+    }
+    // compute_decommitment_positions_and_witness_evals with fold_step = 1; witness values are gathered later.
+    static void positions_and_witness(const std::vector<size_t>& queries, std::vector<size_t>& positions, std::vector<size_t>& witness_pos) {
+        size_t i = 0;
+        while (i < queries.size()) {
+            size_t j = i;
+            while (j < queries.size() && (queries[j] >> 1) == (queries[i] >> 1)) j++;
+            size_t start = (queries[i] >> 1) << 1, qi = i;
+            for (size_t pos = start; pos < start + 2; pos++) {
+                positions.push_back(pos);
+                if (qi < j && queries[qi] == pos) { qi++; continue; }
+                witness_pos.push_back(pos);
+            }
+            i = j;
+        }
+    }
+    std::vector<Q31> gather_secure(const DSecure& s, const std::vector<size_t>& pos) {
+        Gather g;
+        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
+        auto d = g.run(c);
+        std::vector<Q31> out;
+        for (size_t k = 0; k < pos.size(); k++) out.push_back(q_make(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]));
+        return out;
+    }
+    static std::vector<DCol> secure_cols(const DSecure& s) {
+        std::vector<DCol> v(4);
+        for (int w = 0; w < 4; w++) { v[w].ptr = s.c[w]; v[w].log_size = s.log_size; v[w].shift = 0; }
+        return v;
+    }
+
+    void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf) {
+        // FriProver::commit — first layer: one Merkle tree over the coordinate columns of every quotient
+        std::vector<DCol> first_cols;
+        for (auto& q : quotients) for (auto& col : secure_cols(q)) first_cols.push_back(col);
+        DevMerkle first_tree = merkle_commit(first_cols);
+        ch.mix_root(first_tree.root);
+        struct Inner { DSecure ev; DevMerkle tree; };
+        std::vector<Inner> inner;
+        u32 line_log = quotients[0].log_size - 1;
+        DSecure layer; layer.log_size = line_log;
+        for (int w = 0; w < 4; w++) { layer.c[w] = c.alloc_u32(size_t(1) << line_log); BF_HIP(hipMemsetAsync(layer.c[w], 0, sizeof(u32) << line_log, c.stream)); }
+        size_t qi = 0;
+        Q31 alpha = ch.draw_felt();
+        u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
+        while (line_log > last_log) {
+            while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
+                const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
+                fold_circle_into_line(c.stream, layer.c, src, alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size);
+                qi++;
+            }
+            Inner in; in.ev = layer;
+            in.tree = merkle_commit(secure_cols(layer));
+            ch.mix_root(in.tree.root);
+            alpha = ch.draw_felt();
+            DSecure next; next.log_size = line_log - 1;
+            for (int w = 0; w < 4; w++) next.c[w] = c.alloc_u32(size_t(1) << (line_log - 1));
+            const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
+            fold_line(c.stream, next.c, src, alpha, c.d_itw, c.tw_root_log, line_log);
+            inner.push_back(in);
+            layer = next; line_log--;
+        }
+        if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
+        // last layer: 2^last_log evaluations -> line polynomial (host; LineEvaluation::interpolate on <= 2 values for the default config)
+        {
+            if (last_log != 1 || cfg.log_last_layer_degree_bound != 0) throw HipError("only the default FRI last-layer configuration is supported");
+            std::vector<size_t> pos = {0, 1};
+            auto v = gather_secure(layer, pos);
+            // line_ifft on 2 values over LineDomain(half_odds(1)): c0 = (v0 + v1) / 2, c1 = (v0 - v1) / (2 x0) must vanish
+            u32 inv2 = m_inv(2);
+            Q31 c0 = q_mulm(q_add(v[0], v[1]), inv2);
+            if (!q_eq(v[0], v[1])) throw HipError("invalid degree");
+            pf.fri_proof.last_layer_coeffs = {c0};
+            pf.fri_proof.last_layer_log_size = 0;
+            ch.mix_felts(&c0, 1);
+        }
+        tap("fri_commit");
+
+        // proof of work (GrindOps): GPU search in spans, smallest nonce wins
+        {
+            c.stage_checkpoint();
+            u32* d_digest = (u32*)c.stage(ch.digest.b, 32);
+            unsigned long long init = ~0ull;
+            unsigned long long* d_best = (unsigned long long*)c.stage(&init, 1);
+            unsigned long long best = ~0ull;
+            const u32 span = 1u << 16;
+            for (u64 base = 0; best == ~0ull; base += span) {
+                grind_span(c.stream, d_digest, base, span, cfg.pow_bits, d_best);
+                BF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c.stream));
+                c.sync();
+            }
+            pf.proof_of_work = best;
+            ch.mix_u64(best);
+        }
+
+        // FRI decommit
+        double t0 = now();
+        u32 max_log = quotients[0].log_size;
+        std::vector<size_t> queries;
+        {
+            std::set<size_t> qs; u32 cnt = 0; u32 maskq = (u32)((u64(1) << max_log) - 1);
+            while (cnt < cfg.n_queries) {
+                Hash32 r = ch.draw_random_bytes();
+                for (int k = 0; k < 8 && cnt < cfg.n_queries; k++) { u32 w; memcpy(&w, r.b + 4 * k, 4); qs.insert(w & maskq); cnt++; }
+            }
+            queries.assign(qs.begin(), qs.end());
+        }
+        std::map<u32, std::vector<size_t>> positions_by_log;
+        for (auto& q : quotients) positions_by_log[q.log_size] = fold_queries(queries, max_log - q.log_size);
+        {
+            std::map<u32, std::vector<size_t>> dpos;
+            for (auto& q : quotients) {
+                std::vector<size_t> pos, wpos;
+                positions_and_witness(fold_queries(queries, max_log - q.log_size), pos, wpos);
+                dpos[q.log_size] = pos;
+                auto w = gather_secure(q, wpos);
+                pf.fri_proof.first_layer.fri_witness.insert(pf.fri_proof.first_layer.fri_witness.end(), w.begin(), w.end());
+            }
+            std::vector<u32> unused;
+            decommit(first_tree, first_cols, dpos, unused, pf.fri_proof.first_layer.decommitment);
+            pf.fri_proof.first_layer.commitment = first_tree.root;
+        }
+        auto lq = fold_queries(queries, 1);
+        for (auto& in : inner) {
+            FriLayerProof lp;
+            std::vector<size_t> pos, wpos;
+            positions_and_witness(lq, pos, wpos);
+            lp.fri_witness = gather_secure(in.ev, wpos);
+            std::map<u32, std::vector<size_t>> dpos; dpos[in.ev.log_size] = pos;
+            std::vector<u32> unused;
+            decommit(in.tree, secure_cols(in.ev), dpos, unused, lp.decommitment);
+            lp.commitment = in.tree.root;
+            pf.fri_proof.inner_layers.push_back(std::move(lp));
+            lq = fold_queries(lq, 1);
+        }
+        for (auto& t : trees) {
+            std::vector<u32> qv; MerkleDecommitment d;
+            decommit(t.mk, t.evals, positions_by_log, qv, d);
+            pf.queried_values.push_back(qv);
+            pf.decommitments.push_back(d);
+            pf.commitments.push_back(t.mk.root);
+        }
+        tm.decommit = now() - t0;
+    }
+};
+
+}  // namespace bf
+
+using namespace bf;
+
+extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, uint32_t log_max_rows,
+                                          char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
+    try {
+        std::vector<u32> ins = compile(code);
+        Machine m(ins, std::vector<u8>(input, input + n_input));
+        m.execute();
+        HipProver pv(ctx->c, log_max_rows);
+        pv.want_transcript = transcript != nullptr;
+        BrainfuckProof bp = pv.prove(m.trace, ins);
+        std::string js = proof_to_json(bp);
+        *proof_json = (char*)malloc(js.size() + 1);
+        memcpy(*proof_json, js.c_str(), js.size() + 1);
+        *proof_len = js.size();
+        if (transcript) { *transcript = (char*)malloc(pv.transcript.size() + 1); memcpy(*transcript, pv.transcript.c_str(), pv.transcript.size() + 1); }
+        if (phase_seconds) {
+            const PhaseTimes& t = pv.tm;
+            double v[10] = {t.preprocessed, t.tables, t.main_trace, t.interaction, t.composition, t.oods, t.quotients, t.fri, t.decommit, t.total};
+            memcpy(phase_seconds, v, sizeof v);
+        }
+        return 0;
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
+}
+extern "C" void bfhip_free_host(void* p) { free(p); }

@@ -1,0 +1,247 @@
+// Out-of-domain sampling, DEEP/FRI quotients, FRI folding and query gathers for gfx950 — SURVEY.md §8 rows a8, a9, a10, a12.
+// Replaces stwo `PolyOps::eval_at_point`, `QuotientOps::accumulate_quotients`, `FriOps::{fold_circle_into_line, fold_line}` and
+// the column reads of the Merkle/FRI decommitment, all reached from prover::prove at
+// crates/brainfuck_prover/src/brainfuck_air/mod.rs:732 (CommitmentSchemeProver::prove_values).
+#include "kernels.h"
+
+namespace bf {
+
+__device__ __forceinline__ Q31 ld_q(const uint4* p, size_t i) { uint4 v = p[i]; return q_make(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 pk_q(Q31 q) { return make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// eval_at_point (a8): f(P) = sum_j c_j * prod_{b : bit b of j set} F[b],  F = [P.y, P.x, 2x^2-1, ...]  (stwo `fold`).
+// Stage 1: one workgroup folds a chunk of 4096 coefficients (16 per lane against a 16-entry weight table, then an LDS tree);
+// Stage 2: one workgroup per job folds the chunk partials with the remaining factors. Fixed reduction tree => deterministic.
+// Row-granular (replicated) coefficient columns hold only the coefficients of index 0 mod 16, so their factors start at F[4].
+// ------------------------------------------------------------------------------------------------------------------------------
+static constexpr u32 EAP_CHUNK_LOG = 12;
+
+__global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __restrict__ jobs, const uint4* __restrict__ factors, uint4* __restrict__ partials) {
+    const EvalJob job = jobs[blockIdx.y];
+    const u32 n = 1u << job.log_n;
+    const u32 chunk = blockIdx.x;
+    if (((u64)chunk << EAP_CHUNK_LOG) >= n) return;
+    __shared__ uint4 s_w[16];
+    __shared__ uint4 s_p[256];
+    const uint4* F = factors + (size_t)job.point * 32 + job.factor_shift;   // F[b] multiplies bit b of the (row-granular) index
+    const u32 t = threadIdx.x;
+    if (t < 16) {
+        Q31 w = q_one();
+        for (u32 b = 0; b < 4; b++) if ((t >> b) & 1) w = q_mul(w, ld_q(F, b));
+        s_w[t] = pk_q(w);
+    }
+    __syncthreads();
+    const u32 base = (chunk << EAP_CHUNK_LOG) + t * 16;
+    Q31 acc = q_zero();
+    if (base < n) {
+        if (n >= 16) {
+            const uint4* src = reinterpret_cast<const uint4*>(job.coeffs + base);
+#pragma unroll
+            for (u32 v4 = 0; v4 < 4; v4++) {
+                uint4 c = src[v4];
+                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 0), c.x));
+                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 1), c.y));
+                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 2), c.z));
+                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 3), c.w));
+            }
+        } else {
+            for (u32 k = 0; k < n; k++) acc = q_add(acc, q_mulm(ld_q(s_w, k), job.coeffs[k]));
+        }
+    }
+    s_p[t] = pk_q(acc);
+    __syncthreads();
+    // tree over the 256 lane partials: level b uses factor F[4 + b]
+    for (u32 b = 0; b < 8; b++) {
+        u32 half = 128u >> b;
+        Q31 r;
+        bool act = t < half;
+        if (act) {
+            Q31 lo = ld_q(s_p, 2 * t), hi = ld_q(s_p, 2 * t + 1);
+            // partial index bit b corresponds to coefficient-index bit 4 + b; beyond log_n the hi partial is zero anyway
+            r = (4 + b < job.log_n) ? q_add(lo, q_mul(hi, ld_q(F, 4 + b))) : lo;
+        }
+        __syncthreads();
+        if (act) s_p[t] = pk_q(r);
+        __syncthreads();
+    }
+    if (t == 0) partials[(size_t)job.partial_off + chunk] = s_p[0];
+}
+
+__global__ void __launch_bounds__(256) k_eval_at_point_stage2(const EvalJob* __restrict__ jobs, const uint4* __restrict__ factors, const uint4* __restrict__ partials, uint4* __restrict__ out) {
+    const EvalJob job = jobs[blockIdx.x];
+    const u32 nchunks = job.log_n > EAP_CHUNK_LOG ? 1u << (job.log_n - EAP_CHUNK_LOG) : 1u;
+    const uint4* F = factors + (size_t)job.point * 32 + job.factor_shift;
+    const uint4* p = partials + job.partial_off;
+    __shared__ uint4 s[256];
+    const u32 t = threadIdx.x;
+    // each lane folds a contiguous run of `per` partials (per = nchunks / 256 when nchunks > 256), then an LDS tree
+    u32 lanes = nchunks < 256 ? nchunks : 256;
+    u32 per_log = 0; while ((lanes << per_log) < nchunks) per_log++;
+    Q31 acc = q_zero();
+    if (t < lanes) {
+        // sequential fold of 2^per_log partials: weight of local index k = prod of F[12 + b] over set bits b of k
+        u32 per = 1u << per_log;
+        for (u32 k = 0; k < per; k++) {
+            Q31 w = q_one();
+            for (u32 b = 0; b < per_log; b++) if ((k >> b) & 1) w = q_mul(w, ld_q(F, EAP_CHUNK_LOG + b));
+            acc = q_add(acc, q_mul(ld_q(p, ((size_t)t << per_log) + k), w));
+        }
+    }
+    s[t] = pk_q(acc);
+    __syncthreads();
+    u32 lanes_log = 0; while ((1u << lanes_log) < lanes) lanes_log++;
+    for (u32 b = 0; b < lanes_log; b++) {
+        u32 half = lanes >> (b + 1);
+        Q31 r; bool act = t < half;
+        if (act) r = q_add(ld_q(s, 2 * t), q_mul(ld_q(s, 2 * t + 1), ld_q(F, EAP_CHUNK_LOG + per_log + b)));
+        __syncthreads();
+        if (act) s[t] = pk_q(r);
+        __syncthreads();
+    }
+    if (t == 0) out[blockIdx.x] = s[0];
+}
+
+void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 max_log_n, const void* d_factors, void* d_partials, void* d_out) {
+    if (!n_jobs) return;
+    u32 chunks = max_log_n > EAP_CHUNK_LOG ? 1u << (max_log_n - EAP_CHUNK_LOG) : 1u;
+    hipLaunchKernelGGL(k_eval_at_point_stage1, dim3(chunks, n_jobs), dim3(256), 0, stream, d_jobs, (const uint4*)d_factors, (uint4*)d_partials);
+    hipLaunchKernelGGL(k_eval_at_point_stage2, dim3(n_jobs), dim3(256), 0, stream, d_jobs, (const uint4*)d_factors, (const uint4*)d_partials, (uint4*)d_out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Domain points from the twiddle tree: for CanonicCoset(log).circle_domain() in bit-reversed order,
+//   x(row) = +-T1[row >> 2] (negated when bit 1 of row is set), y(row) = +-circle_twiddle(row >> 1) (negated when bit 0 is set),
+// where T1 is the first line-layer table of the domain (2^(log-2) entries at tw + 2^R - 2^(log-1)).
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void domain_point(const u32* __restrict__ tw, u32 tw_total, u32 log, u32 row, u32& x, u32& y) {
+    const u32* t1 = tw + (tw_total - (1u << (log - 1)));
+    u32 xv = t1[row >> 2];
+    x = (row & 2) ? m_neg(xv) : xv;
+    u32 h = row >> 1;
+    u32 cx = t1[(h >> 2) * 2], cy = t1[(h >> 2) * 2 + 1];
+    u32 sel = h & 3;
+    u32 yv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
+    y = (row & 1) ? m_neg(yv) : yv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// accumulate_quotients (a9): row value = Horner over sample batches of  (sum_k c_k f_k(row) - (A y + B)) / den(batch, row)
+// with A = sum_k a_k, B = sum_k b_k (line coefficients of complex_conjugate_line_coeffs, pre-summed on the host).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= (1u << a.log)) return;
+    u32 x, y;
+    domain_point(a.tw, a.tw_total, a.log, row, x, y);
+    Q31 acc = q_zero();
+    u32 e = 0;
+    for (u32 b = 0; b < a.n_batches; b++) {
+        const QuotientBatch qb = a.batches[b];
+        Q31 num = q_zero();
+        for (u32 k = 0; k < qb.n_cols; k++, e++) {
+            const QuotientEntry qe = a.entries[e];
+            ColDesc cd = a.cols[qe.col];
+            num = q_add(num, q_mulm(qe.c, cd.ptr[row >> cd.shift]));
+        }
+        num = q_sub(num, q_add(q_mulm(qb.a_sum, y), qb.b_sum));
+        // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x   in CM31
+        C31 dx = qb.prx; dx.a = m_sub(dx.a, x);
+        C31 dy = qb.pry; dy.a = m_sub(dy.a, y);
+        C31 den = c_sub(c_mul(dx, qb.piy), c_mul(dy, qb.pix));
+        acc = q_add(q_mul(acc, qb.batch_coeff), q_mulc(num, c_inv(den)));
+    }
+    a.out[0][row] = acc.a.a; a.out[1][row] = acc.a.b; a.out[2][row] = acc.b.a; a.out[3][row] = acc.b.b;
+}
+void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
+    u32 n = 1u << a.log;
+    hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// FRI folds (a10). Inverse twiddles come from the inverse twiddle tree:
+//   circle -> line: pair i of a circle evaluation of size 2^log uses 1/y = inverse circle twiddle i of the domain;
+//   line fold     : pair i of a line evaluation of size 2^log over Coset::half_odds(log) uses 1/x = first layer entry i of the
+//                   layered buffer of that coset (tail of the tree: itw + 2^R - 2^log).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u32* const d1, u32* const d2, u32* const d3,
+                                                               const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
+                                                               Q31 alpha, Q31 alpha_sq, const u32* __restrict__ itw, u32 tw_total, u32 log) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (log - 1))) return;
+    const u32* t1 = itw + (tw_total - (1u << (log - 1)));
+    u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
+    u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
+    uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
+    Q31 fp = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
+    Q31 f0 = q_add(fp, fn), f1 = q_mulm(q_sub(fp, fn), yinv);
+    Q31 fprime = q_add(q_mul(alpha, f1), f0);
+    Q31 dst = q_make(d0[i], d1[i], d2[i], d3[i]);
+    Q31 r = q_add(q_mul(dst, alpha_sq), fprime);
+    d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
+}
+__global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3,
+                                                   const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
+                                                   Q31 alpha, const u32* __restrict__ itw, u32 tw_total, u32 log) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (log - 1))) return;
+    u32 xinv = itw[tw_total - (1u << log) + i];
+    uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
+    Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
+    Q31 f0 = q_add(fx, fn), f1 = q_mulm(q_sub(fx, fn), xinv);
+    Q31 r = q_add(f0, q_mul(alpha, f1));
+    d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
+}
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log) {
+    u32 n = 1u << (log - 1);
+    hipLaunchKernelGGL(k_fold_circle_into_line, dim3((n + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3],
+                       alpha, q_mul(alpha, alpha), itw, 1u << tw_root_log, log);
+}
+void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log) {
+    u32 n = 1u << (log - 1);
+    hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3], alpha, itw, 1u << tw_root_log, log);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Decommitment gathers (a12): out[j] = word `word` of element `index` of a u32 array (column cell or hash word).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void k_gather(const GatherReq* __restrict__ req, u32 n, u32* __restrict__ out) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    GatherReq r = req[j];
+    out[j] = r.base[r.index];
+}
+void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, stream, d_req, n, d_out);
+}
+
+// AccumulationOps::accumulate: dst += src (M31, elementwise) — used when merging the per-size composition accumulators.
+__global__ void k_accumulate(u32* __restrict__ dst, const u32* __restrict__ src, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = m_add(dst[i], src[i]);
+}
+void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n) {
+    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, n);
+}
+
+// ColumnOps::bit_reverse_column (not on the prove path — the reference stores traces already bit-reversed — but part of the
+// backend surface): out-of-place permutation.
+__global__ void k_bit_reverse(const u32* __restrict__ src, u32* __restrict__ dst, u32 log) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (1u << log)) dst[bit_rev(i, log)] = src[i];
+}
+void bit_reverse(hipStream_t stream, const u32* src, u32* dst, u32 log) {
+    u32 n = 1u << log;
+    hipLaunchKernelGGL(k_bit_reverse, dim3((n + 255) / 256), dim3(256), 0, stream, src, dst, log);
+}
+
+// gen_is_first (preprocessed columns, mod.rs:497): only its interpolation matters; the coefficients of the indicator of cell 0
+// are written directly by the FFT of a one-hot column, so this just builds the one-hot column.
+__global__ void k_one_hot(u32* __restrict__ dst, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i == 0 ? 1u : 0u;
+}
+void one_hot(hipStream_t stream, u32* dst, u32 n) { hipLaunchKernelGGL(k_one_hot, dim3((n + 255) / 256), dim3(256), 0, stream, dst, n); }
+
+}  // namespace bf
