@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: prove_brainfuck on MI355X, metric = trace cells committed+proved per second (BASELINE.json).
+
+A "step" is one complete proof (preprocessed commitment .. decommitment, crates/brainfuck_prover/src/brainfuck_air/mod.rs:493-734)
+of one trace whose row-granular table columns are already resident in HBM. Workload at N=1: BASELINE.json configs[1]
+(fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, LOG_MAX_ROWS = 24).
+N > 1: one process per GPU, every rank proves its own independent trace ("replicas only", weak scaling).
+
+Prints ONE JSON line on rank 0 (driver contract). The roofline object is measured live with HIP events on the library's stream;
+the cpu_baseline object times the CPU oracle ("port") on a bounded sample on the host cores of the same box.
+"""
+import argparse
+import ctypes
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+FIB19 = "+++++++++++++++++>+>+<<[->>[->+>+<<]<[->>+<<]>>[-<+>]>[-<<<+>>>]<<<<]>>."  # tests/golden/programs/fib19.bf (workload input)
+
+
+def load_package():
+    name = "stwo_brainfuck_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "stwo-brainfuck_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(sample_seconds_hint=20):
+    """Times the CPU oracle (kind "port": the Rust reference cannot be built on this image) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    orc = Oracle()
+    path = os.path.join(ROOT, "tests", "golden", "programs", "collatz.bf")
+    code = open(path).read()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 64)   # the port's OpenMP loops stop scaling beyond a few dozen threads
+    orc.L.orc_set_threads(cores)
+    log_sizes, steps = orc.log_sizes(code, b"7\n")
+    main_cols = [8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7]
+    inter_cols = [4, 4, 4, 12, 4, 4, 4, 4, 4, 4, 4, 4, 4]
+    cells = sum((m + i) << l for m, i, l in zip(main_cols, inter_cols, log_sizes))
+    _, _, sec = orc.prove(code, b"7\n", log_max_rows=max(log_sizes))
+    return {"value": cells / sec, "unit": "trace cells/s", "cores": cores, "kind": "port",
+            "sample": f"collatz.bf input '7\\n' ({steps} VM steps, {cells} cells, LOG_MAX_ROWS={max(log_sizes)}), one proof, {sec:.1f} s, OpenMP over {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-max-rows", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    pkg = load_package()
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    ctx = pkg.Context(local_rank, max_log_domain=args.log_max_rows + 2)
+    trace = pkg.Trace(ctx, FIB19, b"")          # VM + table build + upload: outside the timed region (inputs resident in HBM)
+    lib = pkg.lib()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    proof = None
+    for _ in range(args.warmup):
+        proof, _ = trace.prove(args.log_max_rows)
+    if not args.no_kernel_events:
+        lib.bfhip_profile_enable(ctx._h, 1)
+        lib.bfhip_profile_reset(ctx._h)
+    barrier()
+    t0 = time.perf_counter()
+    phases = None
+    for _ in range(args.steps):
+        proof, phases = trace.prove(args.log_max_rows)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if not args.no_kernel_events:
+        js = ctypes.c_void_p()
+        lib.bfhip_profile_report(ctx._h, ctypes.byref(js))
+        rep = json.loads(ctypes.string_at(js).decode())
+        lib.bfhip_free_host(js)
+        lib.bfhip_profile_enable(ctx._h, 0)
+        name, d = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
+        avg_ms = d["total_ms"] / d["calls"]
+        achieved = d["bytes"] / d["calls"] / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # filled from the separate rocprofv3 --pmc passes, if committed
+        if os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path)).get(name, {}).get("hbm_bytes_per_launch")
+        roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
+                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
+                    "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
+
+    cells = trace.cells
+    if rank == 0:
+        out = {
+            "metric": "trace cells committed+proved/sec",
+            "value": world * cells * args.steps / dt,
+            "unit": "trace cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (M31 / QM31 modular arithmetic)",
+            "data": "fib19.bf execution trace (199246 VM steps); proof bytes identical to the CPU oracle on the oracle-sized parity programs",
+            "config": {"workload": "fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, 1 proof per step",
+                       "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
+                       "component_log_sizes": trace.log_sizes, "parallelism": "replicas" if world > 1 else "single",
+                       "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()}},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    trace.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,7 @@ extern "C" {
 #endif
 
 typedef struct bfhip_ctx bfhip_ctx;
+typedef struct bfhip_trace bfhip_trace;
 
 const char* bfhip_last_error(void);
 /* Number of visible HIP devices (0 when there is no GPU). */
@@ -65,6 +66,21 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
 int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
                               char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
 void bfhip_free_host(void* p);
+
+/* The two halves of prove_brainfuck, so that a caller (and the benchmark) can keep the prover input resident in HBM:
+ * bfhip_trace_create = VM run + the 13 `XTable::from(&vm_trace)` builders (mod.rs:508-547) + upload of the row-granular columns;
+ * bfhip_prove_trace  = everything from the preprocessed commitment (mod.rs:493) to the finished proof (mod.rs:734). */
+int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, bfhip_trace** out,
+                           uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells);
+int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* trace);
+int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
+                          char** transcript, double* phase_seconds);
+
+/* Optional per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline object).
+ * Report: JSON {"kernel": {"calls": n, "total_ms": t, "bytes": algorithmic_bytes}, ...}, malloc'd (bfhip_free_host). */
+int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on);
+int32_t bfhip_profile_reset(bfhip_ctx* ctx);
+int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json);
 
 #ifdef __cplusplus
 }

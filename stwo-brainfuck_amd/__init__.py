@@ -125,3 +125,36 @@ def prove_brainfuck(code, input_bytes=b"", ctx=None, log_max_rows=24, with_trans
     finally:
         if own:
             ctx.close()
+
+
+class Trace:
+    """Prover input resident in HBM (bfhip_trace_create): VM trace -> 13 component tables -> row-granular device columns."""
+
+    def __init__(self, ctx, code, input_bytes=b""):
+        self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        ls = (ctypes.c_uint32 * 13)()
+        steps, mc, ic = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().bfhip_trace_create(ctx._h, code.encode(), input_bytes, ctypes.c_size_t(len(input_bytes)), ctypes.byref(self._h), ls,
+                                        ctypes.byref(steps), ctypes.byref(mc), ctypes.byref(ic)))
+        self.log_sizes = list(ls)
+        self.n_steps, self.main_cells, self.interaction_cells = steps.value, mc.value, ic.value
+
+    @property
+    def cells(self):
+        return self.main_cells + self.interaction_cells
+
+    def prove(self, log_max_rows=24, want_json=True):
+        js, n = ctypes.c_void_p(), ctypes.c_size_t()
+        times = (ctypes.c_double * 10)()
+        _check(lib().bfhip_prove_trace(self.ctx._h, self._h, log_max_rows, ctypes.byref(js) if want_json else None, ctypes.byref(n), None, times))
+        proof = None
+        if want_json:
+            proof = ctypes.string_at(js, n.value)
+            lib().bfhip_free_host(js)
+        return proof, dict(zip(PHASES, list(times)))
+
+    def close(self):
+        if self._h:
+            lib().bfhip_trace_destroy(self.ctx._h, self._h)
+            self._h = ctypes.c_void_p()

@@ -49,8 +49,8 @@ template <class F> BF_HD Fq combine7(const Lookup& l, F a, F b, F c, F d, F e, F
 // Evaluator concept E:
 //   typename E::F;  F is_first();  F trace();  F cst(u32);
 //   void constraint(F) / constraint(Fq);
-//   void logup(Fq numerator, Fq denominator)   — one per add_to_relation, in order
-//   void finalize()                            — finalize_logup()
+//   void logup_mid(Fq numerator, Fq denominator) / logup_last(..) — one per add_to_relation, in order; the last closes the row
+//                                                (add_to_relation + finalize_logup of the reference)
 
 // memory/component.rs:62-137
 template <class E> BF_HD void air_memory(E& e, const Lookups& el) {
@@ -69,8 +69,7 @@ template <class E> BF_HD void air_memory(E& e, const Lookups& el) {
     e.constraint((next_mp - mp) * next_mv);
     e.constraint(d * (next_mp - mp));
     e.constraint(d * (next_mv - mv));
-    e.logup(to_ef(d - one), combine3(el.memory, clk, mp, mv));
-    e.finalize();
+    e.logup_last(to_ef(d - one), combine3(el.memory, clk, mp, mv));
 }
 // instruction/component.rs:65-142
 template <class E> BF_HD void air_instruction(E& e, const Lookups& el) {
@@ -88,8 +87,7 @@ template <class E> BF_HD void air_instruction(E& e, const Lookups& el) {
     e.constraint((next_ip - ip) * (next_ip - ip - one));
     e.constraint((next_ip - ip - one) * (next_ci - ci));
     e.constraint((next_ip - ip - one) * (next_ni - ni));
-    e.logup(to_ef(d - one), combine3(el.instruction, ip, ci, ni));
-    e.finalize();
+    e.logup_last(to_ef(d - one), combine3(el.instruction, ip, ci, ni));
 }
 // program/component.rs:60-104
 template <class E> BF_HD void air_program(E& e, const Lookups& el) {
@@ -101,8 +99,7 @@ template <class E> BF_HD void air_program(E& e, const Lookups& el) {
     e.constraint(d * (d - one));
     e.constraint(d * ci);
     e.constraint(d * ni);
-    e.logup(to_ef(one - d), combine3(el.instruction, ip, ci, ni));
-    e.finalize();
+    e.logup_last(to_ef(one - d), combine3(el.instruction, ip, ci, ni));
 }
 // processor/component.rs:79-153 — three relation entries in the order Processor, Instruction, Memory
 template <class E> BF_HD void air_processor(E& e, const Lookups& el) {
@@ -118,10 +115,10 @@ template <class E> BF_HD void air_processor(E& e, const Lookups& el) {
     e.constraint(mvi * (mv * mvi - one));
     e.constraint(next_clk - clk - one);
     Fq num = Fq{q_one()} - to_ef(d);
-    e.logup(num, combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
-    e.logup(num, combine3(el.instruction, ip, ci, ni));
-    e.logup(num, combine3(el.memory, clk, mp, mv));
-    e.finalize();
+    Fq den_p = combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi), den_i = combine3(el.instruction, ip, ci, ni), den_m = combine3(el.memory, clk, mp, mv);
+    e.logup_mid(num, den_p);
+    e.logup_mid(num, den_i);
+    e.logup_last(num, den_m);
 }
 // jump/jump_if_not_zero_component.rs:61-130, jump/jump_if_zero_component.rs:61-130
 template <class E> BF_HD void air_jump(E& e, const Lookups& el, bool if_zero) {
@@ -138,8 +135,7 @@ template <class E> BF_HD void air_jump(E& e, const Lookups& el, bool if_zero) {
     else e.constraint((d - one) * (is_mv_zero * (next_ip - ip - two) + mv * (next_ip - ni)));
     e.constraint(next_mp - mp);
     e.constraint(next_mv - mv);
-    e.logup(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
-    e.finalize();
+    e.logup_last(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
 }
 // processor/instructions/{input,left,minus,output,plus,right}_component.rs:62-122
 template <class E> BF_HD void air_instr(E& e, const Lookups& el, u32 opcode) {
@@ -158,16 +154,14 @@ template <class E> BF_HD void air_instr(E& e, const Lookups& el, u32 opcode) {
     else if (opcode == OP_RIGHT) e.constraint((one - d) * (next_mp - mp - one));
     else if (opcode == OP_READCHAR) e.constraint(next_mp - mp);
     else { e.constraint(next_mp - mp); e.constraint(next_mv - mv); }   // OP_PUTCHAR
-    e.logup(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
-    e.finalize();
+    e.logup_last(to_ef(d - one), combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
 }
 // end_of_execution/component.rs:61-90
 template <class E> BF_HD void air_eoe(E& e, const Lookups& el) {
     typedef typename E::F F;
     F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace();
     e.constraint(ci);
-    e.logup(Fq{q_neg(q_one())}, combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
-    e.finalize();
+    e.logup_last(Fq{q_neg(q_one())}, combine7(el.processor, clk, ip, ci, ni, mp, mv, mvi));
 }
 
 template <int COMP, class E> BF_HD void air_eval(E& e, const Lookups& el) {
@@ -186,26 +180,29 @@ template <int COMP, class E> BF_HD void air_eval(E& e, const Lookups& el) {
     else air_eoe(e, el);
 }
 
-// logUp row machinery shared by evaluators (stwo LogupAtRow): up to 3 fractions; all but the last become `cur - prev_col`
-// constraints on single-offset columns, the last uses the {0,-1} masks and the IsFirst-corrected previous row.
+// logUp row machinery shared by evaluators (stwo LogupAtRow, finalize_logup without batching): every fraction but the last becomes
+// a `(cur - prev_col) * den - num` constraint on a single-offset interaction column; the last one uses the {0,-1} masks and the
+// IsFirst-corrected previous row. The first fraction of a row fetches IsFirst(log_size) (second preprocessed mask of the row).
+// No arrays, so the evaluator state stays in registers on the GPU.
 template <class D, class F_>
 struct LogupState {
-    Fq num[3], den[3]; int nf = 0; F_ lu_is_first; Q31 total_sum;
+    Fq prev_col; F_ lu_is_first; Q31 total_sum; bool lu_started = false;
     BF_HD D& self() { return *static_cast<D*>(this); }
-    BF_HD void logup(Fq n, Fq d) { if (nf == 0) lu_is_first = self().is_first(); num[nf] = n; den[nf] = d; nf++; }
-    BF_HD void finalize() {
-        Fq prev_col{q_zero()};
-        for (int k = 0; k + 1 < nf; k++) {
-            Fq cur = self().inter_cur();
-            Fq diff = cur - prev_col;
-            prev_col = cur;
-            self().constraint(diff * den[k] - num[k]);
-        }
+    BF_HD void lu_begin() { if (!lu_started) { lu_is_first = self().is_first(); prev_col = Fq{q_zero()}; lu_started = true; } }
+    BF_HD void logup_mid(Fq n, Fq d) {
+        lu_begin();
+        Fq cur = self().inter_cur();
+        Fq diff = cur - prev_col;
+        prev_col = cur;
+        self().constraint(diff * d - n);
+    }
+    BF_HD void logup_last(Fq n, Fq d) {
+        lu_begin();
         Fq cur, prev_row;
         self().inter_cur_prev(cur, prev_row);
         Fq fixed_prev = prev_row - Fq{total_sum} * lu_is_first;
         Fq diff = cur - fixed_prev - prev_col;
-        self().constraint(diff * den[nf - 1] - num[nf - 1]);
+        self().constraint(diff * d - n);
     }
 };
 

@@ -18,17 +18,7 @@ namespace bf {
 // ------------------------------------------------------------------------------------------------------------------------------
 // Constraint evaluation
 // ------------------------------------------------------------------------------------------------------------------------------
-struct ConstraintArgs {
-    const u32* is_first;        // IsFirst(log_size) LDE column (2^(log_size+1) cells)
-    ColDesc trace[13];          // main LDE columns
-    ColDesc inter[12];          // interaction LDE columns, 4 per logUp column
-    u32* acc[4];                // accumulator (2^(log_size+1) cells per coordinate)
-    Q31 coeff[12];              // random-coefficient power for constraint j (already in "reversed" order)
-    Lookups el;
-    Q31 total_sum;
-    u32 denom_inv[2];           // 1/coset_vanishing on the two cosets of the LDE domain, indexed by row >> log_size
-    u32 log_size;
-};
+typedef ConstraintLaunch ConstraintArgs;   // lives in HBM (staged by the host); read through scalar loads
 
 struct DomainEval : LogupState<DomainEval, Fm> {
     typedef Fm F;
@@ -56,7 +46,8 @@ struct DomainEval : LogupState<DomainEval, Fm> {
 };
 
 template <int COMP>
-__global__ void __launch_bounds__(256) k_constraints(ConstraintArgs a) {
+__global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __restrict__ ap) {
+    const ConstraintArgs& a = *ap;
     u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= (2u << a.log_size)) return;
     DomainEval e(a, row);
@@ -69,33 +60,27 @@ __global__ void __launch_bounds__(256) k_constraints(ConstraintArgs a) {
 }
 
 template <int COMP>
-static void launch_c(hipStream_t s, const ConstraintArgs& a) {
-    u32 n = 2u << a.log_size;
+static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size) {
+    u32 n = 2u << log_size;
+    ProfScope ps(s, "k_constraints", 0);
     hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
-void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch& L) {
-    ConstraintArgs a;
-    a.is_first = L.is_first;
-    for (int i = 0; i < 13; i++) a.trace[i] = L.trace[i];
-    for (int i = 0; i < 12; i++) a.inter[i] = L.inter[i];
-    for (int i = 0; i < 4; i++) a.acc[i] = L.acc[i];
-    for (int i = 0; i < 12; i++) a.coeff[i] = L.coeff[i];
-    a.el = L.el; a.total_sum = L.total_sum; a.denom_inv[0] = L.denom_inv[0]; a.denom_inv[1] = L.denom_inv[1]; a.log_size = L.log_size;
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size) {
     switch (comp) {
-        case C_MEMORY: launch_c<C_MEMORY>(stream, a); break;
-        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a); break;
-        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a); break;
-        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a); break;
-        case C_JNZ: launch_c<C_JNZ>(stream, a); break;
-        case C_JZ: launch_c<C_JZ>(stream, a); break;
-        case C_INPUT: launch_c<C_INPUT>(stream, a); break;
-        case C_LEFT: launch_c<C_LEFT>(stream, a); break;
-        case C_MINUS: launch_c<C_MINUS>(stream, a); break;
-        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a); break;
-        case C_PLUS: launch_c<C_PLUS>(stream, a); break;
-        case C_RIGHT: launch_c<C_RIGHT>(stream, a); break;
-        default: launch_c<C_EOE>(stream, a); break;
+        case C_MEMORY: launch_c<C_MEMORY>(stream, a, log_size); break;
+        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a, log_size); break;
+        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a, log_size); break;
+        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a, log_size); break;
+        case C_JNZ: launch_c<C_JNZ>(stream, a, log_size); break;
+        case C_JZ: launch_c<C_JZ>(stream, a, log_size); break;
+        case C_INPUT: launch_c<C_INPUT>(stream, a, log_size); break;
+        case C_LEFT: launch_c<C_LEFT>(stream, a, log_size); break;
+        case C_MINUS: launch_c<C_MINUS>(stream, a, log_size); break;
+        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a, log_size); break;
+        case C_PLUS: launch_c<C_PLUS>(stream, a, log_size); break;
+        case C_RIGHT: launch_c<C_RIGHT>(stream, a, log_size); break;
+        default: launch_c<C_EOE>(stream, a, log_size); break;
     }
 }
 

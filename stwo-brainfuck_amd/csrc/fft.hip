@@ -241,6 +241,7 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
         while ((u64)ntiles * ((ncols + cpb - 1) / cpb) > 8192 && cpb < ncols) cpb *= 2;
         a.cols_per_block = cpb;
         dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
+        ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", 8.0 * ncols * (double)(1u << log));
         if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, a);
         else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, a);
     }

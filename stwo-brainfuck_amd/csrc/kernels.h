@@ -3,12 +3,27 @@
 #include <hip/hip_runtime.h>
 #include "m31.h"
 #include "air.h"
+#include <string>
 
 namespace bf {
 
 // A column in HBM. shift = 0: one u32 per domain cell. shift = 4: one u32 per table row, standing for a column whose values
 // are broadcast into 16 consecutive cells (reference: memory/table.rs:95-104) — cell i reads ptr[i >> 4].
 struct ColDesc { const u32* ptr; u32 shift; u32 pad_; };
+
+// prof.hip — optional per-kernel HIP-event timing (bench.py roofline)
+bool prof_enabled();
+void prof_enable(bool on);
+void prof_begin(hipStream_t s, const char* name, double bytes);
+void prof_end(hipStream_t s);
+void prof_collect();
+void prof_reset();
+std::string prof_report_json();
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(hipStream_t s_, const char* name, double bytes) : s(s_), on(prof_enabled()) { if (on) prof_begin(s, name, bytes); }
+    ~ProfScope() { if (on) prof_end(s); }
+};
 
 // fft.hip
 void gen_twiddles(hipStream_t stream, u32* d_tw, u32* d_itw, u32 R, const uint2* d_tlo, const uint2* d_thi);
@@ -19,7 +34,7 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
                const u32* tw, const u32* itw, u32 tw_root_log);
 
 // merkle.hip
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log);
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes);
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
 
@@ -27,7 +42,8 @@ void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32
 struct ConstraintLaunch {
     const u32* is_first; ColDesc trace[13]; ColDesc inter[12]; u32* acc[4]; Q31 coeff[12]; Lookups el; Q31 total_sum; u32 denom_inv[2]; u32 log_size;
 };
-void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch& L);
+// `d_args` points to a ConstraintLaunch staged in device memory.
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size);
 struct LogupLaunch {
     const u32* cols[13];   // row-granular main columns
     u32* out_rep[8];       // row-granular coordinate columns of the non-last logUp columns

@@ -105,12 +105,15 @@ __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ l
     }
 }
 
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log) {
+// col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes) {
     u32 n = 1u << log;
     u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
+    ProfScope ps(stream, "k_merkle_layer", (prev ? 64.0 * n : 0.0) + 32.0 * n + col_bytes);
     hipLaunchKernelGGL(k_merkle_layer, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n);
 }
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
+    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));
     hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log);
 }
 

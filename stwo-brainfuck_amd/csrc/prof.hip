@@ -1,0 +1,57 @@
+// Per-kernel HIP-event timing used by bench.py's roofline object: every kernel launch of the library can be bracketed by a pair of
+// events on the launching stream; durations and algorithmic byte counts are aggregated per kernel name.
+#include "kernels.h"
+#include <map>
+#include <vector>
+#include <string>
+#include <cstdio>
+#include <cstdlib>
+
+namespace bf {
+
+struct ProfRec { const char* name; double bytes; hipEvent_t e0, e1; };
+struct ProfAgg { u64 calls = 0; double ms = 0, bytes = 0; };
+
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static std::map<std::string, ProfAgg> g_agg;
+
+bool prof_enabled() { return g_prof_on; }
+void prof_enable(bool on) { g_prof_on = on; }
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void prof_begin(hipStream_t s, const char* name, double bytes) {
+    ProfRec r{name, bytes, get_event(), get_event()};
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+
+// Must be called after the stream has been synchronised.
+void prof_collect() {
+    for (auto& r : g_recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = g_agg[r.name]; a.calls++; a.ms += ms; a.bytes += r.bytes; }
+        g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    }
+    g_recs.clear();
+}
+void prof_reset() { prof_collect(); g_agg.clear(); }
+std::string prof_report_json() {
+    prof_collect();
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : g_agg) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s\"%s\":{\"calls\":%llu,\"total_ms\":%.6f,\"bytes\":%.0f}", first ? "" : ",", kv.first.c_str(), (unsigned long long)kv.second.calls, kv.second.ms, kv.second.bytes);
+        s += buf; first = false;
+    }
+    return s + "}";
+}
+
+}  // namespace bf

@@ -45,6 +45,16 @@ struct Gather {
     }
 };
 
+// The prover's input once resident in HBM: row-granular main-trace columns of the 13 components (what the reference's
+// `XTable::from(&vm_trace).trace_evaluation()` calls produce, mod.rs:511-547, minus the 16x lane broadcast).
+struct TraceInput {
+    std::vector<std::vector<DCol>> rows;   // [component][column]
+    u32 log_sizes[N_COMPONENTS];
+    u64 n_steps = 0, main_cells = 0, interaction_cells = 0;
+    std::vector<u32*> owned;
+    void release() { for (u32* p : owned) (void)hipFree(p); owned.clear(); rows.clear(); }
+};
+
 struct PhaseTimes { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, decommit = 0, tables = 0, total = 0; };
 
 struct HipProver {
@@ -101,10 +111,10 @@ struct HipProver {
         size_t ci = 0;
         u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
-            std::vector<ColDesc> lc;
-            while (ci < cols.size() && cols[ci].log_size == (u32)log) lc.push_back(cols[ci++].desc());
+            std::vector<ColDesc> lc; double col_bytes = 0;
+            while (ci < cols.size() && cols[ci].log_size == (u32)log) { col_bytes += 4.0 * cols[ci].stored(); lc.push_back(cols[ci++].desc()); }
             const ColDesc* d = lc.empty() ? nullptr : c.stage(lc.data(), lc.size());
-            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, d, (u32)lc.size(), (u32)log);
+            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, d, (u32)lc.size(), (u32)log, col_bytes);
         }
         if (fused_top > 0) {
             void* const* dl = (void* const*)c.stage(mk.layers.data(), mk.layers.size());
@@ -223,7 +233,27 @@ struct HipProver {
     };
 
     // ------------------------------------------------------------------------------------------------------------------------------
-    BrainfuckProof prove(const std::vector<Registers>& vm_trace, const std::vector<u32>& code) {
+    // Host table build + upload (outside the metric's timed region: "inputs already resident in HBM").
+    static void upload_trace(Ctx& c, const std::vector<Registers>& vm_trace, const std::vector<u32>& code, TraceInput& in) {
+        std::vector<Table> tables = build_tables(vm_trace, code);
+        in.rows.assign(N_COMPONENTS, {});
+        in.n_steps = vm_trace.size();
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            in.log_sizes[k] = tables[k].log_size();
+            in.main_cells += (u64)n_main_cols(k) << in.log_sizes[k];
+            in.interaction_cells += (u64)(4 * n_logup_cols(k)) << in.log_sizes[k];
+            for (u32 j = 0; j < n_main_cols(k); j++) {
+                DCol r; r.log_size = in.log_sizes[k]; r.shift = LOG_N_LANES;
+                BF_HIP(hipMalloc((void**)&r.ptr, r.stored() * sizeof(u32)));
+                in.owned.push_back(r.ptr);
+                BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+                in.rows[k].push_back(r);
+            }
+        }
+        c.sync();
+    }
+
+    BrainfuckProof prove(const TraceInput& in) {
         double t_start = now();
         c.arena.reset();
         ch = Channel();
@@ -245,22 +275,17 @@ struct HipProver {
 
         // ---- Phase 1: main trace (mod.rs:506-583) -----------------------------------------------------------------------------
         t0 = now();
-        std::vector<Table> tables = build_tables(vm_trace, code);
-        tm.tables = now() - t0;
-        std::vector<std::vector<DCol>> rows(N_COMPONENTS);   // row-granular table columns (kept for the logUp pass)
+        const std::vector<std::vector<DCol>>& rows = in.rows;   // row-granular table columns (also feed the logUp pass)
         size_t main_off[N_COMPONENTS], inter_off[N_COMPONENTS];
         {
             size_t mo = 0, io = 0;
             for (int k = 0; k < N_COMPONENTS; k++) { main_off[k] = mo; inter_off[k] = io; mo += n_main_cols(k); io += 4 * n_logup_cols(k); }
         }
         for (int k = 0; k < N_COMPONENTS; k++) {
-            bp.log_sizes[k] = tables[k].log_size();
+            bp.log_sizes[k] = in.log_sizes[k];
             if (bp.log_sizes[k] > log_max_rows) throw HipError("a component exceeds LOG_MAX_ROWS");
             for (u32 j = 0; j < n_main_cols(k); j++) {
-                DCol r; r.log_size = bp.log_sizes[k]; r.shift = LOG_N_LANES; r.ptr = c.alloc_u32(r.stored());
-                BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
-                rows[k].push_back(r);
-                DCol p = r; p.ptr = c.alloc_u32(p.stored());
+                DCol p = rows[k][j]; p.ptr = c.alloc_u32(p.stored());
                 trees[1].polys.push_back(p);
             }
         }
@@ -272,7 +297,7 @@ struct HipProver {
         for (int k = 0; k < N_COMPONENTS; k++) ch.mix_u64(bp.log_sizes[k]);   // claim.mix_into (mod.rs:102-116)
         commit_tree(trees[1]);
         tap("root1");
-        tm.main_trace = now() - t0 - tm.tables;
+        tm.main_trace = now() - t0;
 
         // ---- Phase 2: interaction trace (mod.rs:589-723) ------------------------------------------------------------------------
         t0 = now();
@@ -419,7 +444,8 @@ struct HipProver {
             L.el = el; L.total_sum = bp.claimed_sums[k]; L.log_size = log;
             // denom_inv[i] = 1 / coset_vanishing(CanonicCoset(log).coset, eval_domain.at(i)), i in {0, 1} (bit-reversal of 2 entries = identity)
             for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log, canonic_domain_at(eval_log, i)));
-            eval_constraints(c.stream, k, L);
+            c.stage_checkpoint();
+            eval_constraints(c.stream, k, c.stage(&L, 1), log);
         }
         BF_HIP(hipGetLastError());
         // finalize: ascending sizes; evaluate the running polynomial on the next populated size, add, interpolate
@@ -692,26 +718,64 @@ struct HipProver {
 
 using namespace bf;
 
-extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, uint32_t log_max_rows,
-                                          char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
+struct bfhip_trace { TraceInput in; };
+
+static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
+    if (proof_json) {
+        std::string js = proof_to_json(bp);
+        *proof_json = (char*)malloc(js.size() + 1);
+        memcpy(*proof_json, js.c_str(), js.size() + 1);
+        if (proof_len) *proof_len = js.size();
+    }
+    if (transcript) { *transcript = (char*)malloc(pv.transcript.size() + 1); memcpy(*transcript, pv.transcript.c_str(), pv.transcript.size() + 1); }
+    if (phase_seconds) {
+        const PhaseTimes& t = pv.tm;
+        double v[10] = {t.preprocessed, t.tables, t.main_trace, t.interaction, t.composition, t.oods, t.quotients, t.fri, t.decommit, t.total};
+        memcpy(phase_seconds, v, sizeof v);
+    }
+}
+
+extern "C" int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, bfhip_trace** out,
+                                       uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
     try {
         std::vector<u32> ins = compile(code);
         Machine m(ins, std::vector<u8>(input, input + n_input));
         m.execute();
-        HipProver pv(ctx->c, log_max_rows);
-        pv.want_transcript = transcript != nullptr;
-        BrainfuckProof bp = pv.prove(m.trace, ins);
-        std::string js = proof_to_json(bp);
-        *proof_json = (char*)malloc(js.size() + 1);
-        memcpy(*proof_json, js.c_str(), js.size() + 1);
-        *proof_len = js.size();
-        if (transcript) { *transcript = (char*)malloc(pv.transcript.size() + 1); memcpy(*transcript, pv.transcript.c_str(), pv.transcript.size() + 1); }
-        if (phase_seconds) {
-            const PhaseTimes& t = pv.tm;
-            double v[10] = {t.preprocessed, t.tables, t.main_trace, t.interaction, t.composition, t.oods, t.quotients, t.fri, t.decommit, t.total};
-            memcpy(phase_seconds, v, sizeof v);
-        }
+        auto* t = new bfhip_trace();
+        try { HipProver::upload_trace(ctx->c, m.trace, ins, t->in); } catch (...) { t->in.release(); delete t; throw; }
+        if (log_sizes) memcpy(log_sizes, t->in.log_sizes, sizeof(u32) * N_COMPONENTS);
+        if (n_steps) *n_steps = t->in.n_steps;
+        if (main_cells) *main_cells = t->in.main_cells;
+        if (interaction_cells) *interaction_cells = t->in.interaction_cells;
+        *out = t;
         return 0;
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
 }
+extern "C" int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* t) { (void)ctx; if (t) { t->in.release(); delete t; } return 0; }
+
+extern "C" int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
+                                      char** transcript, double* phase_seconds) {
+    try {
+        HipProver pv(ctx->c, log_max_rows);
+        pv.want_transcript = transcript != nullptr;
+        BrainfuckProof bp = pv.prove(trace->in);
+        fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
+        return 0;
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
+}
+
+extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, uint32_t log_max_rows,
+                                          char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
+    bfhip_trace* t = nullptr;
+    if (bfhip_trace_create(ctx, code, input, n_input, &t, nullptr, nullptr, nullptr, nullptr) != 0) return -1;
+    int32_t rc = bfhip_prove_trace(ctx, t, log_max_rows, proof_json, proof_len, transcript, phase_seconds);
+    bfhip_trace_destroy(ctx, t);
+    return rc;
+}
 extern "C" void bfhip_free_host(void* p) { free(p); }
+extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on) { (void)ctx; prof_enable(on != 0); return 0; }
+extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) { try { ctx->c.sync(); prof_reset(); return 0; } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } }
+extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {
+    try { ctx->c.sync(); std::string s = prof_report_json(); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
+    catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}

@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
 }
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
     u32 n = 1u << a.log;
+    ProfScope ps(stream, "k_quotients", 0);
     hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 
