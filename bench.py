@@ -79,33 +79,27 @@ def main():
     pkg = load_package()
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    ctx = pkg.Context(local_rank, max_log_domain=args.log_max_rows + 2)
+    ctx = pkg.Context(local_rank, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK
     trace = pkg.Trace(ctx, FIB19, b"")          # VM + table build + upload: outside the timed region (inputs resident in HBM)
     lib = pkg.lib()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    spec = importlib.util.spec_from_file_location("stwo_brainfuck_amd_replicas", os.path.join(ROOT, "stwo-brainfuck_amd", "replicas.py"))
+    replicas = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(replicas)
+
+    def sync():
         ctx.sync()
         torch.cuda.synchronize()
 
-    proof = None
-    for _ in range(args.warmup):
-        proof, _ = trace.prove(args.log_max_rows)
-    if not args.no_kernel_events:
-        lib.bfhip_profile_enable(ctx._h, 1)
-        lib.bfhip_profile_reset(ctx._h)
-    barrier()
-    t0 = time.perf_counter()
-    phases = None
-    for _ in range(args.steps):
-        proof, phases = trace.prove(args.log_max_rows)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def start_events():
+        if not args.no_kernel_events:
+            lib.bfhip_profile_enable(ctx._h, 1)
+            lib.bfhip_profile_reset(ctx._h)
+
+    cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if dist is not None else None
+    dt, (proof, phases) = replicas.timed_region(lambda: trace.prove(args.log_max_rows), args.steps, args.warmup, dist=dist, sync_fn=sync,
+                                                backend_tensor=cuda_t, on_timed_start=start_events)
+    total_cells = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
 
     roofline = None
     if not args.no_kernel_events:
@@ -130,7 +124,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "trace cells committed+proved/sec",
-            "value": world * cells * args.steps / dt,
+            "value": total_cells * args.steps / dt,
             "unit": "trace cells/s",
             "n_gpus": world,
             "steps": args.steps,

@@ -76,6 +76,15 @@ int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* trace);
 int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                           char** transcript, double* phase_seconds);
 
+/* Host-only pieces of the drop-in (usable without a GPU): the Brainfuck compiler (crates/brainfuck_vm/src/compiler.rs:17-37), the VM
+ * (crates/brainfuck_vm/src/machine.rs:141-238; trace rows are 7 u32: clk, ip, ci, ni, mp, mv, mvi) and the 13 table builders
+ * (`XTable::from`, the table.rs files under crates/brainfuck_prover/src/components; component index = claim order of mod.rs:85-99), row-major out. */
+int32_t bfhip_host_compile(const char* code, uint32_t* out, size_t cap, size_t* n);
+int32_t bfhip_host_run(const char* code, const uint8_t* input_h, size_t n_input, uint8_t* out, size_t out_cap, size_t* n_out,
+                       uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows);
+int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t* code, size_t n_code, int32_t component,
+                         uint32_t* out_row_major, size_t cap, size_t* n_rows, size_t* n_cols);
+
 /* Optional per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline object).
  * Report: JSON {"kernel": {"calls": n, "total_ms": t, "bytes": algorithmic_bytes}, ...}, malloc'd (bfhip_free_host). */
 int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on);

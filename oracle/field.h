@@ -12,6 +12,7 @@
 #include <vector>
 #include <array>
 #include <cassert>
+#include <stdexcept>
 
 namespace orc {
 
@@ -42,7 +43,7 @@ static inline M31& operator-=(M31& a, M31 b) { a = a - b; return a; }
 static inline M31& operator*=(M31& a, M31 b) { a = a * b; return a; }
 static inline M31 m31_pow(M31 b, u64 e) { M31 r(1); while (e) { if (e & 1) r = r * b; b = b * b; e >>= 1; } return r; }
 // stwo m31.rs `inverse` = x^(P-2) (reference call site: crates/brainfuck_vm/src/machine.rs:225).
-static inline M31 inv(M31 a) { assert(a.v != 0); return m31_pow(a, P - 2); }
+static inline M31 inv(M31 a) { if (a.v == 0) throw std::runtime_error("M31 inverse of zero"); return m31_pow(a, P - 2); }
 
 // CM31 = M31[i]/(i^2+1)  (stwo core/fields/cm31.rs)
 struct CM31 {

@@ -157,6 +157,36 @@ int orc_table(const char* code, const u8* input, size_t n_in, int component, u32
     return 0;
     ORC_CATCH
 }
+// Table built from an explicit register trace + compiled program (mirrors the reference's table unit tests).
+int orc_table_from_registers(const u32* trace7, size_t n_trace, const u32* code, size_t n_code, int component, u32* out, size_t cap, size_t* n_rows, size_t* n_cols) {
+    ORC_TRY
+    std::vector<Registers> tr(n_trace);
+    for (size_t i = 0; i < n_trace; i++) { const u32* v = trace7 + 7 * i; tr[i] = Registers{v[0], v[1], v[2], v[3], v[4], v[5], v[6]}; }
+    std::vector<u32> ins(code, code + n_code);
+    Table t;
+    switch (component) {
+        case C_MEMORY: t = memory_table(tr); break;
+        case C_INSTRUCTION: t = instruction_table(tr, ins); break;
+        case C_PROGRAM: t = program_table(ins); break;
+        case C_PROCESSOR: t = processor_table(tr); break;
+        case C_JNZ: t = jump_table(tr, OP_JNZ); break;
+        case C_JZ: t = jump_table(tr, OP_JZ); break;
+        case C_INPUT: t = instruction_sub_table(tr, OP_READCHAR); break;
+        case C_LEFT: t = instruction_sub_table(tr, OP_LEFT); break;
+        case C_MINUS: t = instruction_sub_table(tr, OP_MINUS); break;
+        case C_OUTPUT: t = instruction_sub_table(tr, OP_PUTCHAR); break;
+        case C_PLUS: t = instruction_sub_table(tr, OP_PLUS); break;
+        case C_RIGHT: t = instruction_sub_table(tr, OP_RIGHT); break;
+        default: t = eoe_table(tr); break;
+    }
+    *n_rows = t.n_rows; *n_cols = t.cols.size();
+    if (out) {
+        if (t.n_rows * t.cols.size() > cap) { g_err = "cap"; return -2; }
+        for (size_t r = 0; r < t.n_rows; r++) for (size_t c = 0; c < t.cols.size(); c++) out[r * t.cols.size() + c] = t.cols[c][r];
+    }
+    return 0;
+    ORC_CATCH
+}
 int orc_log_sizes(const char* code, const u8* input, size_t n_in, u32 out[13], u64* n_steps) {
     ORC_TRY
     std::vector<u32> ins;

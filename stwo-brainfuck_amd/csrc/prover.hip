@@ -773,6 +773,57 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
     return rc;
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
+
+// ---- host-only entry points (no GPU needed): compiler, VM and table builders of the drop-in's host side ---------------------------
+extern "C" int32_t bfhip_host_compile(const char* code, uint32_t* out, size_t cap, size_t* n) {
+    try { auto ins = compile(code); *n = ins.size(); if (ins.size() > cap) { bfhip_set_error("capacity"); return -2; } memcpy(out, ins.data(), 4 * ins.size()); return 0; }
+    catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
+extern "C" int32_t bfhip_host_run(const char* code, const uint8_t* input, size_t n_input, uint8_t* out, size_t out_cap, size_t* n_out,
+                                   uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows) {
+    try {
+        Machine m(compile(code), std::vector<u8>(input, input + n_input));
+        m.execute();
+        if (n_out) *n_out = m.output.size();
+        if (out && m.output.size() <= out_cap) memcpy(out, m.output.data(), m.output.size());
+        if (n_rows) *n_rows = m.trace.size();
+        if (trace7 && m.trace.size() <= trace_cap_rows)
+            for (size_t i = 0; i < m.trace.size(); i++) { const Registers& r = m.trace[i]; u32 v[7] = {r.clk, r.ip, r.ci, r.ni, r.mp, r.mv, r.mvi}; memcpy(trace7 + 7 * i, v, 28); }
+        return 0;
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
+// Table of `component` (0..12, claim order of mod.rs:85-99) built from an explicit register trace (7 u32 per row) and compiled program.
+extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t* code, size_t n_code, int32_t component,
+                                     uint32_t* out_row_major, size_t cap, size_t* n_rows, size_t* n_cols) {
+    try {
+        std::vector<Registers> tr(n_trace);
+        for (size_t i = 0; i < n_trace; i++) { const u32* v = trace7 + 7 * i; tr[i] = Registers{v[0], v[1], v[2], v[3], v[4], v[5], v[6]}; }
+        std::vector<u32> ins(code, code + n_code);
+        Table t;
+        switch (component) {
+            case C_MEMORY: t = memory_table(tr); break;
+            case C_INSTRUCTION: t = instruction_table(tr, ins); break;
+            case C_PROGRAM: t = program_table(ins); break;
+            case C_PROCESSOR: t = processor_table(tr); break;
+            case C_JNZ: t = jump_table(tr, OP_JNZ); break;
+            case C_JZ: t = jump_table(tr, OP_JZ); break;
+            case C_INPUT: t = instruction_sub_table(tr, OP_READCHAR); break;
+            case C_LEFT: t = instruction_sub_table(tr, OP_LEFT); break;
+            case C_MINUS: t = instruction_sub_table(tr, OP_MINUS); break;
+            case C_OUTPUT: t = instruction_sub_table(tr, OP_PUTCHAR); break;
+            case C_PLUS: t = instruction_sub_table(tr, OP_PLUS); break;
+            case C_RIGHT: t = instruction_sub_table(tr, OP_RIGHT); break;
+            case C_EOE: t = eoe_table(tr); break;
+            default: bfhip_set_error("bad component"); return -1;
+        }
+        *n_rows = t.n_rows; *n_cols = t.cols.size();
+        if (out_row_major) {
+            if (t.n_rows * t.cols.size() > cap) { bfhip_set_error("capacity"); return -2; }
+            for (size_t r = 0; r < t.n_rows; r++) for (size_t c = 0; c < t.cols.size(); c++) out_row_major[r * t.cols.size() + c] = t.cols[c][r];
+        }
+        return 0;
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
 extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on) { (void)ctx; prof_enable(on != 0); return 0; }
 extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) { try { ctx->c.sync(); prof_reset(); return 0; } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } }
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {

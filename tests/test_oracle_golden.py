@@ -1,0 +1,154 @@
+"""CPU: the oracle (and the product's host-side VM / table builders) against the reference's own golden vectors
+(tests/golden/reference_vectors.json, hand-transcribed from the reference's unit tests) and public KATs."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, P
+
+V = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")))
+PROGS = os.path.join(ROOT, "tests", "golden", "programs")
+
+
+def prog(name):
+    return open(os.path.join(PROGS, name)).read()
+
+
+# ---- product host side through the C ABI (no GPU needed) -------------------------------------------------------------------------
+class Host:
+    def __init__(self, pkg):
+        self.L = pkg.lib()
+
+    def compile(self, code):
+        out = np.zeros(2 * len(code) + 4, dtype=np.uint32)
+        n = ctypes.c_size_t()
+        assert self.L.bfhip_host_compile(code.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size), ctypes.byref(n)) == 0
+        return out[: n.value].tolist()
+
+    def run(self, code, inp):
+        n_out, n_rows = ctypes.c_size_t(), ctypes.c_size_t()
+        assert self.L.bfhip_host_run(code.encode(), inp, ctypes.c_size_t(len(inp)), None, ctypes.c_size_t(0), ctypes.byref(n_out), None, ctypes.c_size_t(0), ctypes.byref(n_rows)) == 0
+        out = (ctypes.c_ubyte * max(1, n_out.value))()
+        tr = np.zeros((n_rows.value, 7), dtype=np.uint32)
+        assert self.L.bfhip_host_run(code.encode(), inp, ctypes.c_size_t(len(inp)), out, ctypes.c_size_t(n_out.value), ctypes.byref(n_out),
+                                     tr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_rows.value), ctypes.byref(n_rows)) == 0
+        return bytes(out[: n_out.value]), tr
+
+    def table(self, trace, code_words, component):
+        trace = np.ascontiguousarray(trace, dtype=np.uint32).reshape(-1, 7)
+        cw = np.ascontiguousarray(code_words, dtype=np.uint32)
+        nr, nc = ctypes.c_size_t(), ctypes.c_size_t()
+        args = (trace.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(trace.shape[0]), cw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cw.size), component)
+        assert self.L.bfhip_host_table(*args, None, ctypes.c_size_t(0), ctypes.byref(nr), ctypes.byref(nc)) == 0
+        out = np.zeros((nr.value, nc.value), dtype=np.uint32)
+        assert self.L.bfhip_host_table(*args, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size), ctypes.byref(nr), ctypes.byref(nc)) == 0
+        return out
+
+
+@pytest.fixture(scope="module")
+def host(pkg):
+    return Host(pkg)
+
+
+def oracle_table_from_registers(oracle, trace, code_words, component):
+    trace = np.ascontiguousarray(trace, dtype=np.uint32).reshape(-1, 7)
+    cw = np.ascontiguousarray(code_words, dtype=np.uint32)
+    nr, nc = ctypes.c_size_t(), ctypes.c_size_t()
+    args = (trace.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(trace.shape[0]), cw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cw.size), component)
+    assert oracle.L.orc_table_from_registers(*args, None, ctypes.c_size_t(0), ctypes.byref(nr), ctypes.byref(nc)) == 0
+    out = np.zeros((nr.value, nc.value), dtype=np.uint32)
+    assert oracle.L.orc_table_from_registers(*args, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size), ctypes.byref(nr), ctypes.byref(nc)) == 0
+    return out
+
+
+# ---- compiler / VM ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("v", V["compile"])
+def test_compile_golden(oracle, host, v):
+    assert oracle.compile(v["code"]) == v["expected"]
+    assert host.compile(v["code"]) == v["expected"]
+
+
+def test_compile_strips_whitespace(oracle, host):
+    # compiler.rs:50-59 (test_whitespace)
+    assert oracle.compile(" +  +> , < [> + .< - ]  ") == oracle.compile("++>,<[>+.<-]")
+    assert host.compile(" +  +> , < [> + .< - ]  ") == host.compile("++>,<[>+.<-]")
+
+
+@pytest.mark.parametrize("v", V["trace"])
+def test_trace_golden(oracle, host, v):
+    _, tr = oracle.run(v["code"], bytes(v["input"]))
+    assert tr.tolist() == v["expected"]
+    _, tr2 = host.run(v["code"], bytes(v["input"]))
+    assert tr2.tolist() == v["expected"]
+
+
+@pytest.mark.parametrize("v", V["vm_outputs"], ids=lambda v: v["program"])
+def test_vm_outputs_golden(oracle, host, v):
+    out, tr = oracle.run(prog(v["program"]), bytes(v["input"]))
+    assert list(out) == v["expected"]
+    out2, tr2 = host.run(prog(v["program"]), bytes(v["input"]))
+    assert list(out2) == v["expected"]
+    assert np.array_equal(tr, tr2)
+
+
+def test_mvi_is_inverse(oracle):
+    _, tr = oracle.run(prog("hello_kakarot.bf"))
+    mv, mvi = tr[:, 5].astype(np.uint64), tr[:, 6].astype(np.uint64)
+    assert np.all(((mv * mvi) % P)[mv != 0] == 1) and np.all(mvi[mv == 0] == 0)
+
+
+# ---- tables -----------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("v", V["tables"], ids=lambda v: f"component{v['component']}")
+def test_tables_golden(oracle, host, v):
+    if "trace" in v:
+        trace, code_words = v["trace"], v["code_words"]
+    else:
+        _, trace = oracle.run(v["code"], bytes(v["input"]))
+        code_words = oracle.compile(v["code"])
+    want = np.array(v["expected"], dtype=np.uint32)
+    assert np.array_equal(oracle_table_from_registers(oracle, trace, code_words, v["component"]), want)
+    assert np.array_equal(host.table(trace, code_words, v["component"]), want)
+
+
+@pytest.mark.parametrize("name,inp", [("hello_kakarot.bf", b""), ("collatz.bf", b"7\n"), ("a-bc.bf", b"a"), ("loop.bf", b"")])
+def test_host_tables_equal_oracle_tables(oracle, host, name, inp):
+    code = prog(name)
+    _, trace = oracle.run(code, inp)
+    cw = oracle.compile(code)
+    for comp in range(13):
+        assert np.array_equal(host.table(trace, cw, comp), oracle.table(code, inp, comp)), f"component {comp}"
+
+
+@pytest.mark.parametrize("v", V["log_sizes"], ids=lambda v: v["program"])
+def test_log_sizes(oracle, v):
+    ls, steps = oracle.log_sizes(prog(v["program"]), bytes(v["input"]))
+    assert ls == v["expected"] and steps == v["steps"]
+
+
+def test_empty_subcomponent_gets_one_dummy_row(oracle):
+    # instructions/table.rs:293-307: 0usize.next_power_of_two() == 1 -> one dummy entry -> log_size 4
+    t = oracle.table("+", b"", 6)  # no ',' in the program
+    assert t.shape == (1, 11) and t[0, 7] == 1 and not t[0, :7].any()
+
+
+def test_end_of_execution_requires_exactly_one_row(oracle):
+    # end_of_execution/table.rs:75-77 — exactly one row with ci == 0, always the last trace row
+    t = oracle.table("++", b"", 12)
+    assert t.shape == (1, 7) and t[0, 2] == 0 and t[0, 0] == 2
+
+
+# ---- hashing ----------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("v", V["blake2s"])
+def test_blake2s_kat(oracle, v):
+    assert oracle.blake2s(bytes.fromhex(v["msg_hex"])).hex() == v["digest_hex"]
+
+
+def test_blake2s_matches_hashlib_on_random_lengths(oracle):
+    import hashlib
+    rng = np.random.default_rng(7)
+    for n in [1, 31, 32, 63, 64, 65, 127, 128, 129, 1000]:
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.blake2s(m) == hashlib.blake2s(m).digest()
