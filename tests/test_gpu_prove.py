@@ -34,3 +34,48 @@ def test_proof_is_deterministic(ctx, pkg):
     a = pkg.prove_brainfuck(*PROGRAMS[0], ctx=ctx, log_max_rows=20)
     b = pkg.prove_brainfuck(*PROGRAMS[0], ctx=ctx, log_max_rows=20)
     assert a == b
+
+
+def _prog(name):
+    return open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "programs", name)).read()
+
+
+def test_hello_kakarot_matches_oracle(ctx, pkg, oracle):
+    """BASELINE config 1 program; LOG_MAX_ROWS = its largest component (17) so the CPU oracle finishes in seconds."""
+    code = _prog("hello_kakarot.bf")
+    got = pkg.prove_brainfuck(code, b"", ctx=ctx, log_max_rows=17)
+    want, _, _ = oracle.prove(code, b"", log_max_rows=17)
+    assert got == want
+
+
+def test_collatz_matches_oracle(ctx, pkg, oracle):
+    code = _prog("collatz.bf")
+    got = pkg.prove_brainfuck(code, b"7\n", ctx=ctx, log_max_rows=21)
+    want, _, _ = oracle.prove(code, b"7\n", log_max_rows=21)
+    assert got == want
+
+
+def test_fib19_full_size_proof_verifies(pkg, oracle):
+    """BASELINE config 2 at full size (LOG_MAX_ROWS = 24, 2^24-row memory component): too big for the CPU prover in a test, so the
+    size-independent property is used: the oracle's verifier accepts the HIP proof, and rejects it after a one-word change."""
+    c = pkg.Context(0, max_log_domain=26)
+    try:
+        tr = pkg.Trace(c, _prog("fib19.bf"))
+        assert tr.log_sizes == [24, 22, 11, 22, 19, 11, 4, 20, 19, 4, 20, 20, 4] and tr.cells == 403753616
+        proof, _ = tr.prove(24)
+        ok, err = oracle.verify(proof, 24)
+        assert ok, err
+        bad = proof.replace(b'"proof_of_work":', b'"proof_of_work":1', 1)
+        assert not oracle.verify(bad, 24)[0]
+        proof2, _ = tr.prove(24)
+        assert proof2 == proof        # deterministic
+        tr.close()
+    finally:
+        c.close()
+
+
+def test_bad_program_reports_error(ctx, pkg):
+    with pytest.raises(pkg.BfhipError):
+        pkg.prove_brainfuck("+]", b"", ctx=ctx, log_max_rows=20)      # unbalanced bracket
+    with pytest.raises(pkg.BfhipError):
+        pkg.prove_brainfuck(",", b"", ctx=ctx, log_max_rows=20)       # input exhausted (machine.rs:163-169)
