@@ -172,6 +172,209 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast path (transforms of >= 2^12 cells): register-radix butterflies, one LDS round trip per 4 layers.
+//   k_fft_tile12 : contiguous 4096-cell tile, layers [0, k), 6 <= k <= 12. 256 lanes x 16 cells. Layers 0,1 and 10,11 are done
+//                  in registers on the 16-byte global accesses; layers 2..5 and 6..9 are two radix-16 rounds through LDS.
+//   k_fft_strided7: 128 rows x 32 cells (128-B rows at stride 2^lo), layers [lo, lo+7). 128 lanes x 32 cells. Layers lo..lo+2 in
+//                  registers on the 16-byte accesses, layers lo+3..lo+6 as one radix-16 round with 4-byte coalesced row accesses.
+// LDS index padding p(i) = i + 4*(i >> 6) keeps the stride-4 round conflict-free and the 16-byte accesses aligned.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool INV> __device__ __forceinline__ void bfly(u32& x, u32& y, u32 t) {
+    if (INV) { u32 s = m_add(x, y); y = m_mul(m_sub(x, y), t); x = s; }
+    else { u32 w = m_mul(y, t); y = m_sub(x, w); x = m_add(x, w); }
+}
+// radix-16 over the 4 local bits of v[16]; tw(jl, idx) returns the twiddle of local layer jl for pair index (e >> (jl+1)).
+template <bool INV, class TW> __device__ __forceinline__ void radix16(u32 (&v)[16], u32 nlayers, TW tw) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int jl = INV ? s : 3 - s;
+        if ((u32)jl < nlayers) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int e0 = ((b >> jl) << (jl + 1)) | (b & ((1 << jl) - 1));
+                bfly<INV>(v[e0], v[e0 | (1 << jl)], tw(jl, e0 >> (jl + 1)));
+            }
+        }
+    }
+}
+__device__ __forceinline__ u32 lds_pad(u32 i) { return i + 4 * (i >> 6); }
+
+template <bool INV>
+__global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_val[4096 + 4 * 64];
+    __shared__ u32 s_tw[4096];
+    const u32 t = threadIdx.x, k = a.k, tile = blockIdx.x;
+    const u32 base = tile << 12;
+    // stage twiddles of local layers j < k: entry (j, q) at 4096 - 2^(12-j) + q, q < 2^(11-j); global h = (tile << (11-j)) + q
+    for (u32 e = t; e < 4096u - (4096u >> k); e += 256) {
+        u32 j = __clz(~(e << 20));
+        u32 q = e - (4096u - (4096u >> j));
+        u32 h = (tile << (11 - j)) + q;
+        u32 v;
+        if (a.circle && j == 0) {
+            const u32* l0 = layer_table(a, 1);
+            u32 x = l0[(h >> 2) * 2], y = l0[(h >> 2) * 2 + 1], sel = h & 3;
+            v = sel == 0 ? y : sel == 1 ? m_neg(y) : sel == 2 ? m_neg(x) : x;
+        } else v = layer_table(a, j)[h];
+        s_tw[e] = v;
+    }
+    auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[4096u - (4096u >> layer) + idx]; };
+    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    for (u32 col = col0; col < col1; col++) {
+        const u32* src = a.src[col];
+        u32* dst = a.dst[col];
+        __syncthreads();
+        u32 r[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 v = *reinterpret_cast<const uint4*>(src + ((base + 1024 * q + 4 * t) & a.src_mask));
+            r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
+        }
+        // ---- register stage on the 16-byte groups: layers 0,1 (cells 4t..4t+3 of each quarter q) and 10,11 (across q) --------
+        auto stage_low = [&]() {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int L = INV ? s : 1 - s;
+                if ((u32)L < k) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        u32 i = 1024 * q + 4 * t;
+                        if (L == 0) { bfly<INV>(r[q][0], r[q][1], TW(0, i >> 1)); bfly<INV>(r[q][2], r[q][3], TW(0, (i >> 1) + 1)); }
+                        else { u32 w = TW(1, i >> 2); bfly<INV>(r[q][0], r[q][2], w); bfly<INV>(r[q][1], r[q][3], w); }
+                    }
+                }
+            }
+        };
+        auto stage_high = [&]() {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int L = INV ? 10 + s : 11 - s;
+                if ((u32)L < k) {
+                    if (L == 10) { u32 w0 = TW(10, 0), w1 = TW(10, 1);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { bfly<INV>(r[0][j], r[1][j], w0); bfly<INV>(r[2][j], r[3][j], w1); } }
+                    else { u32 w = TW(11, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { bfly<INV>(r[0][j], r[2][j], w); bfly<INV>(r[1][j], r[3][j], w); } }
+                }
+            }
+        };
+        auto round_lds = [&](u32 first_layer) {
+            // 16 cells per lane with tile-index bits [first_layer, first_layer+4) = e
+            u32 lo_bits = first_layer;                       // 2 or 6
+            u32 lo = t & ((1u << lo_bits) - 1), hi = t >> lo_bits;
+            u32 idx0 = (hi << (lo_bits + 4)) | lo;
+            u32 v[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) v[e] = s_val[lds_pad(idx0 | ((u32)e << lo_bits))];
+            u32 nl = k > first_layer ? k - first_layer : 0;
+            radix16<INV>(v, nl, [&](int jl, int pe) -> u32 { return TW(first_layer + jl, ((hi << 4) >> (jl + 1)) + pe); });
+#pragma unroll
+            for (int e = 0; e < 16; e++) s_val[lds_pad(idx0 | ((u32)e << lo_bits))] = v[e];
+        };
+        auto put = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<uint4*>(&s_val[lds_pad(1024 * q + 4 * t)]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+        };
+        auto get = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { uint4 v = *reinterpret_cast<uint4*>(&s_val[lds_pad(1024 * q + 4 * t)]); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+        };
+        if (INV) {
+            stage_low(); put(); __syncthreads();
+            round_lds(2); __syncthreads();
+            round_lds(6); __syncthreads();
+            get(); stage_high();
+        } else {
+            stage_high(); put(); __syncthreads();
+            round_lds(6); __syncthreads();
+            round_lds(2); __syncthreads();
+            get(); stage_low();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 v = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+            if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+            *reinterpret_cast<uint4*>(dst + base + 1024 * q + 4 * t) = v;
+        }
+    }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(128) k_fft_strided7(PassArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_val[4096];
+    __shared__ u32 s_tw[128];
+    const u32 t = threadIdx.x, lo = a.lo, tile = blockIdx.x;
+    const u32 n_lhi_log = lo - 5;
+    const u32 H = tile >> n_lhi_log, Lhi = tile & ((1u << n_lhi_log) - 1);
+    const u32 base = (H << (lo + 7)) | (Lhi << 5);
+    // twiddles: local layer j (global lo + j) entry q < 2^(6-j) at 128 - 2^(7-j) + q; global h = (H << (6-j)) + q
+    if (t < 127) {
+        u32 j = __clz(~(t << 25));
+        u32 q = t - (128u - (128u >> j));
+        s_tw[t] = layer_table(a, lo + j)[(H << (6 - j)) + q];
+    }
+    auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[128u - (128u >> layer) + idx]; };
+    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    const u32 l4 = 4 * (t & 7), r4 = t >> 3;      // 16-byte phase: rows m = 8*r4 + q (q = 0..7), cells l4..l4+3
+    for (u32 col = col0; col < col1; col++) {
+        const u32* src = a.src[col];
+        u32* dst = a.dst[col];
+        __syncthreads();
+        auto wide_stage = [&](u32 (&r)[8][4]) {   // layers 0..2 over q
+#pragma unroll
+            for (int s = 0; s < 3; s++) {
+                const int jl = INV ? s : 2 - s;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int q0 = ((b >> jl) << (jl + 1)) | (b & ((1 << jl) - 1));
+                    u32 w = TW(jl, (8 * r4 + q0) >> (jl + 1));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bfly<INV>(r[q0][j], r[q0 | (1 << jl)][j], w);
+                }
+            }
+        };
+        auto narrow_task = [&](u32 id, bool from_global, bool to_global) {   // layers 3..6 over e for fixed (mlow3, l)
+            u32 l = id & 31, mlow = id >> 5;
+            u32 v[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                u32 m = 8 * e + mlow;
+                v[e] = from_global ? src[(base | (m << lo) | l) & a.src_mask] : s_val[32 * m + l];
+            }
+            radix16<INV>(v, 4, [&](int jl, int pe) -> u32 { return TW(3 + jl, pe); });
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                u32 m = 8 * e + mlow;
+                if (to_global) dst[base | (m << lo) | l] = (INV && a.scale != 1) ? m_mul(v[e], a.scale) : v[e];
+                else s_val[32 * m + l] = v[e];
+            }
+        };
+        if (INV) {
+            u32 r[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<const uint4*>(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+            wide_stage(r);
+#pragma unroll
+            for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+            __syncthreads();
+            narrow_task(t, false, true);
+            narrow_task(t + 128, false, true);
+        } else {
+            narrow_task(t, true, false);
+            narrow_task(t + 128, true, false);
+            __syncthreads();
+            u32 r[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+            wide_stage(r);
+#pragma unroll
+            for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(dst + (base | ((8 * r4 + q) << lo) | l4)) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+        }
+    }
+}
+
 // Tiny transforms (log <= 5): one thread per column, straight loops over registers/local memory. Only the handful of
 // 16..32-cell columns of empty sub-component tables take this route.
 template <bool INV>
@@ -212,6 +415,38 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
         a.scale = inverse ? m_inv(1u << log) : 1;
         if (inverse) hipLaunchKernelGGL(k_fft_tiny<true>, dim3((ncols + 63) / 64), dim3(64), 0, stream, a);
         else hipLaunchKernelGGL(k_fft_tiny<false>, dim3((ncols + 63) / 64), dim3(64), 0, stream, a);
+        return;
+    }
+    // ---- fast path: 2^12-cell contiguous pass with k0 in [6,12] layers + strided passes of exactly 7 layers ----------------
+    if (log >= 12 && nl >= 6) {
+        u32 ns = nl > 12 ? (nl - 12 + 6) / 7 : 0;
+        u32 k0 = nl - 7 * ns;
+        int np = 1 + (int)ns;
+        for (int pi = 0; pi < np; pi++) {
+            int p = inverse ? pi : np - 1 - pi;
+            bool first = pi == 0, last = pi == np - 1;
+            a.src = first ? d_src : (const u32* const*)d_dst;
+            a.dst = d_dst;
+            a.src_mask = first ? ((1u << src_log) - 1) : 0xffffffffu;
+            a.scale = (inverse && last) ? m_inv(1u << log) : 1;
+            u32 ntiles = 1u << (log - 12);
+            // one workgroup walks as many columns as possible per tile (twiddles staged once), as long as >= 2048 workgroups remain
+            u32 cpb = ncols;
+            while (cpb > 1 && (u64)ntiles * ((ncols + cpb - 1) / cpb) < 2048) cpb = (cpb + 1) / 2;
+            a.cols_per_block = cpb;
+            dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
+            if (p == 0) {
+                a.lo = 0; a.k = k0; a.tile_log = 12;
+                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", 8.0 * ncols * (double)(1u << log));
+                if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, a);
+            } else {
+                a.lo = k0 + 7 * (p - 1); a.k = 7;
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", 8.0 * ncols * (double)(1u << log));
+                if (inverse) hipLaunchKernelGGL(k_fft_strided7<true>, grid, dim3(128), 0, stream, a);
+                else hipLaunchKernelGGL(k_fft_strided7<false>, grid, dim3(128), 0, stream, a);
+            }
+        }
         return;
     }
     // pass boundaries: [0, k0) contiguous, then strided passes [k0, k0 + k1), ...

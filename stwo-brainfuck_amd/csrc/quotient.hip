@@ -129,32 +129,60 @@ __device__ __forceinline__ void domain_point(const u32* __restrict__ tw, u32 tw_
 // accumulate_quotients (a9): row value = Horner over sample batches of  (sum_k c_k f_k(row) - (A y + B)) / den(batch, row)
 // with A = sum_k a_k, B = sum_k b_k (line coefficients of complex_conjugate_line_coeffs, pre-summed on the host).
 // ------------------------------------------------------------------------------------------------------------------------------
+// Each lane owns 4 consecutive rows: full-size columns are read as one 16-byte access, replicated columns as one word, and the 4
+// denominators of a batch share one M31 inversion (Montgomery trick on the CM31 norms) — values identical to 4 separate inverses.
 __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
-    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= (1u << a.log)) return;
-    u32 x, y;
-    domain_point(a.tw, a.tw_total, a.log, row, x, y);
-    Q31 acc = q_zero();
+    u32 row0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (row0 >= (1u << a.log)) return;
+    u32 x[4], y[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) domain_point(a.tw, a.tw_total, a.log, row0 + r, x[r], y[r]);
+    Q31 acc[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
     u32 e = 0;
     for (u32 b = 0; b < a.n_batches; b++) {
         const QuotientBatch qb = a.batches[b];
-        Q31 num = q_zero();
+        Q31 num[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
         for (u32 k = 0; k < qb.n_cols; k++, e++) {
             const QuotientEntry qe = a.entries[e];
             ColDesc cd = a.cols[qe.col];
-            num = q_add(num, q_mulm(qe.c, cd.ptr[row >> cd.shift]));
+            if (cd.shift == 0) {
+                uint4 v = *reinterpret_cast<const uint4*>(cd.ptr + row0);
+                num[0] = q_add(num[0], q_mulm(qe.c, v.x)); num[1] = q_add(num[1], q_mulm(qe.c, v.y));
+                num[2] = q_add(num[2], q_mulm(qe.c, v.z)); num[3] = q_add(num[3], q_mulm(qe.c, v.w));
+            } else {
+                Q31 t = q_mulm(qe.c, cd.ptr[row0 >> cd.shift]);    // shift >= 2: the 4 rows share one stored cell
+#pragma unroll
+                for (int r = 0; r < 4; r++) num[r] = q_add(num[r], t);
+            }
         }
-        num = q_sub(num, q_add(q_mulm(qb.a_sum, y), qb.b_sum));
-        // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x   in CM31
-        C31 dx = qb.prx; dx.a = m_sub(dx.a, x);
-        C31 dy = qb.pry; dy.a = m_sub(dy.a, y);
-        C31 den = c_sub(c_mul(dx, qb.piy), c_mul(dy, qb.pix));
-        acc = q_add(q_mul(acc, qb.batch_coeff), q_mulc(num, c_inv(den)));
+        C31 den[4]; u32 nrm[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            num[r] = q_sub(num[r], q_add(q_mulm(qb.a_sum, y[r]), qb.b_sum));
+            // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x   in CM31
+            C31 dx = qb.prx; dx.a = m_sub(dx.a, x[r]);
+            C31 dy = qb.pry; dy.a = m_sub(dy.a, y[r]);
+            den[r] = c_sub(c_mul(dx, qb.piy), c_mul(dy, qb.pix));
+            nrm[r] = m_add(m_sqr(den[r].a), m_sqr(den[r].b));
+        }
+        u32 p01 = m_mul(nrm[0], nrm[1]), p012 = m_mul(p01, nrm[2]), inv_all = m_inv(m_mul(p012, nrm[3]));
+        u32 i3 = m_mul(inv_all, p012), t3 = m_mul(inv_all, nrm[3]);
+        u32 i2 = m_mul(t3, p01), t2 = m_mul(t3, nrm[2]);
+        u32 i1 = m_mul(t2, nrm[0]), i0 = m_mul(t2, nrm[1]);
+        u32 ninv[4] = {i0, i1, i2, i3};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            C31 dinv = {m_mul(den[r].a, ninv[r]), m_neg(m_mul(den[r].b, ninv[r]))};
+            acc[r] = q_add(q_mul(acc[r], qb.batch_coeff), q_mulc(num[r], dinv));
+        }
     }
-    a.out[0][row] = acc.a.a; a.out[1][row] = acc.a.b; a.out[2][row] = acc.b.a; a.out[3][row] = acc.b.b;
+    *reinterpret_cast<uint4*>(a.out[0] + row0) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
+    *reinterpret_cast<uint4*>(a.out[1] + row0) = make_uint4(acc[0].a.b, acc[1].a.b, acc[2].a.b, acc[3].a.b);
+    *reinterpret_cast<uint4*>(a.out[2] + row0) = make_uint4(acc[0].b.a, acc[1].b.a, acc[2].b.a, acc[3].b.a);
+    *reinterpret_cast<uint4*>(a.out[3] + row0) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
 }
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
-    u32 n = 1u << a.log;
+    u32 n = (1u << a.log) / 4;   // 4 rows per lane (all quotient domains have >= 2^5 rows)
     ProfScope ps(stream, "k_quotients", 0);
     hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
