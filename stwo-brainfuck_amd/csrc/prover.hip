@@ -11,6 +11,7 @@
 #include <chrono>
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 
 namespace bf {
 
@@ -81,6 +82,8 @@ struct HipProver {
         c.stage_checkpoint();
         std::map<std::pair<u32, u32>, std::vector<size_t>> groups;   // (dst log_size, shift) -> indices
         for (size_t i = 0; i < dst.size(); i++) groups[{dst[i].log_size, dst[i].shift}].push_back(i);
+        struct Job { size_t off, n; u32 log, src_log, sh; };
+        std::vector<Job> jobs; std::vector<const u32*> ptrs;
         for (auto it = groups.rbegin(); it != groups.rend(); ++it) {
             const auto& idx = it->second;
             u32 log = it->first.first, sh = it->first.second;
@@ -88,13 +91,14 @@ struct HipProver {
             std::map<u32, std::vector<size_t>> by_src;
             for (size_t i : idx) by_src[src[i].log_size].push_back(i);
             for (auto& kv : by_src) {
-                std::vector<const u32*> s; std::vector<u32*> d;
-                for (size_t i : kv.second) { s.push_back(src[i].ptr); d.push_back(dst[i].ptr); }
-                const u32* const* ds = c.stage(s.data(), s.size());
-                u32* const* dd = c.stage(d.data(), d.size());
-                fft_batch(c.stream, inverse, ds, dd, (u32)s.size(), log - sh, kv.first - sh, sh == 0, c.d_tw, c.d_itw, c.tw_root_log);
+                jobs.push_back({ptrs.size(), kv.second.size(), log, kv.first, sh});
+                for (size_t i : kv.second) ptrs.push_back(src[i].ptr);
+                for (size_t i : kv.second) ptrs.push_back(dst[i].ptr);
             }
         }
+        const u32* const* d_ptrs = c.stage(ptrs.data(), ptrs.size());
+        for (auto& j : jobs)
+            fft_batch(c.stream, inverse, d_ptrs + j.off, (u32* const*)(d_ptrs + j.off + j.n), (u32)j.n, j.log - j.sh, j.src_log - j.sh, j.sh == 0, c.d_tw, c.d_itw, c.tw_root_log);
         BF_HIP(hipGetLastError());
     }
 
@@ -108,13 +112,20 @@ struct HipProver {
         mk.layers.resize(mk.max_log + 1);
         for (u32 l = 0; l <= mk.max_log; l++) mk.layers[l] = (u32*)c.arena.alloc(size_t(32) << l);
         u32 min_col_log = cols.back().log_size;
-        size_t ci = 0;
         u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
+        // one staging copy for the column descriptors of every level
+        std::vector<ColDesc> all; std::vector<size_t> off(mk.max_log + 2, 0); std::vector<double> bytes(mk.max_log + 1, 0.0);
+        {
+            size_t ci = 0;
+            for (int log = (int)mk.max_log; log >= 0; log--) {
+                off[log] = all.size();
+                while (ci < cols.size() && cols[ci].log_size == (u32)log) { bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
+            }
+        }
+        const ColDesc* d_all = c.stage(all.data(), all.size());
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
-            std::vector<ColDesc> lc; double col_bytes = 0;
-            while (ci < cols.size() && cols[ci].log_size == (u32)log) { col_bytes += 4.0 * cols[ci].stored(); lc.push_back(cols[ci++].desc()); }
-            const ColDesc* d = lc.empty() ? nullptr : c.stage(lc.data(), lc.size());
-            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, d, (u32)lc.size(), (u32)log, col_bytes);
+            size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
+            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log]);
         }
         if (fused_top > 0) {
             void* const* dl = (void* const*)c.stage(mk.layers.data(), mk.layers.size());
@@ -127,11 +138,12 @@ struct HipProver {
     }
 
     // MerkleProver::decommit — control flow on the host, data through one gather.
-    void decommit(const DevMerkle& mk, const std::vector<DCol>& cols_in, const std::map<u32, std::vector<size_t>>& queries_per_log,
-                  std::vector<u32>& queried_values, MerkleDecommitment& dec) {
+    // Requests go into the shared gather `g`; the returned closure fills the outputs once the gathered words are available.
+    typedef std::function<void(const std::vector<u32>&)> Finisher;
+    Finisher decommit(Gather& g, const DevMerkle& mk, const std::vector<DCol>& cols_in, const std::map<u32, std::vector<size_t>>& queries_per_log,
+                      std::vector<u32>* queried_values, MerkleDecommitment* dec) {
         std::vector<DCol> cols = cols_in;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
-        Gather g;
         struct Slot { int kind; size_t first; };   // kind 0: hash witness (8 words), 1: column witness, 2: queried value
         std::vector<Slot> slots;
         size_t ci = 0;
@@ -163,12 +175,13 @@ struct HipProver {
             }
             last = total;
         }
-        std::vector<u32> data = g.run(c);
-        for (auto& s : slots) {
-            if (s.kind == 0) { Hash32 h; memcpy(h.b, &data[s.first], 32); dec.hash_witness.push_back(h); }
-            else if (s.kind == 1) dec.column_witness.push_back(data[s.first]);
-            else queried_values.push_back(data[s.first]);
-        }
+        return [slots, queried_values, dec](const std::vector<u32>& data) {
+            for (auto& s : slots) {
+                if (s.kind == 0) { Hash32 h; memcpy(h.b, &data[s.first], 32); dec->hash_witness.push_back(h); }
+                else if (s.kind == 1) dec->column_witness.push_back(data[s.first]);
+                else if (queried_values) queried_values->push_back(data[s.first]);
+            }
+        };
     }
 
     // CommitmentTreeProver::new: LDE by the blowup factor, Merkle, mix_root.
@@ -585,6 +598,12 @@ struct HipProver {
             i = j;
         }
     }
+    Finisher gather_secure_deferred(Gather& g, const DSecure& s, const std::vector<size_t>& pos, std::vector<Q31>* out) {
+        size_t first = g.reqs.size();
+        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
+        size_t n = pos.size();
+        return [first, n, out](const std::vector<u32>& d) { for (size_t k = 0; k < n; k++) out->push_back(q_make(d[first + 4 * k], d[first + 4 * k + 1], d[first + 4 * k + 2], d[first + 4 * k + 3])); };
+    }
     std::vector<Q31> gather_secure(const DSecure& s, const std::vector<size_t>& pos) {
         Gather g;
         for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
@@ -677,39 +696,42 @@ struct HipProver {
         }
         std::map<u32, std::vector<size_t>> positions_by_log;
         for (auto& q : quotients) positions_by_log[q.log_size] = fold_queries(queries, max_log - q.log_size);
+        // All decommitment reads (FRI witnesses, Merkle witnesses, queried values) are planned first and fetched by ONE gather launch:
+        // the control flow depends only on the query positions.
+        Gather g;
+        std::vector<Finisher> fin;
         {
             std::map<u32, std::vector<size_t>> dpos;
             for (auto& q : quotients) {
                 std::vector<size_t> pos, wpos;
                 positions_and_witness(fold_queries(queries, max_log - q.log_size), pos, wpos);
                 dpos[q.log_size] = pos;
-                auto w = gather_secure(q, wpos);
-                pf.fri_proof.first_layer.fri_witness.insert(pf.fri_proof.first_layer.fri_witness.end(), w.begin(), w.end());
+                fin.push_back(gather_secure_deferred(g, q, wpos, &pf.fri_proof.first_layer.fri_witness));
             }
-            std::vector<u32> unused;
-            decommit(first_tree, first_cols, dpos, unused, pf.fri_proof.first_layer.decommitment);
+            fin.push_back(decommit(g, first_tree, first_cols, dpos, nullptr, &pf.fri_proof.first_layer.decommitment));
             pf.fri_proof.first_layer.commitment = first_tree.root;
         }
         auto lq = fold_queries(queries, 1);
-        for (auto& in : inner) {
-            FriLayerProof lp;
+        pf.fri_proof.inner_layers.resize(inner.size());
+        for (size_t li = 0; li < inner.size(); li++) {
+            auto& in = inner[li];
+            FriLayerProof& lp = pf.fri_proof.inner_layers[li];
             std::vector<size_t> pos, wpos;
             positions_and_witness(lq, pos, wpos);
-            lp.fri_witness = gather_secure(in.ev, wpos);
+            fin.push_back(gather_secure_deferred(g, in.ev, wpos, &lp.fri_witness));
             std::map<u32, std::vector<size_t>> dpos; dpos[in.ev.log_size] = pos;
-            std::vector<u32> unused;
-            decommit(in.tree, secure_cols(in.ev), dpos, unused, lp.decommitment);
+            fin.push_back(decommit(g, in.tree, secure_cols(in.ev), dpos, nullptr, &lp.decommitment));
             lp.commitment = in.tree.root;
-            pf.fri_proof.inner_layers.push_back(std::move(lp));
             lq = fold_queries(lq, 1);
         }
-        for (auto& t : trees) {
-            std::vector<u32> qv; MerkleDecommitment d;
-            decommit(t.mk, t.evals, positions_by_log, qv, d);
-            pf.queried_values.push_back(qv);
-            pf.decommitments.push_back(d);
-            pf.commitments.push_back(t.mk.root);
+        pf.queried_values.resize(trees.size());
+        pf.decommitments.resize(trees.size());
+        for (size_t ti = 0; ti < trees.size(); ti++) {
+            fin.push_back(decommit(g, trees[ti].mk, trees[ti].evals, positions_by_log, &pf.queried_values[ti], &pf.decommitments[ti]));
+            pf.commitments.push_back(trees[ti].mk.root);
         }
+        std::vector<u32> data = g.run(c);
+        for (auto& f : fin) f(data);
         tm.decommit = now() - t0;
     }
 };
