@@ -34,7 +34,8 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
                const u32* tw, const u32* itw, u32 tw_root_log);
 
 // merkle.hip
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes);
+// out_shift / prev_shift: replication of this layer / of the child layer (nodes are stored at index node >> shift)
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift);
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
 

@@ -45,9 +45,14 @@ __device__ __forceinline__ void blake2s_compress(u32 h[8], const u32 m[16], u32 
 }
 
 // One Merkle layer of 2^log nodes. prev == nullptr for the deepest layer. Requires has_prev || ncols > 0 ... or hashes the empty string.
-__global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// Replication-aware: when every input of a layer is replicated (row-granular columns and/or a replicated child layer), nodes
+// i and i' with i >> out_shift == i' >> out_shift hash identical messages, so only 2^(log - out_shift) nodes are computed and
+// stored; readers index `node >> shift`. Hash values are exactly those of the full layer.
+__global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
+                                                      u32 out_shift, u32 prev_shift) {
+    u32 st = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st >= n_stored) return;
+    const u32 i = st << out_shift;          // representative node of this stored slot
     u32 h[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
@@ -57,13 +62,14 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
     u32 done = 0;   // bytes compressed so far
     u32 c0 = 0;     // next column to absorb
     if (prev) {
-        uint4 a = prev[4 * (size_t)i], b = prev[4 * (size_t)i + 1], c = prev[4 * (size_t)i + 2], d = prev[4 * (size_t)i + 3];
+        const size_t cl = ((size_t)2 * i) >> prev_shift, cr = ((size_t)2 * i + 1) >> prev_shift;   // stored slots of the two children
+        uint4 a = prev[2 * cl], b = prev[2 * cl + 1], c = prev[2 * cr], d = prev[2 * cr + 1];
         m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
         m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
         done = 64;
         bool last = total_bytes == 64;
         blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
-        if (last) { out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]); return; }
+        if (last) { out[2 * (size_t)st] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]); return; }
     }
     // remaining message: column values, 16 words per block (zero padded)
     for (;;) {
@@ -80,8 +86,8 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
         blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
         if (last) break;
     }
-    out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]);
-    out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+    out[2 * (size_t)st] = make_uint4(h[0], h[1], h[2], h[3]);
+    out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 
 // Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
@@ -106,11 +112,11 @@ __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ l
 }
 
 // col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes) {
-    u32 n = 1u << log;
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift) {
+    u32 n = (1u << log) >> out_shift;
     u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
     ProfScope ps(stream, "k_merkle_layer", (prev ? 64.0 * n : 0.0) + 32.0 * n + col_bytes);
-    hipLaunchKernelGGL(k_merkle_layer, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n);
+    hipLaunchKernelGGL(k_merkle_layer, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift);
 }
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
     ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));

@@ -22,7 +22,7 @@ struct DCol {
     size_t stored() const { return size_t(1) << (log_size - shift); }
     ColDesc desc() const { return ColDesc{ptr, shift, 0}; }
 };
-struct DevMerkle { std::vector<u32*> layers; u32 max_log = 0; Hash32 root; };
+struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; };   // layer k: node i stored at i >> shifts[k]
 struct DTree { std::vector<DCol> polys, evals; DevMerkle mk; };
 struct DSecure { u32* c[4]; u32 log_size; };
 
@@ -110,22 +110,28 @@ struct HipProver {
         DevMerkle mk;
         mk.max_log = cols[0].log_size;
         mk.layers.resize(mk.max_log + 1);
-        for (u32 l = 0; l <= mk.max_log; l++) mk.layers[l] = (u32*)c.arena.alloc(size_t(32) << l);
+        mk.shifts.assign(mk.max_log + 1, 0);
         u32 min_col_log = cols.back().log_size;
-        u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
-        // one staging copy for the column descriptors of every level
+        // one staging copy for the column descriptors of every level; replication shift of every level
         std::vector<ColDesc> all; std::vector<size_t> off(mk.max_log + 2, 0); std::vector<double> bytes(mk.max_log + 1, 0.0);
         {
             size_t ci = 0;
             for (int log = (int)mk.max_log; log >= 0; log--) {
                 off[log] = all.size();
-                while (ci < cols.size() && cols[ci].log_size == (u32)log) { bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
+                u32 sh = log < (int)mk.max_log ? (mk.shifts[log + 1] ? mk.shifts[log + 1] - 1 : 0) : 32;
+                while (ci < cols.size() && cols[ci].log_size == (u32)log) { sh = std::min(sh, cols[ci].shift); bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
+                mk.shifts[log] = std::min<u32>(sh == 32 ? 0 : sh, (u32)log);
+                mk.layers[log] = (u32*)c.arena.alloc((size_t(32) << log) >> mk.shifts[log]);
             }
         }
-        const ColDesc* d_all = c.stage(all.data(), all.size());
+        u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
+        while (fused_top > 0 && mk.shifts[fused_top] != 0) fused_top--;   // the fused kernel expects un-replicated layers
+        if (mk.shifts[fused_top] != 0) fused_top = 0;
+        const ColDesc* d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
-            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log]);
+            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
+                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0);
         }
         if (fused_top > 0) {
             void* const* dl = (void* const*)c.stage(mk.layers.data(), mk.layers.size());
@@ -153,6 +159,7 @@ struct HipProver {
             std::vector<DCol> lc;
             while (ci < cols.size() && cols[ci].log_size == (u32)log) lc.push_back(cols[ci++]);
             const u32* prev_hashes = log < (int)mk.max_log ? mk.layers[log + 1] : nullptr;
+            const u32 prev_shift = log < (int)mk.max_log ? mk.shifts[log + 1] : 0;
             auto it = queries_per_log.find((u32)log);
             const std::vector<size_t>& colq = it == queries_per_log.end() ? empty : it->second;
             std::vector<size_t> total;
@@ -165,7 +172,7 @@ struct HipProver {
                 if (prev_hashes) {
                     for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
                         if (pi < last.size() && last[pi] == child) pi++;
-                        else { size_t f = g.reqs.size(); for (u32 w = 0; w < 8; w++) g.add(prev_hashes, child * 8 + w); slots.push_back({0, f}); }
+                        else { size_t f = g.reqs.size(); for (u32 w = 0; w < 8; w++) g.add(prev_hashes, (child >> prev_shift) * 8 + w); slots.push_back({0, f}); }
                     }
                 }
                 bool queried = qi < colq.size() && colq[qi] == node;
