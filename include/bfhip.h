@@ -56,6 +56,32 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
  * CanonicCoset(log_eval).circle_domain(), log_eval >= log_size. replicated as above (output is row-granular, 2^(log_eval-4) cells). */
 int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* const* dst_cols_h, uint32_t n_cols, uint32_t log_size, uint32_t log_eval, int32_t replicated);
 
+/* ---- single backend operations (each is what one stwo trait method would call; all reached from mod.rs:732 prover::prove unless noted) ----
+ * A secure (QM31) column is passed as 4 coordinate pointers. Values/points passed from the host are u32[4] per QM31. */
+
+/* ColumnOps::bit_reverse_column: dst[bit_reverse(i)] = src[i] (out of place), 2^log_size cells. */
+int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size);
+/* FieldOps::batch_inverse over M31 (used by LogupTraceGenerator::finalize_col, memory/table.rs:513): dst[i] = src[i]^-1, src[i] != 0. */
+int32_t bfhip_batch_inverse_m31(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, size_t n);
+/* AccumulationOps::accumulate: dst[i] += src[i] in M31. */
+int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d, size_t n);
+/* PolyOps::eval_at_point (CommitmentSchemeProver::prove_values): f(P) for P = (x, y) in QM31^2 given as u32[8] = x[4] || y[4];
+ * coeffs_d holds 2^log_size coefficients (replicated != 0: the 2^(log_size-4) coefficients of index 0 mod 16). out_h = u32[4]. */
+int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t log_size, int32_t replicated, const uint32_t point_h[8], uint32_t out_h[4]);
+/* MerkleOps<Blake2sMerkleHasher>::commit_on_layer (tree_builder.commit, mod.rs:500,583,723): 2^log_size nodes,
+ * node i = Blake2s(prev[2i] || prev[2i+1] || LE u32 of cols[k][i >> col_shift[k]] for k < n_cols); prev_layer_d may be NULL (deepest
+ * layer). col_shifts_h may be NULL (all 0). Hashes are 32-byte records. */
+int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
+                                  uint32_t n_cols, void* out_hashes_d);
+/* FriOps::fold_line: 2^log_size evaluations over LineDomain(Coset::half_odds(log_size)) -> 2^(log_size-1); alpha_h = u32[4]. */
+int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]);
+/* FriOps::fold_circle_into_line: dst = dst * alpha^2 + fold(src); src has 2^log_size cells on CanonicCoset(log_size).circle_domain(). */
+int32_t bfhip_fold_circle_into_line(bfhip_ctx* ctx, uint32_t* const dst_d[4], const uint32_t* const src_d[4], uint32_t log_size, const uint32_t alpha_h[4]);
+/* GrindOps::grind for Blake2sChannel: smallest nonce such that mix_u64(nonce) on `digest_h` (32 bytes) leaves >= pow_bits trailing zeros. */
+int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bits, uint64_t* nonce);
+/* Decommitment reads: out_h[j] = col_d[idx_h[j]] for n positions of one column. */
+int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_h, size_t n, uint32_t* out_h);
+
 /* prove_brainfuck (crates/brainfuck_prover/src/brainfuck_air/mod.rs:471-735), device resident: compiles and runs `code` on the
  * host VM (crates/brainfuck_vm), builds the 13 component tables, then commits, evaluates constraints, samples, builds the FRI
  * quotients, runs FRI, grinds and decommits on the GPU. *proof_json receives the serde_json form of BrainfuckProof (mod.rs:71-76),

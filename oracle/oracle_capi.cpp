@@ -95,6 +95,32 @@ int orc_eval_at_point(const u32* coeffs, u32 log_size, const u32 point[8], u32 o
     return 0;
 }
 
+// FRI folds on secure columns given as 4 coordinate arrays (stwo backend/cpu/fri.rs).
+int orc_fold_line(const u32* const src[4], u32 log, const u32 alpha[4], u32* const dst[4]) {
+    ORC_TRY
+    size_t n = size_t(1) << log;
+    std::vector<QM31> ev(n);
+    for (size_t i = 0; i < n; i++) ev[i] = QM31::from_u32(src[0][i], src[1][i], src[2][i], src[3][i]);
+    auto out = fold_line(ev, log, QM31::from_u32(alpha[0], alpha[1], alpha[2], alpha[3]));
+    for (size_t i = 0; i < out.size(); i++) { auto a = out[i].to_u32(); for (int k = 0; k < 4; k++) dst[k][i] = a[k]; }
+    return 0;
+    ORC_CATCH
+}
+int orc_fold_circle_into_line(u32* const dst[4], const u32* const src[4], u32 log, const u32 alpha[4]) {
+    ORC_TRY
+    size_t n = size_t(1) << log;
+    SecureCol s; s.init(log);
+    for (int k = 0; k < 4; k++) memcpy(s.c[k].data(), src[k], 4 * n);
+    std::vector<QM31> d(n / 2);
+    for (size_t i = 0; i < n / 2; i++) d[i] = QM31::from_u32(dst[0][i], dst[1][i], dst[2][i], dst[3][i]);
+    fold_circle_into_line(d, s, QM31::from_u32(alpha[0], alpha[1], alpha[2], alpha[3]));
+    for (size_t i = 0; i < n / 2; i++) { auto a = d[i].to_u32(); for (int k = 0; k < 4; k++) dst[k][i] = a[k]; }
+    return 0;
+    ORC_CATCH
+}
+// Nonce search on an explicit digest.
+u64 orc_grind_digest(const u8 digest[32], u32 pow_bits) { Channel c; memcpy(c.digest.b, digest, 32); return grind(c, pow_bits); }
+
 // ---- hashing / channel / Merkle ---------------------------------------------------------------------------------------------
 int orc_blake2s(const u8* data, size_t len, u8 out[32]) { Hash32 h = Blake2s::hash(data, len); memcpy(out, h.b, 32); return 0; }
 // cols: n pointers, logs: n log sizes. Writes every layer's hashes contiguously, deepest layer first, if layers_out != NULL.

@@ -93,6 +93,44 @@ class Context:
     def evaluate(self, coeff_ptrs, dst_ptrs, log_size, log_eval, replicated=False):
         _check(lib().bfhip_evaluate(self._h, self._ptr_array(coeff_ptrs), self._ptr_array(dst_ptrs), len(coeff_ptrs), log_size, log_eval, int(replicated)))
 
+    def eval_at_point(self, coeff_ptr, log_size, point8, replicated=False):
+        pt = (ctypes.c_uint32 * 8)(*[int(v) for v in point8])
+        out = (ctypes.c_uint32 * 4)()
+        _check(lib().bfhip_eval_at_point(self._h, ctypes.c_void_p(coeff_ptr), log_size, int(replicated), pt, out))
+        return list(out)
+
+    # -- ColumnOps / FieldOps / AccumulationOps ---------------------------------------------------------------------------------
+    def bit_reverse(self, src_ptr, dst_ptr, log_size):
+        _check(lib().bfhip_bit_reverse(self._h, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), log_size))
+
+    def batch_inverse_m31(self, src_ptr, dst_ptr, n):
+        _check(lib().bfhip_batch_inverse_m31(self._h, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), ctypes.c_size_t(n)))
+
+    def accumulate(self, dst_ptr, src_ptr, n):
+        _check(lib().bfhip_accumulate(self._h, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(n)))
+
+    # -- MerkleOps / FriOps / GrindOps -------------------------------------------------------------------------------------------------
+    def merkle_commit_layer(self, log_size, prev_ptr, col_ptrs, out_ptr, col_shifts=None):
+        sh = None if col_shifts is None else (ctypes.c_uint32 * len(col_shifts))(*col_shifts)
+        _check(lib().bfhip_merkle_commit_layer(self._h, log_size, ctypes.c_void_p(prev_ptr) if prev_ptr else None, self._ptr_array(col_ptrs), sh, len(col_ptrs), ctypes.c_void_p(out_ptr)))
+
+    def fold_line(self, src_ptrs, dst_ptrs, log_size, alpha4):
+        _check(lib().bfhip_fold_line(self._h, self._ptr_array(src_ptrs), self._ptr_array(dst_ptrs), log_size, (ctypes.c_uint32 * 4)(*[int(v) for v in alpha4])))
+
+    def fold_circle_into_line(self, dst_ptrs, src_ptrs, log_size, alpha4):
+        _check(lib().bfhip_fold_circle_into_line(self._h, self._ptr_array(dst_ptrs), self._ptr_array(src_ptrs), log_size, (ctypes.c_uint32 * 4)(*[int(v) for v in alpha4])))
+
+    def grind(self, digest32, pow_bits):
+        nonce = ctypes.c_uint64()
+        _check(lib().bfhip_grind(self._h, bytes(digest32), pow_bits, ctypes.byref(nonce)))
+        return nonce.value
+
+    def gather(self, col_ptr, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        out = np.empty(idx.size, dtype=np.uint32)
+        _check(lib().bfhip_gather(self._h, ctypes.c_void_p(col_ptr), idx.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(idx.size), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def twiddles(self):
         tw, itw, rl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
         _check(lib().bfhip_twiddles(self._h, ctypes.byref(tw), ctypes.byref(itw), ctypes.byref(rl)))

@@ -2,6 +2,7 @@
 #include "../../include/bfhip.h"
 #include "ctx.h"
 #include <cstdio>
+#include <vector>
 
 using namespace bf;
 
@@ -113,6 +114,103 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
     auto* d = c.stage(dst_cols_h, n_cols);
     fft_batch(c.stream, false, (const u32* const*)s, (u32* const*)d, n_cols, log_eval - sh, log_size - sh, !replicated, c.d_tw, c.d_itw, c.tw_root_log);
     BF_HIP(hipGetLastError());
+    return 0;
+    API_CATCH
+}
+
+
+int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size) {
+    API_TRY if (src_d == dst_d) throw HipError("bit_reverse is out of place"); bit_reverse(ctx->c.stream, src_d, dst_d, log_size); BF_HIP(hipGetLastError()); return 0; API_CATCH
+}
+int32_t bfhip_batch_inverse_m31(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, size_t n) {
+    API_TRY batch_inverse_m31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+}
+int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d, size_t n) {
+    API_TRY accumulate(ctx->c.stream, dst_d, src_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+}
+int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t log_size, int32_t replicated, const uint32_t point_h[8], uint32_t out_h[4]) {
+    API_TRY
+    Ctx& c = ctx->c;
+    if (replicated && log_size < 4) throw HipError("replicated columns need log_size >= 4");
+    c.stage_checkpoint();
+    uint4 factors[32];
+    Q31 x = q_make(point_h[0], point_h[1], point_h[2], point_h[3]);
+    factors[0] = make_uint4(point_h[4], point_h[5], point_h[6], point_h[7]);
+    for (u32 b = 1; b < 32; b++) { factors[b] = make_uint4(x.a.a, x.a.b, x.b.a, x.b.b); Q31 s = q_mul(x, x); x = q_subm(q_add(s, s), 1); }
+    EvalJob job{coeffs_d, replicated ? log_size - 4 : log_size, 0, replicated ? 4u : 0u, 0};
+    const EvalJob* dj = c.stage(&job, 1);
+    const uint4* df = c.stage(factors, 32);
+    u32 nchunks = job.log_n > 12 ? 1u << (job.log_n - 12) : 1u;
+    uint4* partials = nullptr; uint4* dout = nullptr;
+    BF_HIP(hipMalloc((void**)&partials, sizeof(uint4) * (nchunks + 1)));
+    dout = partials + nchunks;
+    eval_at_points(c.stream, dj, 1, job.log_n, df, partials, dout);
+    uint4 r;
+    hipError_t e = hipMemcpyAsync(&r, dout, sizeof(uint4), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    (void)hipFree(partials);
+    BF_HIP(e);
+    out_h[0] = r.x; out_h[1] = r.y; out_h[2] = r.z; out_h[3] = r.w;
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
+                                  uint32_t n_cols, void* out_hashes_d) {
+    API_TRY
+    Ctx& c = ctx->c;
+    c.stage_checkpoint();
+    std::vector<ColDesc> d(n_cols);
+    for (u32 k = 0; k < n_cols; k++) d[k] = ColDesc{cols_h[k], col_shifts_h ? col_shifts_h[k] : 0u, 0};
+    const ColDesc* dd = n_cols ? c.stage(d.data(), n_cols) : nullptr;
+    merkle_layer(c.stream, out_hashes_d, prev_layer_d, dd, n_cols, log_size, 0.0, 0, 0);
+    BF_HIP(hipGetLastError());
+    return 0;
+    API_CATCH
+}
+static Q31 q_from_h(const uint32_t v[4]) { return q_make(v[0], v[1], v[2], v[3]); }
+int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
+    API_TRY
+    if (log_size < 1 || log_size > ctx->c.tw_root_log) throw HipError("fold_line: log_size outside the twiddle tree");
+    fold_line(ctx->c.stream, dst_d, src_d, q_from_h(alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
+    API_CATCH
+}
+int32_t bfhip_fold_circle_into_line(bfhip_ctx* ctx, uint32_t* const dst_d[4], const uint32_t* const src_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
+    API_TRY
+    if (log_size < 3 || log_size > ctx->c.tw_root_log + 1) throw HipError("fold_circle_into_line: log_size outside the twiddle tree");
+    fold_circle_into_line(ctx->c.stream, dst_d, src_d, q_from_h(alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
+    API_CATCH
+}
+int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bits, uint64_t* nonce) {
+    API_TRY
+    Ctx& c = ctx->c;
+    c.stage_checkpoint();
+    u32* d_digest = (u32*)c.stage(digest_h, 32);
+    unsigned long long init = ~0ull, best = ~0ull;
+    unsigned long long* d_best = c.stage(&init, 1);
+    const u32 span = 1u << 20;
+    for (u64 base = 0; best == ~0ull; base += span) {
+        grind_span(c.stream, d_digest, base, span, pow_bits, d_best);
+        BF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        if (base > (u64(1) << 40)) throw HipError("grind: no nonce found below 2^40");
+    }
+    *nonce = best;
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_h, size_t n, uint32_t* out_h) {
+    API_TRY
+    Ctx& c = ctx->c;
+    std::vector<GatherReq> req(n);
+    for (size_t i = 0; i < n; i++) req[i] = GatherReq{col_d, idx_h[i]};
+    GatherReq* dreq = nullptr; u32* dout = nullptr;
+    BF_HIP(hipMalloc((void**)&dreq, sizeof(GatherReq) * (n + 1)));
+    hipError_t e = hipMalloc((void**)&dout, sizeof(u32) * (n + 1));
+    if (e == hipSuccess) e = hipMemcpyAsync(dreq, req.data(), sizeof(GatherReq) * n, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) { gather_u32(c.stream, dreq, (u32)n, dout); e = hipMemcpyAsync(out_h, dout, sizeof(u32) * n, hipMemcpyDeviceToHost, c.stream); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    (void)hipFree(dreq); (void)hipFree(dout);
+    BF_HIP(e);
     return 0;
     API_CATCH
 }

@@ -254,6 +254,25 @@ void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n) {
     hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, n);
 }
 
+// FieldOps::batch_inverse over M31: 8 elements per lane share one inversion (Montgomery trick) — values equal elementwise inverses.
+__global__ void __launch_bounds__(256) k_batch_inverse_m31(const u32* __restrict__ src, u32* __restrict__ dst, u32 n) {
+    u32 base = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (base >= n) return;
+    u32 v[8], pre[8];
+    u32 cnt = min(8u, n - base);
+    u32 acc = 1;
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) { v[k] = k < cnt ? src[base + k] : 1u; pre[k] = acc; acc = m_mul(acc, v[k]); }
+    u32 inv = m_inv(acc);
+#pragma unroll
+    for (int k = 7; k >= 0; k--) { u32 r = m_mul(inv, pre[k]); inv = m_mul(inv, v[k]); if ((u32)k < cnt) dst[base + k] = r; }
+}
+void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n) {
+    if (!n) return;
+    u32 lanes = (n + 7) / 8;
+    hipLaunchKernelGGL(k_batch_inverse_m31, dim3((lanes + 255) / 256), dim3(256), 0, stream, src, dst, n);
+}
+
 // ColumnOps::bit_reverse_column (not on the prove path — the reference stores traces already bit-reversed — but part of the
 // backend surface): out-of-place permutation.
 __global__ void k_bit_reverse(const u32* __restrict__ src, u32* __restrict__ dst, u32 log) {
