@@ -6,6 +6,8 @@
 #include "vm.h"
 #include <algorithm>
 #include <stdexcept>
+#include <thread>
+#include <exception>
 
 namespace bf {
 
@@ -25,42 +27,53 @@ struct Table {
 static inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }  // usize::next_power_of_two (0 -> 1)
 static inline u32 madd(u32 a, u32 b) { return m_add(a, b % P31); }
 
-// --- Memory: memory/table.rs:249-303 (sort, gap-fill, pad), :121-151 (pairing) -------------------------------------
-struct MemEntry { u32 clk, mp, mv, d; };
-static inline std::vector<MemEntry> memory_intermediate(const std::vector<Registers>& trace) {
-    std::vector<MemEntry> t;
-    t.reserve(trace.size());
-    for (auto& r : trace) t.push_back({r.clk, r.mp, r.mv, 0});
-    std::stable_sort(t.begin(), t.end(), [](const MemEntry& a, const MemEntry& b) { return a.mp != b.mp ? a.mp < b.mp : a.clk < b.clk; });
-    std::vector<MemEntry> out;
-    if (!t.empty()) {
-        const MemEntry* prev = &t[0];
-        for (auto& e : t) {
-            u32 next_clk = madd(prev->clk, 1);
-            if (e.mp == prev->mp && e.clk > next_clk)
-                for (u32 clk = next_clk; clk < e.clk; clk++) out.push_back({clk, prev->mp, prev->mv, 1});
-            out.push_back(e);
-            prev = &e;
-        }
-    }
-    if (!out.empty()) {
-        MemEntry last = out.back();
-        size_t pad = next_pow2(out.size()) - out.size();
-        for (size_t i = 1; i <= pad; i++) out.push_back({madd(last.clk, (u32)i), last.mp, last.mv, 1});
-    }
-    return out;
-}
+// --- Memory: memory/table.rs:249-303 (sort by (mp, clk), clk-gap fill, pad), :121-151 (pairing) -------------------------------------
+// The VM trace is already ordered by clk, so the stable sort by (mp, clk) is a stable bucketing by mp (counting sort); rows are
+// written straight into the 8 output columns.
 static inline Table memory_table(const std::vector<Registers>& trace) {
-    auto e = memory_intermediate(trace);
     Table t;
-    if (e.empty()) return t;
-    MemEntry last = e.back();
-    e.push_back({madd(last.clk, 1), last.mp, last.mv, 1});
-    t.init(8, e.size() - 1);
-    for (size_t r = 0; r + 1 < e.size(); r++) {
-        t.cols[0][r] = e[r].clk; t.cols[1][r] = e[r].mp; t.cols[2][r] = e[r].mv; t.cols[3][r] = e[r].d;
-        t.cols[4][r] = e[r + 1].clk; t.cols[5][r] = e[r + 1].mp; t.cols[6][r] = e[r + 1].mv; t.cols[7][r] = e[r + 1].d;
+    if (trace.empty()) return t;
+    bool clk_sorted = true;
+    for (size_t i = 1; i < trace.size(); i++) if (trace[i].clk <= trace[i - 1].clk) { clk_sorted = false; break; }
+    std::vector<u32> order(trace.size());
+    u32 max_mp = 0;
+    for (auto& r : trace) max_mp = std::max(max_mp, r.mp);
+    if (clk_sorted && max_mp < (1u << 24)) {
+        std::vector<u32> cnt(max_mp + 2, 0);
+        for (auto& r : trace) cnt[r.mp + 1]++;
+        for (size_t m = 1; m < cnt.size(); m++) cnt[m] += cnt[m - 1];
+        for (size_t i = 0; i < trace.size(); i++) order[cnt[trace[i].mp]++] = (u32)i;
+    } else {
+        for (size_t i = 0; i < trace.size(); i++) order[i] = (u32)i;
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return trace[a].mp != trace[b].mp ? trace[a].mp < trace[b].mp : trace[a].clk < trace[b].clk; });
     }
+    // size after gap fill
+    size_t n = 0;
+    for (size_t k = 0; k < order.size(); k++) {
+        const Registers& e = trace[order[k]];
+        if (k > 0) { const Registers& p = trace[order[k - 1]]; u32 nc = madd(p.clk, 1); if (e.mp == p.mp && e.clk > nc) n += e.clk - nc; }
+        n++;
+    }
+    size_t rows = next_pow2(n);
+    t.init(8, rows);
+    u32 *clk = t.cols[0].data(), *mp = t.cols[1].data(), *mv = t.cols[2].data(), *d = t.cols[3].data();
+    size_t w = 0;
+    auto put = [&](u32 c, u32 p, u32 v, u32 dd) { clk[w] = c; mp[w] = p; mv[w] = v; d[w] = dd; w++; };
+    for (size_t k = 0; k < order.size(); k++) {
+        const Registers& e = trace[order[k]];
+        if (k > 0) {
+            const Registers& p = trace[order[k - 1]];
+            u32 nc = madd(p.clk, 1);
+            if (e.mp == p.mp && e.clk > nc) for (u32 c = nc; c < e.clk; c++) put(c, p.mp, p.mv, 1);
+        }
+        put(e.clk, e.mp, e.mv, 0);
+    }
+    u32 lc = clk[w - 1], lp = mp[w - 1], lv = mv[w - 1];
+    for (size_t i = 1; w < rows; i++) put(madd(lc, (u32)i), lp, lv, 1);
+    // pairing with the next entry; the last row pairs with one more dummy (last.clk + 1, last.mp, last.mv)
+    u32 *nclk = t.cols[4].data(), *nmp = t.cols[5].data(), *nmv = t.cols[6].data(), *nd = t.cols[7].data();
+    for (size_t r = 0; r + 1 < rows; r++) { nclk[r] = clk[r + 1]; nmp[r] = mp[r + 1]; nmv[r] = mv[r + 1]; nd[r] = d[r + 1]; }
+    nclk[rows - 1] = madd(clk[rows - 1], 1); nmp[rows - 1] = mp[rows - 1]; nmv[rows - 1] = mv[rows - 1]; nd[rows - 1] = 1;
     return t;
 }
 
@@ -188,21 +201,32 @@ static inline Table eoe_table(const std::vector<Registers>& trace) {
 }
 
 // All 13 tables in claim/commit order (brainfuck_air/mod.rs:550-562).
+static inline Table build_one_table(int comp, const std::vector<Registers>& trace, const std::vector<u32>& code) {
+    switch (comp) {
+        case C_MEMORY: return memory_table(trace);
+        case C_INSTRUCTION: return instruction_table(trace, code);
+        case C_PROGRAM: return program_table(code);
+        case C_PROCESSOR: return processor_table(trace);
+        case C_JNZ: return jump_table(trace, OP_JNZ);
+        case C_JZ: return jump_table(trace, OP_JZ);
+        case C_INPUT: return instruction_sub_table(trace, OP_READCHAR);
+        case C_LEFT: return instruction_sub_table(trace, OP_LEFT);
+        case C_MINUS: return instruction_sub_table(trace, OP_MINUS);
+        case C_OUTPUT: return instruction_sub_table(trace, OP_PUTCHAR);
+        case C_PLUS: return instruction_sub_table(trace, OP_PLUS);
+        case C_RIGHT: return instruction_sub_table(trace, OP_RIGHT);
+        default: return eoe_table(trace);
+    }
+}
+// The 13 builders are independent: one host thread each (the reference builds them one after the other, mod.rs:511-547).
 static inline std::vector<Table> build_tables(const std::vector<Registers>& trace, const std::vector<u32>& code) {
     std::vector<Table> t(N_COMPONENTS);
-    t[C_MEMORY] = memory_table(trace);
-    t[C_INSTRUCTION] = instruction_table(trace, code);
-    t[C_PROGRAM] = program_table(code);
-    t[C_PROCESSOR] = processor_table(trace);
-    t[C_JNZ] = jump_table(trace, OP_JNZ);
-    t[C_JZ] = jump_table(trace, OP_JZ);
-    t[C_INPUT] = instruction_sub_table(trace, OP_READCHAR);
-    t[C_LEFT] = instruction_sub_table(trace, OP_LEFT);
-    t[C_MINUS] = instruction_sub_table(trace, OP_MINUS);
-    t[C_OUTPUT] = instruction_sub_table(trace, OP_PUTCHAR);
-    t[C_PLUS] = instruction_sub_table(trace, OP_PLUS);
-    t[C_RIGHT] = instruction_sub_table(trace, OP_RIGHT);
-    t[C_EOE] = eoe_table(trace);
+    std::vector<std::exception_ptr> err(N_COMPONENTS);
+    std::vector<std::thread> th;
+    for (int c = 0; c < N_COMPONENTS; c++)
+        th.emplace_back([&, c]() { try { t[c] = build_one_table(c, trace, code); } catch (...) { err[c] = std::current_exception(); } });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
     for (auto& x : t) if (x.n_rows == 0) throw std::runtime_error("EmptyTrace");
     return t;
 }

@@ -41,6 +41,7 @@ struct Machine {
     std::vector<u8> output;
     Registers reg;
     std::vector<Registers> trace;
+    std::vector<u32> inv_memo = std::vector<u32>(1 << 16, 0);   // mv -> mv^-1 for small cell values (same value as m_inv, computed once)
     static constexpr size_t DEFAULT_RAM_SIZE = 30000;  // machine.rs:114
 
     Machine(std::vector<u32> code_, std::vector<u8> input_, size_t ram_size = DEFAULT_RAM_SIZE)
@@ -48,6 +49,7 @@ struct Machine {
 
     // machine.rs:141-161
     void execute() {
+        trace.reserve(1 << 16);
         while (reg.ip < code.size()) {
             reg.ci = code[reg.ip];
             reg.ni = (reg.ip == code.size() - 1) ? 0 : code[reg.ip + 1];
@@ -89,7 +91,9 @@ struct Machine {
             default: throw std::runtime_error("invalid instruction");
         }
         reg.mv = ram.at(reg.mp);
-        reg.mvi = reg.mv == 0 ? 0 : m_inv(reg.mv);
+        if (reg.mv == 0) reg.mvi = 0;
+        else if (reg.mv < inv_memo.size()) { u32& slot = inv_memo[reg.mv]; if (!slot) slot = m_inv(reg.mv); reg.mvi = slot; }
+        else reg.mvi = m_inv(reg.mv);
     }
 };
 
