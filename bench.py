@@ -20,6 +20,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+BLAKE2S_PEAK_GCPS = 39.9   # tools/ubench_blake.hip on MI355X: register-only compression loop, all CUs
+# Blake2s compressions per fib19 proof at LOG_MAX_ROWS = 24 after replication-aware dedup (counted by tools/count_compressions.py)
+MERKLE_COMPRESSIONS_FIB19_LMR24 = 674228124
+
 FIB19 = "+++++++++++++++++>+>+<<[->>[->+>+<<]<[->>+<<]>>[-<+>]>[-<<<+>>>]<<<<]>>."  # tests/golden/programs/fib19.bf (workload input)
 
 
@@ -118,7 +122,16 @@ def main():
         roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
-                    "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
+                    "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])},
+                    "kernels_GBps_moved": {k: round(v["bytes"] / v["total_ms"] / 1e6, 1) for k, v in rep.items() if v["bytes"] > 0}}
+        if name == "k_merkle_layer":
+            # The Merkle kernel is integer-VALU bound, not HBM bound: one Blake2s compression (~977 VALU ops) per 64 message bytes.
+            # Peak = 39.9 G compressions/s measured with tools/ubench_blake.hip (registers only) on the same chip.
+            comp = MERKLE_COMPRESSIONS_FIB19_LMR24 if args.log_max_rows == 24 else None
+            if comp:
+                rate = comp * args.steps / (d["total_ms"] * 1e-3) / 1e9
+                roofline["valu"] = {"unit": "G Blake2s compressions/s", "achieved": round(rate, 2), "peak_measured": BLAKE2S_PEAK_GCPS, "frac": round(rate / BLAKE2S_PEAK_GCPS, 3),
+                                    "compressions_per_proof": comp}
 
     cells = trace.cells
     if rank == 0:

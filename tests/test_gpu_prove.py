@@ -79,3 +79,36 @@ def test_bad_program_reports_error(ctx, pkg):
         pkg.prove_brainfuck("+]", b"", ctx=ctx, log_max_rows=20)      # unbalanced bracket
     with pytest.raises(pkg.BfhipError):
         pkg.prove_brainfuck(",", b"", ctx=ctx, log_max_rows=20)       # input exhausted (machine.rs:163-169)
+
+
+EDGE = [
+    ("+", b""),                      # one instruction: every sub-component but `+` is an empty table (one dummy row, log_size 4)
+    (",", b"\x07"),                  # input only
+    (",.", b"A"),                    # echo
+    ("-", b""),                      # cell wraps to P - 1 (machine.rs:189-192): mvi is a genuine field inverse
+    (">>>><<<<", b""),               # pointer moves only
+    ("[-]", b""),                    # jump-if-zero taken at once: the `]` table stays empty
+    ("+[-]", b""),                   # both jump kinds, each once
+    ("++[>++[>+<-]<-]>>.", b""),     # nested loops
+    (",[.,]", b"ab\x00"),            # input-driven loop
+]
+
+
+@pytest.mark.parametrize("code,inp", EDGE, ids=[e[0] for e in EDGE])
+def test_edge_programs_match_oracle(pkg, oracle, code, inp, small_ctx):
+    got = pkg.prove_brainfuck(code, inp, ctx=small_ctx, log_max_rows=12)
+    want, _, _ = oracle.prove(code, inp, log_max_rows=12)
+    assert got == want
+    assert oracle.verify(got, 12)[0]
+
+
+@pytest.fixture(scope="module")
+def small_ctx(pkg):
+    c = pkg.Context(0, max_log_domain=14)
+    yield c
+    c.close()
+
+
+def test_trace_too_large_for_log_max_rows_is_an_error(pkg, small_ctx):
+    with pytest.raises(pkg.BfhipError, match="LOG_MAX_ROWS"):
+        pkg.prove_brainfuck("++++++++[>++++++++<-]>[<++++>-]", b"", ctx=small_ctx, log_max_rows=6)
