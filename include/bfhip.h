@@ -102,6 +102,11 @@ int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* trace);
 int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                           char** transcript, double* phase_seconds);
 
+/* verify_brainfuck (mod.rs:738-797): replays the channel, checks the logUp sum (mod.rs:207-227), the OODS consistency, the proof of work,
+ * every Merkle decommitment and FRI. Host only (the reference verifies on the CPU as well). Returns 0 = accepted, 1 = rejected with the
+ * reason written to err (VerificationError name), -1 = internal error. */
+int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_t log_max_rows, char* err, size_t err_cap);
+
 /* Host-only pieces of the drop-in (usable without a GPU): the Brainfuck compiler (crates/brainfuck_vm/src/compiler.rs:17-37), the VM
  * (crates/brainfuck_vm/src/machine.rs:141-238; trace rows are 7 u32: clk, ip, ci, ni, mp, mv, mvi) and the 13 table builders
  * (`XTable::from`, the table.rs files under crates/brainfuck_prover/src/components; component index = claim order of mod.rs:85-99), row-major out. */

@@ -165,6 +165,15 @@ def prove_brainfuck(code, input_bytes=b"", ctx=None, log_max_rows=24, with_trans
             ctx.close()
 
 
+def verify_brainfuck(proof_json: bytes, log_max_rows=24):
+    """verify_brainfuck (mod.rs:738): returns (ok, reason). Host only — no GPU needed, like the reference's verifier."""
+    err = ctypes.create_string_buffer(512)
+    rc = lib().bfhip_verify_brainfuck(proof_json, ctypes.c_size_t(len(proof_json)), log_max_rows, err, ctypes.c_size_t(512))
+    if rc < 0:
+        raise BfhipError(lib().bfhip_last_error().decode())
+    return rc == 0, err.value.decode()
+
+
 class Trace:
     """Prover input resident in HBM (bfhip_trace_create): VM trace -> 13 component tables -> row-granular device columns."""
 

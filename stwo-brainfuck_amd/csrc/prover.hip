@@ -6,6 +6,7 @@
 #include "ctx.h"
 #include "host/circle.h"
 #include "host/proof.h"
+#include "host/verifier.h"
 #include <map>
 #include <set>
 #include <chrono>
@@ -204,45 +205,6 @@ struct HipProver {
         ch.mix_root(t.mk.root);
     }
 
-    // ---- host-side OODS evaluation of the constraints (stwo PointEvaluator) -------------------------------------------------------
-    struct PointEval : LogupState<PointEval, Fq> {
-        typedef Fq F;
-        Q31 preproc; const std::vector<Q31>* tvals; const std::vector<Q31>* ivals; int ti = 0, ii = 0;
-        Q31 denom_inverse, random_coeff; Q31* acc;
-        Fq is_first() { return {preproc}; }
-        Fq trace() { return {tvals[ti++][0]}; }
-        Fq cst(u32 k) { return {q_from_m(k)}; }
-        static Q31 combine(const std::vector<Q31>* v, int off) {
-            // SecureField::from_partial_evals: e0 + e1*i + e2*u + e3*iu
-            Q31 r = v[0][off];
-            r = q_add(r, q_mul(v[1][off], q_make(0, 1, 0, 0)));
-            r = q_add(r, q_mul(v[2][off], q_make(0, 0, 1, 0)));
-            r = q_add(r, q_mul(v[3][off], q_make(0, 0, 0, 1)));
-            return r;
-        }
-        Fq inter_cur() { Fq v{combine(ivals + ii, 0)}; ii += 4; return v; }
-        void inter_cur_prev(Fq& cur, Fq& prev) { cur.v = combine(ivals + ii, 0); prev.v = combine(ivals + ii, 1); ii += 4; }
-        void constraint(Fq cv) { *acc = q_add(q_mul(*acc, random_coeff), q_mul(denom_inverse, cv.v)); }
-    };
-    template <int COMP> static void point_eval_one(PointEval& pe, const Lookups& el) { air_eval<COMP>(pe, el); }
-    static void point_eval(int comp, PointEval& pe, const Lookups& el) {
-        switch (comp) {
-            case C_MEMORY: point_eval_one<C_MEMORY>(pe, el); break;
-            case C_INSTRUCTION: point_eval_one<C_INSTRUCTION>(pe, el); break;
-            case C_PROGRAM: point_eval_one<C_PROGRAM>(pe, el); break;
-            case C_PROCESSOR: point_eval_one<C_PROCESSOR>(pe, el); break;
-            case C_JNZ: point_eval_one<C_JNZ>(pe, el); break;
-            case C_JZ: point_eval_one<C_JZ>(pe, el); break;
-            case C_INPUT: point_eval_one<C_INPUT>(pe, el); break;
-            case C_LEFT: point_eval_one<C_LEFT>(pe, el); break;
-            case C_MINUS: point_eval_one<C_MINUS>(pe, el); break;
-            case C_OUTPUT: point_eval_one<C_OUTPUT>(pe, el); break;
-            case C_PLUS: point_eval_one<C_PLUS>(pe, el); break;
-            case C_RIGHT: point_eval_one<C_RIGHT>(pe, el); break;
-            default: point_eval_one<C_EOE>(pe, el); break;
-        }
-    }
-
     struct PointLess {
         bool operator()(const PtQ& a, const PtQ& b) const {
             u32 av[8] = {a.x.a.a, a.x.a.b, a.x.b.a, a.x.b.b, a.y.a.a, a.y.a.b, a.y.b.a, a.y.b.b};
@@ -418,20 +380,10 @@ struct HipProver {
 
         // Sanity check of prover::prove: composition OODS value == constraints evaluated on the sampled mask values.
         {
-            Q31 acc = q_zero();
-            for (int k = 0; k < N_COMPONENTS; k++) {
-                PointEval pe;
-                const auto& pv = bp.proof.sampled_values[0][log_max_rows - bp.log_sizes[k]];
-                pe.preproc = pv[0];
-                pe.tvals = &bp.proof.sampled_values[1][main_off[k]];
-                pe.ivals = &bp.proof.sampled_values[2][inter_off[k]];
-                pe.denom_inverse = q_inv(coset_vanishing_q(bp.log_sizes[k], oods));
-                pe.random_coeff = random_coeff; pe.acc = &acc; pe.total_sum = bp.claimed_sums[k];
-                point_eval(k, pe, el);
-            }
+            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff);
             const auto& cv = bp.proof.sampled_values[3];
             std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
-            if (!q_eq(PointEval::combine(ce, 0), acc)) throw HipError("ConstraintsNotSatisfied");
+            if (!q_eq(HostPointEval::combine(ce, 0), want)) throw HipError("ConstraintsNotSatisfied");
         }
         tm.total = now() - t_start;
         return bp;
@@ -802,6 +754,17 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
     return rc;
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
+
+// verify_brainfuck (mod.rs:738-797). Host only. 0 = accepted, 1 = rejected (reason in err), -1 = internal error.
+extern "C" int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_t log_max_rows, char* err, size_t err_cap) {
+    try {
+        std::string reason;
+        try { BrainfuckProof bp = proof_from_json(proof_json, proof_len); reason = verify_brainfuck(bp, log_max_rows); }
+        catch (const std::exception& e) { reason = std::string("InvalidStructure: ") + e.what(); }
+        if (err && err_cap) snprintf(err, err_cap, "%s", reason.c_str());
+        return reason.empty() ? 0 : 1;
+    } catch (...) { bfhip_set_error("unknown error"); return -1; }
+}
 
 // ---- host-only entry points (no GPU needed): compiler, VM and table builders of the drop-in's host side ---------------------------
 extern "C" int32_t bfhip_host_compile(const char* code, uint32_t* out, size_t cap, size_t* n) {

@@ -28,6 +28,7 @@ def test_proof_bytes_match_oracle(ctx, pkg, oracle, code, inp):
     assert got == want
     ok, err = oracle.verify(got, log_max_rows=20)
     assert ok, err
+    assert pkg.verify_brainfuck(got, 20) == (True, "")          # the product's own host-side verifier (mod.rs:738)
 
 
 def test_proof_is_deterministic(ctx, pkg):
@@ -65,6 +66,7 @@ def test_fib19_full_size_proof_verifies(pkg, oracle):
         proof, _ = tr.prove(24)
         ok, err = oracle.verify(proof, 24)
         assert ok, err
+        assert pkg.verify_brainfuck(proof, 24) == (True, "")
         bad = proof.replace(b'"proof_of_work":', b'"proof_of_work":1', 1)
         assert not oracle.verify(bad, 24)[0]
         proof2, _ = tr.prove(24)
