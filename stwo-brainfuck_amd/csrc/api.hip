@@ -23,6 +23,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipSetDevice(dev));
     BF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
+    BF_HIP(hipHostMalloc((void**)&h_small, 4096));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
     // point tables: G^a and G^(b << 16) for the M31 circle generator G = (2, 1268011823)
     std::vector<uint2> tlo(1 << 16), thi(1 << 15);
@@ -49,6 +50,7 @@ void Ctx::destroy() {
     arena.release();
     (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
     if (h_stage) (void)hipHostFree(h_stage);
+    if (h_small) (void)hipHostFree(h_small);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -39,6 +39,7 @@ struct Ctx {
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
     Arena arena;
     // pinned staging for pointer arrays / small parameter blocks
+    char* h_small = nullptr;   // 4 KiB pinned scratch for deferred tiny device->host results
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
 
     void init(int dev, u32 max_log_domain);

@@ -104,7 +104,8 @@ struct HipProver {
     }
 
     // ---- Merkle (a4) -----------------------------------------------------------------------------------------------------------
-    DevMerkle merkle_commit(const std::vector<DCol>& cols_in) {
+    // defer_root: leave the 32-byte root copy pending in pinned memory (*pinned_root) instead of synchronising the stream.
+    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr) {
         std::vector<DCol> cols = cols_in;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
         c.stage_checkpoint();
@@ -139,6 +140,7 @@ struct HipProver {
             merkle_top(c.stream, dl, fused_top);
         }
         BF_HIP(hipGetLastError());
+        if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
         BF_HIP(hipMemcpyAsync(mk.root.b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream));
         c.sync();
         return mk;
@@ -193,7 +195,7 @@ struct HipProver {
     }
 
     // CommitmentTreeProver::new: LDE by the blowup factor, Merkle, mix_root.
-    void commit_tree(DTree& t) {
+    void commit_tree(DTree& t, Hash32* pinned_root = nullptr) {
         t.evals.resize(t.polys.size());
         for (size_t i = 0; i < t.polys.size(); i++) {
             DCol e; e.log_size = t.polys[i].log_size + cfg.log_blowup; e.shift = t.polys[i].shift;
@@ -201,8 +203,8 @@ struct HipProver {
             t.evals[i] = e;
         }
         fft_cols(false, t.polys, t.evals);
-        t.mk = merkle_commit(t.evals);
-        ch.mix_root(t.mk.root);
+        t.mk = merkle_commit(t.evals, pinned_root);
+        if (!pinned_root) ch.mix_root(t.mk.root);
     }
 
     struct PointLess {
@@ -235,7 +237,11 @@ struct HipProver {
         c.sync();
     }
 
-    BrainfuckProof prove(const TraceInput& in) {
+    BrainfuckProof prove(const TraceInput& in) { return prove([&]() -> const TraceInput& { return in; }); }
+
+    // get_input() runs on the host AFTER the (trace-independent) preprocessed phase has been enqueued, so a caller that still has to
+    // run the VM and build the tables overlaps that host work with GPU work (bfhip_prove_brainfuck does).
+    BrainfuckProof prove(const std::function<const TraceInput&()>& get_input) {
         double t_start = now();
         c.arena.reset();
         ch = Channel();
@@ -251,7 +257,12 @@ struct HipProver {
             trees[0].polys.push_back(p);
         }
         fft_cols(true, trees[0].polys, trees[0].polys);
-        commit_tree(trees[0]);
+        Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
+        commit_tree(trees[0], pinned_root0);
+        const TraceInput& in = get_input();
+        c.sync();
+        trees[0].mk.root = *pinned_root0;
+        ch.mix_root(trees[0].mk.root);
         tap("root0");
         tm.preprocessed = now() - t0;
 
@@ -747,11 +758,22 @@ extern "C" int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, u
 
 extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, uint32_t log_max_rows,
                                           char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
-    bfhip_trace* t = nullptr;
-    if (bfhip_trace_create(ctx, code, input, n_input, &t, nullptr, nullptr, nullptr, nullptr) != 0) return -1;
-    int32_t rc = bfhip_prove_trace(ctx, t, log_max_rows, proof_json, proof_len, transcript, phase_seconds);
-    bfhip_trace_destroy(ctx, t);
-    return rc;
+    TraceInput in;
+    try {
+        HipProver pv(ctx->c, log_max_rows);
+        pv.want_transcript = transcript != nullptr;
+        // VM run + table build + upload happen while the GPU already works on the preprocessed commitment
+        BrainfuckProof bp = pv.prove([&]() -> const TraceInput& {
+            std::vector<u32> ins = compile(code);
+            Machine m(ins, std::vector<u8>(input, input + n_input));
+            m.execute();
+            HipProver::upload_trace(ctx->c, m.trace, ins, in);
+            return in;
+        });
+        fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
+        in.release();
+        return 0;
+    } catch (const std::exception& e) { in.release(); bfhip_set_error(e.what()); return -1; } catch (...) { in.release(); bfhip_set_error("unknown error"); return -1; }
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
 
