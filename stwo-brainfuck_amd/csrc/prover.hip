@@ -218,8 +218,15 @@ struct HipProver {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // Host table build + upload (outside the metric's timed region: "inputs already resident in HBM").
-    static void upload_trace(Ctx& c, const std::vector<Registers>& vm_trace, const std::vector<u32>& code, TraceInput& in) {
+    // use_arena: take the column storage from the per-proof arena (no hipMalloc, which would synchronise the device) — only valid for
+    // the duration of the current proof; otherwise ONE device allocation holds all columns of the trace.
+    static void upload_trace(Ctx& c, const std::vector<Registers>& vm_trace, const std::vector<u32>& code, TraceInput& in, bool use_arena = false) {
         std::vector<Table> tables = build_tables(vm_trace, code);
+        size_t total_words = 0;
+        for (int k = 0; k < N_COMPONENTS; k++) total_words += (size_t)n_main_cols(k) * ((tables[k].n_rows + 63) & ~size_t(63));
+        u32* pool = nullptr;
+        if (use_arena) pool = c.alloc_u32(total_words);
+        else { BF_HIP(hipMalloc((void**)&pool, total_words * sizeof(u32))); in.owned.push_back(pool); }
         in.rows.assign(N_COMPONENTS, {});
         in.n_steps = vm_trace.size();
         for (int k = 0; k < N_COMPONENTS; k++) {
@@ -228,8 +235,7 @@ struct HipProver {
             in.interaction_cells += (u64)(4 * n_logup_cols(k)) << in.log_sizes[k];
             for (u32 j = 0; j < n_main_cols(k); j++) {
                 DCol r; r.log_size = in.log_sizes[k]; r.shift = LOG_N_LANES;
-                BF_HIP(hipMalloc((void**)&r.ptr, r.stored() * sizeof(u32)));
-                in.owned.push_back(r.ptr);
+                r.ptr = pool; pool += (r.stored() + 63) & ~size_t(63);
                 BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
                 in.rows[k].push_back(r);
             }
@@ -767,7 +773,7 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
             std::vector<u32> ins = compile(code);
             Machine m(ins, std::vector<u8>(input, input + n_input));
             m.execute();
-            HipProver::upload_trace(ctx->c, m.trace, ins, in);
+            HipProver::upload_trace(ctx->c, m.trace, ins, in, /*use_arena=*/true);
             return in;
         });
         fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
