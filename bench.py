@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--log-max-rows", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
+    ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,13 +79,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        device = local_rank if args.device is None else args.device
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     pkg = load_package()
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    ctx = pkg.Context(local_rank, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK
+    device = local_rank if args.device is None else args.device
+    ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK
     trace = pkg.Trace(ctx, FIB19, b"")          # VM + table build + upload: outside the timed region (inputs resident in HBM)
     lib = pkg.lib()
 
@@ -100,7 +107,7 @@ def main():
             lib.bfhip_profile_enable(ctx._h, 1)
             lib.bfhip_profile_reset(ctx._h)
 
-    cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if dist is not None else None
+    cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
     dt, (proof, phases) = replicas.timed_region(lambda: trace.prove(args.log_max_rows), args.steps, args.warmup, dist=dist, sync_fn=sync,
                                                 backend_tensor=cuda_t, on_timed_start=start_events)
     total_cells = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
