@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--log-max-rows", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + HIP stream each); >1 reports pipelined throughput, no roofline")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
     args = ap.parse_args()
@@ -93,6 +94,27 @@ def main():
     ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK
     trace = pkg.Trace(ctx, FIB19, b"")          # VM + table build + upload: outside the timed region (inputs resident in HBM)
     lib = pkg.lib()
+    extra = []
+    if args.inflight > 1:
+        args.no_kernel_events = True            # the event profiler is per process, not per stream
+        for _ in range(args.inflight - 1):
+            c2 = pkg.Context(device, max_log_domain=args.log_max_rows + 2)
+            extra.append((c2, pkg.Trace(c2, FIB19, b"")))
+
+    def one_step():
+        if not extra:
+            return trace.prove(args.log_max_rows)
+        import threading
+        res = [None] * (1 + len(extra))
+        def run(i, tr):
+            res[i] = tr.prove(args.log_max_rows)
+        th = [threading.Thread(target=run, args=(i + 1, tr)) for i, (_, tr) in enumerate(extra)]
+        for t in th:
+            t.start()
+        run(0, trace)
+        for t in th:
+            t.join()
+        return res[0]
 
     spec = importlib.util.spec_from_file_location("stwo_brainfuck_amd_replicas", os.path.join(ROOT, "stwo-brainfuck_amd", "replicas.py"))
     replicas = importlib.util.module_from_spec(spec)
@@ -100,6 +122,8 @@ def main():
 
     def sync():
         ctx.sync()
+        for c2, _ in extra:
+            c2.sync()
         torch.cuda.synchronize()
 
     def start_events():
@@ -108,9 +132,9 @@ def main():
             lib.bfhip_profile_reset(ctx._h)
 
     cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
-    dt, (proof, phases) = replicas.timed_region(lambda: trace.prove(args.log_max_rows), args.steps, args.warmup, dist=dist, sync_fn=sync,
+    dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync,
                                                 backend_tensor=cuda_t, on_timed_start=start_events)
-    total_cells = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
+    total_cells = replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=cuda_t)
 
     roofline = None
     if not args.no_kernel_events:
@@ -157,13 +181,15 @@ def main():
             "data": "fib19.bf execution trace (199246 VM steps); proof bytes identical to the CPU oracle on the oracle-sized parity programs",
             "config": {"workload": "fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, 1 proof per step",
                        "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
-                       "component_log_sizes": trace.log_sizes, "parallelism": "replicas" if world > 1 else "single",
+                       "component_log_sizes": trace.log_sizes, "parallelism": "replicas" if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight,
                        "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()}},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    for c2, t2 in extra:
+        t2.close(); c2.close()
     trace.close()
     ctx.close()
     if dist is not None:
