@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--log-max-rows", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--kernel-events", default="dominant", choices=["dominant", "all"], help="HIP-event timing of the dominant kernel only (default, ~1%% overhead) or of every kernel (~10%%)")
     ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + HIP stream each); >1 reports pipelined throughput, no roofline")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
@@ -128,7 +129,7 @@ def main():
 
     def start_events():
         if not args.no_kernel_events:
-            lib.bfhip_profile_enable(ctx._h, 1)
+            lib.bfhip_profile_enable(ctx._h, 1 if args.kernel_events == "all" else 2)
             lib.bfhip_profile_reset(ctx._h)
 
     cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None

@@ -118,7 +118,8 @@ int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t*
 
 /* Optional per-kernel timing with HIP events on the context's stream (used by bench.py for the roofline object).
  * Report: JSON {"kernel": {"calls": n, "total_ms": t, "bytes": algorithmic_bytes}, ...}, malloc'd (bfhip_free_host). */
-int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on);
+/* mode: 0 off, 1 every instrumented kernel, 2 only k_merkle_layer (the dominant kernel; lowest overhead). */
+int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode);
 int32_t bfhip_profile_reset(bfhip_ctx* ctx);
 int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json);
 

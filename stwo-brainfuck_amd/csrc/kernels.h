@@ -12,8 +12,8 @@ namespace bf {
 struct ColDesc { const u32* ptr; u32 shift; u32 pad_; };
 
 // prof.hip — optional per-kernel HIP-event timing (bench.py roofline)
-bool prof_enabled();
-void prof_enable(bool on);
+int prof_mode();
+void prof_enable(int mode);
 void prof_begin(hipStream_t s, const char* name, double bytes);
 void prof_end(hipStream_t s);
 void prof_collect();
@@ -21,7 +21,11 @@ void prof_reset();
 std::string prof_report_json();
 struct ProfScope {
     hipStream_t s; bool on;
-    ProfScope(hipStream_t s_, const char* name, double bytes) : s(s_), on(prof_enabled()) { if (on) prof_begin(s, name, bytes); }
+    ProfScope(hipStream_t s_, const char* name, double bytes) : s(s_) {
+        int m = prof_mode();
+        on = m == 1 || (m == 2 && name[2] == 'm' && name[8] == '_' && name[9] == 'l');   // "k_merkle_layer"
+        if (on) prof_begin(s, name, bytes);
+    }
     ~ProfScope() { if (on) prof_end(s); }
 };
 

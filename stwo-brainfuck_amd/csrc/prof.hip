@@ -12,13 +12,13 @@ namespace bf {
 struct ProfRec { const char* name; double bytes; hipEvent_t e0, e1; };
 struct ProfAgg { u64 calls = 0; double ms = 0, bytes = 0; };
 
-static bool g_prof_on = false;
+static int g_prof_on = 0;   // 0 off, 1 every instrumented kernel, 2 only the Merkle layer kernel (cheapest: ~250 event pairs per proof)
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static std::map<std::string, ProfAgg> g_agg;
 
-bool prof_enabled() { return g_prof_on; }
-void prof_enable(bool on) { g_prof_on = on; }
+int prof_mode() { return g_prof_on; }
+void prof_enable(int mode) { g_prof_on = mode; }
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }

@@ -844,7 +844,7 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
         return 0;
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
-extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t on) { (void)ctx; prof_enable(on != 0); return 0; }
+extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) { (void)ctx; prof_enable(mode); return 0; }
 extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) { try { ctx->c.sync(); prof_reset(); return 0; } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } }
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {
     try { ctx->c.sync(); std::string s = prof_report_json(); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
