@@ -99,6 +99,11 @@ void bfhip_free_host(void* p);
 int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, bfhip_trace** out,
                            uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells);
 int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* trace);
+/* Where the 13 `XTable::from(&vm_trace)` builders (mod.rs:511-547) run: 1 = on the GPU (default; sorts, clk-gap fill, padding, pairing and
+ * per-opcode selection as gfx950 kernels), 0 = host builders + upload. Results are identical. Process-wide switch. */
+int32_t bfhip_set_table_builder(int32_t on_gpu);
+/* Row-granular main-trace column `column` of component `component` (claim order) of a resident trace -> host. out_h may be NULL (size query). */
+int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows);
 int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                           char** transcript, double* phase_seconds);
 

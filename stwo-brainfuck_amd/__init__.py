@@ -174,6 +174,11 @@ def verify_brainfuck(proof_json: bytes, log_max_rows=24):
     return rc == 0, err.value.decode()
 
 
+def set_table_builder(on_gpu=True):
+    """Where the 13 component tables are built: GPU kernels (default) or the host builders. Identical results."""
+    _check(lib().bfhip_set_table_builder(int(on_gpu)))
+
+
 class Trace:
     """Prover input resident in HBM (bfhip_trace_create): VM trace -> 13 component tables -> row-granular device columns."""
 
@@ -200,6 +205,13 @@ class Trace:
             proof = ctypes.string_at(js, n.value)
             lib().bfhip_free_host(js)
         return proof, dict(zip(PHASES, list(times)))
+
+    def column(self, component, column):
+        n = ctypes.c_size_t()
+        _check(lib().bfhip_trace_column(self.ctx._h, self._h, component, column, None, ctypes.c_size_t(0), ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.uint32)
+        _check(lib().bfhip_trace_column(self.ctx._h, self._h, component, column, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(out.size), ctypes.byref(n)))
+        return out
 
     def close(self):
         if self._h:

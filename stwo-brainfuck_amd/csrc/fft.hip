@@ -16,6 +16,7 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 
 namespace bf {
 
@@ -408,7 +409,7 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
     if (ncols == 0) return;
     PassArgs a{};
     a.ncols = ncols; a.log = log; a.circle = circle ? 1 : 0; a.tw = inverse ? itw : tw; a.tw_total = 1u << tw_root_log; a.scale = 1;
-    if (log > 5 && src_log < 2) { fprintf(stderr, "bfhip: fft_batch: src_log < 2 with log > 5 unsupported\n"); abort(); }
+    if (log > 5 && src_log < 2) throw std::runtime_error("fft_batch: extending a polynomial with fewer than 4 coefficients to more than 32 cells is not supported");
     const u32 nl = inverse ? log : src_log;   // forward: the layers >= src_log only duplicate (zero extension) = wrap-around load
     if (log <= 5) {
         a.dst = d_dst; a.src = d_src; a.src_mask = (1u << src_log) - 1; a.lo = 0; a.k = nl;

@@ -16,6 +16,10 @@
 
 namespace bf {
 
+// tables.hip
+void build_tables_device(Ctx& c, const std::vector<u32> trace7_soa[7], u32 n, const std::vector<u32>& code, const std::function<u32*(size_t)>& alloc,
+                         std::vector<std::vector<u32*>>& cols_out, u32 log_sizes_out[13]);
+
 struct PcsConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_bound = 0, n_queries = 3; };  // PcsConfig::default() (mod.rs:479)
 
 struct DCol {
@@ -218,27 +222,42 @@ struct HipProver {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // Host table build + upload (outside the metric's timed region: "inputs already resident in HBM").
+    // Prover-input preparation from the VM trace. on_gpu (default): the 13 table builders run on the device (tables.hip);
+    // otherwise the host builders (host/tables.h) fill the columns and they are uploaded.
     // use_arena: take the column storage from the per-proof arena (no hipMalloc, which would synchronise the device) — only valid for
-    // the duration of the current proof; otherwise ONE device allocation holds all columns of the trace.
-    static void upload_trace(Ctx& c, const std::vector<Registers>& vm_trace, const std::vector<u32>& code, TraceInput& in, bool use_arena = false) {
-        std::vector<Table> tables = build_tables(vm_trace, code);
-        size_t total_words = 0;
-        for (int k = 0; k < N_COMPONENTS; k++) total_words += (size_t)n_main_cols(k) * ((tables[k].n_rows + 63) & ~size_t(63));
-        u32* pool = nullptr;
-        if (use_arena) pool = c.alloc_u32(total_words);
-        else { BF_HIP(hipMalloc((void**)&pool, total_words * sizeof(u32))); in.owned.push_back(pool); }
+    // the duration of the current proof; otherwise the columns live in their own device allocations owned by `in`.
+    static void upload_trace(Ctx& c, const std::vector<Registers>& vm_trace, const std::vector<u32>& code, TraceInput& in, bool use_arena = false, bool on_gpu = true) {
         in.rows.assign(N_COMPONENTS, {});
         in.n_steps = vm_trace.size();
+        in.main_cells = in.interaction_cells = 0;
+        auto alloc = [&](size_t words) -> u32* {
+            if (use_arena) return c.alloc_u32(words);
+            u32* p = nullptr; BF_HIP(hipMalloc((void**)&p, (words ? words : 1) * sizeof(u32))); in.owned.push_back(p); return p;
+        };
+        if (on_gpu) {
+            std::vector<u32> soa[7];
+            size_t n = vm_trace.size();
+            for (auto& v : soa) v.resize(n);
+            for (size_t i = 0; i < n; i++) { const Registers& r = vm_trace[i]; soa[0][i] = r.clk; soa[1][i] = r.ip; soa[2][i] = r.ci; soa[3][i] = r.ni; soa[4][i] = r.mp; soa[5][i] = r.mv; soa[6][i] = r.mvi; }
+            std::vector<std::vector<u32*>> cols;
+            build_tables_device(c, soa, (u32)n, code, alloc, cols, in.log_sizes);
+            for (int k = 0; k < N_COMPONENTS; k++)
+                for (u32 j = 0; j < n_main_cols(k); j++) { DCol r; r.log_size = in.log_sizes[k]; r.shift = LOG_N_LANES; r.ptr = cols[k][j]; in.rows[k].push_back(r); }
+        } else {
+            std::vector<Table> tables = build_tables(vm_trace, code);
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                in.log_sizes[k] = tables[k].log_size();
+                for (u32 j = 0; j < n_main_cols(k); j++) {
+                    DCol r; r.log_size = in.log_sizes[k]; r.shift = LOG_N_LANES;
+                    r.ptr = alloc(r.stored());
+                    BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+                    in.rows[k].push_back(r);
+                }
+            }
+        }
         for (int k = 0; k < N_COMPONENTS; k++) {
-            in.log_sizes[k] = tables[k].log_size();
             in.main_cells += (u64)n_main_cols(k) << in.log_sizes[k];
             in.interaction_cells += (u64)(4 * n_logup_cols(k)) << in.log_sizes[k];
-            for (u32 j = 0; j < n_main_cols(k); j++) {
-                DCol r; r.log_size = in.log_sizes[k]; r.shift = LOG_N_LANES;
-                r.ptr = pool; pool += (r.stored() + 63) & ~size_t(63);
-                BF_HIP(hipMemcpyAsync(r.ptr, tables[k].cols[j].data(), r.stored() * sizeof(u32), hipMemcpyHostToDevice, c.stream));
-                in.rows[k].push_back(r);
-            }
         }
         c.sync();
     }
@@ -717,6 +736,23 @@ struct HipProver {
 using namespace bf;
 
 struct bfhip_trace { TraceInput in; };
+static bool g_tables_on_gpu = true;
+// Selects where bfhip_trace_create / bfhip_prove_brainfuck build the 13 component tables: 1 = gfx950 kernels (default), 0 = host builders.
+extern "C" int32_t bfhip_set_table_builder(int32_t on_gpu) { g_tables_on_gpu = on_gpu != 0; return 0; }
+// Downloads one row-granular column of a resident trace (tests: GPU tables == host tables).
+extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows) {
+    try {
+        if (component >= N_COMPONENTS || column >= t->in.rows[component].size()) { bfhip_set_error("bad component/column"); return -1; }
+        const DCol& col = t->in.rows[component][column];
+        *n_rows = col.stored();
+        if (out_h) {
+            if (cap < col.stored()) { bfhip_set_error("capacity"); return -2; }
+            BF_HIP(hipMemcpyAsync(out_h, col.ptr, col.stored() * sizeof(u32), hipMemcpyDeviceToHost, ctx->c.stream));
+            ctx->c.sync();
+        }
+        return 0;
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
 
 static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
     if (proof_json) {
@@ -740,7 +776,7 @@ extern "C" int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const ui
         Machine m(ins, std::vector<u8>(input, input + n_input));
         m.execute();
         auto* t = new bfhip_trace();
-        try { HipProver::upload_trace(ctx->c, m.trace, ins, t->in); } catch (...) { t->in.release(); delete t; throw; }
+        try { HipProver::upload_trace(ctx->c, m.trace, ins, t->in, /*use_arena=*/false, /*on_gpu=*/g_tables_on_gpu); } catch (...) { t->in.release(); delete t; throw; }
         if (log_sizes) memcpy(log_sizes, t->in.log_sizes, sizeof(u32) * N_COMPONENTS);
         if (n_steps) *n_steps = t->in.n_steps;
         if (main_cells) *main_cells = t->in.main_cells;
@@ -773,7 +809,7 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
             std::vector<u32> ins = compile(code);
             Machine m(ins, std::vector<u8>(input, input + n_input));
             m.execute();
-            HipProver::upload_trace(ctx->c, m.trace, ins, in, /*use_arena=*/true);
+            HipProver::upload_trace(ctx->c, m.trace, ins, in, /*use_arena=*/true, /*on_gpu=*/g_tables_on_gpu);
             return in;
         });
         fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
