@@ -146,7 +146,7 @@ int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t l
     uint4* partials = nullptr; uint4* dout = nullptr;
     BF_HIP(hipMalloc((void**)&partials, sizeof(uint4) * (nchunks + 1)));
     dout = partials + nchunks;
-    eval_at_points(c.stream, dj, 1, job.log_n, df, partials, dout);
+    eval_at_points(c.stream, dj, 1, nchunks, df, partials, dout);
     uint4 r;
     hipError_t e = hipMemcpyAsync(&r, dout, sizeof(uint4), hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);

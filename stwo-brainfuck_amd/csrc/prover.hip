@@ -485,14 +485,13 @@ struct HipProver {
             for (u32 b = 1; b < 32; b++) { factors[p * 32 + b] = pk(x); x = q_double_x(x); }
         }
         std::vector<EvalJob> jobs;
-        u32 max_log_n = 0, partial_off = 0;
+        u32 partial_off = 0;
         for (size_t t = 0; t < trees.size(); t++)
             for (size_t col = 0; col < trees[t].polys.size(); col++)
                 for (u32 pt : mask[t][col]) {
                     const DCol& p = trees[t].polys[col];
                     EvalJob j; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = partial_off;
                     partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
-                    max_log_n = std::max(max_log_n, j.log_n);
                     jobs.push_back(j);
                 }
         uint4* d_factors = (uint4*)c.arena.alloc(factors.size() * sizeof(uint4));
@@ -501,7 +500,7 @@ struct HipProver {
         BF_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(EvalJob), hipMemcpyHostToDevice, c.stream));
         void* d_partials = c.arena.alloc(size_t(partial_off) * sizeof(uint4));
         uint4* d_out = (uint4*)c.arena.alloc(jobs.size() * sizeof(uint4));
-        eval_at_points(c.stream, d_jobs, (u32)jobs.size(), max_log_n, d_factors, d_partials, d_out);
+        eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
         BF_HIP(hipGetLastError());
         std::vector<uint4> out(jobs.size());
         BF_HIP(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(uint4), hipMemcpyDeviceToHost, c.stream));

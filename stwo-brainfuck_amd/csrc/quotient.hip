@@ -17,11 +17,14 @@ __device__ __forceinline__ uint4 pk_q(Q31 q) { return make_uint4(q.a.a, q.a.b, q
 // ------------------------------------------------------------------------------------------------------------------------------
 static constexpr u32 EAP_CHUNK_LOG = 12;
 
-__global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __restrict__ jobs, const uint4* __restrict__ factors, uint4* __restrict__ partials) {
-    const EvalJob job = jobs[blockIdx.y];
+// Grid: one workgroup per (job, chunk) pair, flattened — workgroup b belongs to the job with partial_off <= b (binary search over the
+// jobs' partial offsets, which are exactly the flattened chunk indices), so no workgroup is launched only to exit.
+__global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __restrict__ jobs, u32 n_jobs, const uint4* __restrict__ factors, uint4* __restrict__ partials) {
+    u32 lo_j = 0, hi_j = n_jobs;
+    while (hi_j - lo_j > 1) { u32 mid = (lo_j + hi_j) >> 1; if (jobs[mid].partial_off <= blockIdx.x) lo_j = mid; else hi_j = mid; }
+    const EvalJob job = jobs[lo_j];
     const u32 n = 1u << job.log_n;
-    const u32 chunk = blockIdx.x;
-    if (((u64)chunk << EAP_CHUNK_LOG) >= n) return;
+    const u32 chunk = blockIdx.x - job.partial_off;
     __shared__ uint4 s_w[16];
     __shared__ uint4 s_p[256];
     const uint4* F = factors + (size_t)job.point * 32 + job.factor_shift;   // F[b] multiplies bit b of the (row-granular) index
@@ -102,10 +105,10 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage2(const EvalJob* __r
     if (t == 0) out[blockIdx.x] = s[0];
 }
 
-void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 max_log_n, const void* d_factors, void* d_partials, void* d_out) {
+// total_partials = sum over jobs of their chunk counts (= partial_off of the last job + its chunk count); jobs sorted by partial_off.
+void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 total_partials, const void* d_factors, void* d_partials, void* d_out) {
     if (!n_jobs) return;
-    u32 chunks = max_log_n > EAP_CHUNK_LOG ? 1u << (max_log_n - EAP_CHUNK_LOG) : 1u;
-    hipLaunchKernelGGL(k_eval_at_point_stage1, dim3(chunks, n_jobs), dim3(256), 0, stream, d_jobs, (const uint4*)d_factors, (uint4*)d_partials);
+    hipLaunchKernelGGL(k_eval_at_point_stage1, dim3(total_partials), dim3(256), 0, stream, d_jobs, n_jobs, (const uint4*)d_factors, (uint4*)d_partials);
     hipLaunchKernelGGL(k_eval_at_point_stage2, dim3(n_jobs), dim3(256), 0, stream, d_jobs, (const uint4*)d_factors, (const uint4*)d_partials, (uint4*)d_out);
 }
 
