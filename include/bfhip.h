@@ -92,6 +92,10 @@ int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_
 int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
                               char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
 void bfhip_free_host(void* p);
+/* Optional (off by default): keep the preprocessed tree (IsFirst(LOG_MAX_ROWS..=4): polynomials, LDE columns, Merkle layers, root) of
+ * the first proof in the context and reuse it for later proofs with the same LOG_MAX_ROWS. The reference recommits it in every
+ * prove_brainfuck call (mod.rs:495-500); proof bytes are identical either way. Call with on = 0 before bfhip_ctx_destroy to release it. */
+int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on);
 
 /* The two halves of prove_brainfuck, so that a caller (and the benchmark) can keep the prover input resident in HBM:
  * bfhip_trace_create = VM run + the 13 `XTable::from(&vm_trace)` builders (mod.rs:508-547) + upload of the row-granular columns;

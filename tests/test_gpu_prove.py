@@ -114,3 +114,18 @@ def small_ctx(pkg):
 def test_trace_too_large_for_log_max_rows_is_an_error(pkg, small_ctx):
     with pytest.raises(pkg.BfhipError, match="LOG_MAX_ROWS"):
         pkg.prove_brainfuck("++++++++[>++++++++<-]>[<++++>-]", b"", ctx=small_ctx, log_max_rows=6)
+
+
+def test_reusing_the_preprocessed_tree_does_not_change_the_proof(pkg, oracle):
+    c = pkg.Context(0, max_log_domain=22)
+    try:
+        a = pkg.prove_brainfuck("+++>,<[>+.<-]", b"\x01", ctx=c, log_max_rows=20)
+        pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 1)
+        b1 = pkg.prove_brainfuck("+++>,<[>+.<-]", b"\x01", ctx=c, log_max_rows=20)     # builds and keeps the tree
+        b2 = pkg.prove_brainfuck("+++>,<[>+.<-]", b"\x01", ctx=c, log_max_rows=20)     # reuses it
+        b3 = pkg.prove_brainfuck("++[-]+.", b"", ctx=c, log_max_rows=20)                # other program, same tree
+        pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 0)
+        assert a == b1 == b2
+        assert b3 == oracle.prove("++[-]+.", b"", log_max_rows=20)[0]
+    finally:
+        c.close()
