@@ -59,6 +59,9 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
 /* ---- single backend operations (each is what one stwo trait method would call; all reached from mod.rs:732 prover::prove unless noted) ----
  * A secure (QM31) column is passed as 4 coordinate pointers. Values/points passed from the host are u32[4] per QM31. */
 
+/* The 16-lane broadcast of `trace_evaluation` (memory/table.rs:95-104: trace[col].data[row] = value.into()): dst[16 r + l] = rows[r].
+ * Only for callers that want the full-size column; the prover itself keeps such columns row-granular. */
+int32_t bfhip_broadcast16(bfhip_ctx* ctx, const uint32_t* rows_d, uint32_t* dst_d, size_t n_rows);
 /* ColumnOps::bit_reverse_column: dst[bit_reverse(i)] = src[i] (out of place), 2^log_size cells. */
 int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size);
 /* FieldOps::batch_inverse over M31 (used by LogupTraceGenerator::finalize_col, memory/table.rs:513): dst[i] = src[i]^-1, src[i] != 0. */

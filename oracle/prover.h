@@ -21,7 +21,6 @@ namespace orc {
 
 struct PcsConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_bound = 0, n_queries = 3; };  // PcsConfig::default()
 
-struct MerkleDecommitmentP { MerkleDecommitment d; };
 struct FriLayerProof { std::vector<QM31> fri_witness; MerkleDecommitment decommitment; Hash32 commitment; };
 struct FriProof { FriLayerProof first_layer; std::vector<FriLayerProof> inner_layers; std::vector<QM31> last_layer_coeffs; u32 last_layer_log_size = 0; };
 struct StarkProof {
@@ -324,7 +323,6 @@ static inline void decommitment_positions_and_witness(AtFn at, const std::vector
 }
 
 // ---- the prover ----------------------------------------------------------------------------------------------------------------
-struct ProverTimings { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, total = 0; };
 
 struct Prover {
     PcsConfig cfg;

@@ -100,6 +100,9 @@ class Context:
         return list(out)
 
     # -- ColumnOps / FieldOps / AccumulationOps ---------------------------------------------------------------------------------
+    def broadcast16(self, rows_ptr, dst_ptr, n_rows):
+        _check(lib().bfhip_broadcast16(self._h, ctypes.c_void_p(rows_ptr), ctypes.c_void_p(dst_ptr), ctypes.c_size_t(n_rows)))
+
     def bit_reverse(self, src_ptr, dst_ptr, log_size):
         _check(lib().bfhip_bit_reverse(self._h, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), log_size))
 

@@ -121,6 +121,9 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
 }
 
 
+int32_t bfhip_broadcast16(bfhip_ctx* ctx, const uint32_t* rows_d, uint32_t* dst_d, size_t n_rows) {
+    API_TRY broadcast16(ctx->c.stream, rows_d, dst_d, (u32)(n_rows * 16)); BF_HIP(hipGetLastError()); return 0; API_CATCH
+}
 int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size) {
     API_TRY if (src_d == dst_d) throw HipError("bit_reverse is out of place"); bit_reverse(ctx->c.stream, src_d, dst_d, log_size); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }

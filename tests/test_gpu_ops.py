@@ -43,6 +43,19 @@ def test_batch_inverse_m31(ctx, n):
     ctx.free(p); ctx.free(q)
 
 
+def test_broadcast16_then_full_transform_equals_replicated_transform(ctx):
+    log = 12
+    rows = splitmix_column(66, 1 << (log - 4))
+    pr, pf = ctx.upload(rows), ctx.malloc(4 << log)
+    ctx.broadcast16(pr, pf, rows.size)
+    assert np.array_equal(ctx.download(pf, 1 << log), np.repeat(rows, 16))
+    ctx.interpolate([pf], [pf], log)                      # full circle iFFT of the broadcast column
+    ctx.interpolate([pr], [pr], log, replicated=True)     # line-mode iFFT of the row-granular column
+    full = ctx.download(pf, 1 << log)
+    assert np.array_equal(full[::16], ctx.download(pr, 1 << (log - 4))) and not full.reshape(-1, 16)[:, 1:].any()
+    ctx.free(pr); ctx.free(pf)
+
+
 def test_accumulate(ctx):
     a, b = splitmix_column(1, 5000), splitmix_column(2, 5000)
     pa, pb = ctx.upload(a), ctx.upload(b)
