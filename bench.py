@@ -38,7 +38,7 @@ def load_package():
     return mod
 
 
-def cpu_baseline(sample_seconds_hint=20):
+def cpu_baseline():
     """Times the CPU oracle (kind "port": the Rust reference cannot be built on this image) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import Oracle
