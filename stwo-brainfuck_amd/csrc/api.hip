@@ -70,7 +70,7 @@ int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx**
     return 0;
     API_CATCH
 }
-int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
+int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx) { API_TRY ctx->c.sync(); return 0; API_CATCH }
 
 int32_t bfhip_malloc(bfhip_ctx* ctx, size_t bytes, void** out_d) { API_TRY BF_HIP(hipSetDevice(ctx->c.device)); BF_HIP(hipMalloc(out_d, bytes ? bytes : 4)); return 0; API_CATCH }

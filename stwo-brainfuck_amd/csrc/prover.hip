@@ -834,9 +834,10 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
 extern "C" int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on) {
-    PreprocessedCache& cache = preprocessed_caches()[&ctx->c];
-    cache.enabled = on != 0;
-    if (!on) { ctx->c.sync(); cache.valid = false; cache.keep.release(); }
+    auto& caches = preprocessed_caches();
+    if (on) { caches[&ctx->c].enabled = true; return 0; }
+    auto it = caches.find(&ctx->c);
+    if (it != caches.end()) { if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream); it->second.keep.release(); caches.erase(it); }
     return 0;
 }
 
