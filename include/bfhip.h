@@ -76,6 +76,13 @@ int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t l
  * layer). col_shifts_h may be NULL (all 0). Hashes are 32-byte records. */
 int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
                                   uint32_t n_cols, void* out_hashes_d);
+/* MerkleOps<Poseidon252MerkleHasher>::commit_on_layer (upstream stwo capability named by BASELINE.json config 5; the reference itself
+ * only uses Blake2s — SURVEY.md F9): node i = poseidon_hash_many([prev[2i], prev[2i+1]]? ++ blocks), block = 8 M31 column values packed
+ * as w = w * 2^31 + v (zero padded). Hashes are felt252 values stored as 8 little-endian u32 limbs (32 bytes), canonical form. */
+int32_t bfhip_merkle_commit_layer_poseidon252(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h,
+                                             const uint32_t* col_shifts_h, uint32_t n_cols, void* out_hashes_d);
+/* One Hades permutation (Starknet Poseidon, width 3) of three canonical felt252 values, 8 LE u32 limbs each — the known-answer-test hook. */
+int32_t bfhip_hades_permutation(bfhip_ctx* ctx, const uint32_t in_h[24], uint32_t out_h[24]);
 /* FriOps::fold_line: 2^log_size evaluations over LineDomain(Coset::half_odds(log_size)) -> 2^(log_size-1); alpha_h = u32[4]. */
 int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]);
 /* FriOps::fold_circle_into_line: dst = dst * alpha^2 + fold(src); src has 2^log_size cells on CanonicCoset(log_size).circle_domain(). */

@@ -117,6 +117,19 @@ class Context:
         sh = None if col_shifts is None else (ctypes.c_uint32 * len(col_shifts))(*col_shifts)
         _check(lib().bfhip_merkle_commit_layer(self._h, log_size, ctypes.c_void_p(prev_ptr) if prev_ptr else None, self._ptr_array(col_ptrs), sh, len(col_ptrs), ctypes.c_void_p(out_ptr)))
 
+    def merkle_commit_layer_poseidon252(self, log_size, prev_ptr, col_ptrs, out_ptr, col_shifts=None):
+        sh = None if col_shifts is None else (ctypes.c_uint32 * len(col_shifts))(*col_shifts)
+        _check(lib().bfhip_merkle_commit_layer_poseidon252(self._h, log_size, ctypes.c_void_p(prev_ptr) if prev_ptr else None, self._ptr_array(col_ptrs), sh, len(col_ptrs), ctypes.c_void_p(out_ptr)))
+
+    def hades_permutation(self, state3):
+        """state3: three Python ints < p. Returns three ints."""
+        words = []
+        for x in state3:
+            words += [(int(x) >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        out = (ctypes.c_uint32 * 24)()
+        _check(lib().bfhip_hades_permutation(self._h, (ctypes.c_uint32 * 24)(*words), out))
+        return [sum(int(out[8 * k + i]) << (32 * i) for i in range(8)) for k in range(3)]
+
     def fold_line(self, src_ptrs, dst_ptrs, log_size, alpha4):
         _check(lib().bfhip_fold_line(self._h, self._ptr_array(src_ptrs), self._ptr_array(dst_ptrs), log_size, (ctypes.c_uint32 * 4)(*[int(v) for v in alpha4])))
 

@@ -172,6 +172,31 @@ int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void*
     return 0;
     API_CATCH
 }
+int32_t bfhip_merkle_commit_layer_poseidon252(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
+                                             uint32_t n_cols, void* out_hashes_d) {
+    API_TRY
+    Ctx& c = ctx->c;
+    c.stage_checkpoint();
+    std::vector<ColDesc> d(n_cols);
+    for (u32 k = 0; k < n_cols; k++) d[k] = ColDesc{cols_h[k], col_shifts_h ? col_shifts_h[k] : 0u, 0};
+    const ColDesc* dd = n_cols ? c.stage(d.data(), n_cols) : nullptr;
+    merkle_layer_poseidon(c.stream, out_hashes_d, prev_layer_d, dd, n_cols, log_size);
+    BF_HIP(hipGetLastError());
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_hades_permutation(bfhip_ctx* ctx, const uint32_t in_h[24], uint32_t out_h[24]) {
+    API_TRY
+    Ctx& c = ctx->c;
+    c.stage_checkpoint();
+    u32* din = (u32*)c.stage(in_h, 24);
+    u32* dout = (u32*)c.stage(in_h, 24);
+    hades_once(c.stream, din, dout);
+    BF_HIP(hipMemcpyAsync(out_h, dout, 24 * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+    c.sync();
+    return 0;
+    API_CATCH
+}
 static Q31 q_from_h(const uint32_t v[4]) { return q_make(v[0], v[1], v[2], v[3]); }
 int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
     API_TRY

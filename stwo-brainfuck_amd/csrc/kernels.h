@@ -43,6 +43,10 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
 
+// poseidon.hip — Poseidon252 Merkle variant (BASELINE config 5; not used by the reference)
+void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log);
+void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24);
+
 // air.hip
 struct ConstraintLaunch {
     const u32* is_first; ColDesc trace[13]; ColDesc inter[12]; u32* acc[4]; Q31 coeff[12]; Lookups el; Q31 total_sum; u32 denom_inv[2]; u32 log_size;

@@ -1,0 +1,181 @@
+// Poseidon252 Merkle layers for gfx950 — SURVEY.md §8(f)3 / BASELINE.json config 5 (`MerkleOps<Poseidon252MerkleHasher>`).
+// The reference never uses this hasher (no `Poseidon` token in crates/); it is an upstream stwo capability over
+// starknet-crypto's `poseidon_hash_many`. node(i) = poseidon_hash_many([left, right]? ++ blocks), a block = 8 M31 values of the
+// layer's columns packed as w = w * 2^31 + v (zero padded to a multiple of 8).
+//
+// Arithmetic: the Stark field p = 2^251 + 17 * 2^192 + 1, 8 x 32-bit limbs, Montgomery form with R = 2^256. p = 1 (mod 2^32), so the
+// Montgomery factor of every CIOS step is m = -t0 and m * p touches only limbs 0, 6, 7. One Hades permutation (width 3, x^3 S-box,
+// 4 full + 83 partial + 4 full rounds, MDS [[3,1,1],[1,-1,1],[1,1,-2]]) is 214 field multiplications ≈ 90 k lane-ops: this hasher
+// is ~90x more VALU work per 64 hashed bytes than Blake2s — firmly VALU-bound. The permutation is pinned by the public Hades([0,0,0])
+// known-answer vector (oracle/poseidon252.py, tests/test_gpu_poseidon.py); the node layout is recalled from stwo (unpinned).
+#include "kernels.h"
+#include "poseidon_constants.h"
+#include <vector>
+#include <stdexcept>
+
+namespace bf {
+
+struct Fe { u32 l[8]; };
+
+__device__ __forceinline__ Fe fe_load_const(const u32* p) { Fe r; for (int i = 0; i < 8; i++) r.l[i] = p[i]; return r; }
+
+__device__ __forceinline__ Fe fe_add(const Fe& a, const Fe& b, const u32* __restrict__ P) {
+    Fe r; u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (u64)a.l[i] + b.l[i]; r.l[i] = (u32)c; c >>= 32; }
+    Fe s; u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u64 d = (u64)r.l[i] - P[i] - br; s.l[i] = (u32)d; br = d >> 63; }
+    return br ? r : s;
+}
+__device__ __forceinline__ Fe fe_sub(const Fe& a, const Fe& b, const u32* __restrict__ P) {
+    Fe r; u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u64 d = (u64)a.l[i] - b.l[i] - br; r.l[i] = (u32)d; br = d >> 63; }
+    if (br) { u64 c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { c += (u64)r.l[i] + P[i]; r.l[i] = (u32)c; c >>= 32; } }
+    return r;
+}
+// Montgomery product a * b * 2^-256 mod p (CIOS); inputs < p, output < p.
+__device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b, const u32* __restrict__ P) {
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { c += (u64)t[j] + (u64)a.l[j] * b.l[i]; t[j] = (u32)c; c >>= 32; }
+        c += t[8]; t[8] = (u32)c; t[9] = (u32)(c >> 32);
+        // reduction step: m = -t0 (p = 1 mod 2^32); t = (t + m * p) >> 32; p has limbs {1, 0, 0, 0, 0, 0, 17, 2^27}
+        u32 m = 0u - t[0];
+        c = (u64)t[0] + m;              // low word becomes 0, carry = (t0 != 0)
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 6; j++) { c += t[j]; t[j - 1] = (u32)c; c >>= 32; }
+        c += (u64)t[6] + (u64)m * 17u; t[5] = (u32)c; c >>= 32;
+        c += (u64)t[7] + (u64)m * 0x08000000u; t[6] = (u32)c; c >>= 32;
+        c += t[8]; t[7] = (u32)c; c >>= 32;
+        t[8] = t[9] + (u32)c; t[9] = 0;
+    }
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    // conditional subtraction (t < 2p)
+    Fe s; u64 br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { u64 d = (u64)r.l[i] - P[i] - br; s.l[i] = (u32)d; br = d >> 63; }
+    bool ge = t[8] != 0 || br == 0;
+    return ge ? s : r;
+}
+
+__device__ __forceinline__ void hades(Fe s[3], const u32* __restrict__ ark, const u32* __restrict__ P) {
+    for (int r = 0; r < 91; r++) {
+        const u32* k = ark + (size_t)r * 24;
+        s[0] = fe_add(s[0], fe_load_const(k), P);
+        s[1] = fe_add(s[1], fe_load_const(k + 8), P);
+        s[2] = fe_add(s[2], fe_load_const(k + 16), P);
+        bool full = r < 4 || r >= 87;
+        if (full) {
+            Fe q0 = fe_mul(s[0], s[0], P), q1 = fe_mul(s[1], s[1], P);
+            s[0] = fe_mul(q0, s[0], P); s[1] = fe_mul(q1, s[1], P);
+        }
+        Fe q2 = fe_mul(s[2], s[2], P);
+        s[2] = fe_mul(q2, s[2], P);
+        // MDS: t = s0 + s1 + s2; (t + 2 s0, t - 2 s1, t - 3 s2)
+        Fe t = fe_add(fe_add(s[0], s[1], P), s[2], P);
+        Fe d0 = fe_add(s[0], s[0], P), d1 = fe_add(s[1], s[1], P), d2 = fe_add(fe_add(s[2], s[2], P), s[2], P);
+        s[0] = fe_add(t, d0, P); s[1] = fe_sub(t, d1, P); s[2] = fe_sub(t, d2, P);
+    }
+}
+
+struct Sponge {
+    Fe s[3]; u32 count;
+    const u32* ark; const u32* P; const u32* R1;
+    __device__ __forceinline__ void init(const u32* ark_, const u32* P_, const u32* R1_) {
+        ark = ark_; P = P_; R1 = R1_; count = 0;
+        for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) s[k].l[i] = 0;
+    }
+    __device__ __forceinline__ void absorb(const Fe& v) {      // v in Montgomery form
+        if ((count & 1) == 0) s[0] = fe_add(s[0], v, P);
+        else { s[1] = fe_add(s[1], v, P); hades(s, ark, P); }
+        count++;
+    }
+    __device__ __forceinline__ Fe finish() {                    // poseidon_hash_many padding: a single one
+        Fe one = fe_load_const(R1);
+        if (count & 1) s[1] = fe_add(s[1], one, P); else s[0] = fe_add(s[0], one, P);
+        hades(s, ark, P);
+        return s[0];
+    }
+};
+
+// consts layout in device memory: P[8], R1[8], R2[8], ARK[273][8]
+__global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__ out, const u32* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n,
+                                                              const u32* __restrict__ consts) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32* P = consts; const u32* R1 = consts + 8; const u32* R2p = consts + 16; const u32* ark = consts + 24;
+    Fe R2 = fe_load_const(R2p);
+    Sponge sp; sp.init(ark, P, R1);
+    if (prev) {
+        Fe l, r;
+        for (int k = 0; k < 8; k++) { l.l[k] = prev[(size_t)16 * i + k]; r.l[k] = prev[(size_t)16 * i + 8 + k]; }
+        sp.absorb(fe_mul(l, R2, P));        // canonical -> Montgomery
+        sp.absorb(fe_mul(r, R2, P));
+    }
+    for (u32 c0 = 0; c0 < ncols; c0 += 8) {
+        // w = sum_k v_k * 2^(31 * (7 - k)): value k occupies bits [31 (7-k), 31 (8-k))  (< 2^248 < p, no reduction needed)
+        Fe w; for (int k = 0; k < 8; k++) w.l[k] = 0;
+        for (u32 k = 0; k < 8; k++) {
+            u32 c = c0 + k;
+            u32 v = 0;
+            if (c < ncols) { ColDesc cd = cols[c]; v = cd.ptr[i >> cd.shift]; }
+            u32 sh = 31 * (7 - k), limb = sh >> 5, off = sh & 31;
+            w.l[limb] |= v << off;
+            if (off > 1 && limb + 1 < 8) w.l[limb + 1] |= v >> (32 - off);
+        }
+        sp.absorb(fe_mul(w, R2, P));
+    }
+    Fe h = sp.finish();
+    Fe one_plain; for (int k = 0; k < 8; k++) one_plain.l[k] = k == 0 ? 1u : 0u;
+    h = fe_mul(h, one_plain, P);            // Montgomery -> canonical
+    for (int k = 0; k < 8; k++) out[(size_t)8 * i + k] = h.l[k];
+}
+
+// Test hook: one Hades permutation of 3 canonical field elements (24 words in, 24 words out).
+__global__ void k_hades_once(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ consts) {
+    if (threadIdx.x || blockIdx.x) return;
+    const u32* P = consts; const u32* R2p = consts + 16; const u32* ark = consts + 24;
+    Fe R2 = fe_load_const(R2p);
+    Fe s[3];
+    for (int k = 0; k < 3; k++) { Fe x; for (int i = 0; i < 8; i++) x.l[i] = in[8 * k + i]; s[k] = fe_mul(x, R2, P); }
+    hades(s, ark, P);
+    Fe one_plain; for (int k = 0; k < 8; k++) one_plain.l[k] = k == 0 ? 1u : 0u;
+    for (int k = 0; k < 3; k++) { Fe y = fe_mul(s[k], one_plain, P); for (int i = 0; i < 8; i++) out[8 * k + i] = y.l[i]; }
+}
+
+static u32* g_poseidon_consts = nullptr;   // per process; tiny (8.8 KB)
+static const u32* poseidon_consts(hipStream_t s) {
+    if (!g_poseidon_consts) {
+        std::vector<u32> h;
+        h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_R1, POSEIDON_R1 + 8); h.insert(h.end(), POSEIDON_R2, POSEIDON_R2 + 8);
+        for (int r = 0; r < 273; r++) h.insert(h.end(), POSEIDON_ARK[r], POSEIDON_ARK[r] + 8);
+        if (hipMalloc((void**)&g_poseidon_consts, h.size() * sizeof(u32)) != hipSuccess) throw std::runtime_error("hipMalloc(poseidon constants)");
+        if (hipMemcpy(g_poseidon_consts, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy(poseidon constants)");
+    }
+    (void)s;
+    return g_poseidon_consts;
+}
+
+void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log) {
+    u32 n = 1u << log;
+    u32 threads = n < 128 ? (n < 64 ? 64 : n) : 128;
+    ProfScope ps(stream, "k_merkle_layer_poseidon", 0);
+    hipLaunchKernelGGL(k_merkle_layer_poseidon, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (u32*)out, (const u32*)prev, d_cols, ncols, n, poseidon_consts(stream));
+}
+void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24) {
+    hipLaunchKernelGGL(k_hades_once, dim3(1), dim3(64), 0, stream, d_in24, d_out24, poseidon_consts(stream));
+}
+
+}  // namespace bf
