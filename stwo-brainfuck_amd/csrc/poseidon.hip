@@ -12,6 +12,7 @@
 #include "poseidon_constants.h"
 #include <vector>
 #include <stdexcept>
+#include <mutex>
 
 namespace bf {
 
@@ -156,7 +157,9 @@ __global__ void k_hades_once(const u32* __restrict__ in, u32* __restrict__ out, 
 }
 
 static u32* g_poseidon_consts = nullptr;   // per process; tiny (8.8 KB)
+static std::mutex g_poseidon_mutex;
 static const u32* poseidon_consts(hipStream_t s) {
+    std::lock_guard<std::mutex> guard(g_poseidon_mutex);
     if (!g_poseidon_consts) {
         std::vector<u32> h;
         h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_R1, POSEIDON_R1 + 8); h.insert(h.end(), POSEIDON_R2, POSEIDON_R2 + 8);

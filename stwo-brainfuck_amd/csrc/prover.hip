@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <functional>
+#include <mutex>
 
 namespace bf {
 
@@ -65,7 +66,9 @@ struct TraceInput {
 // programs can commit it once per context and reuse polynomials, LDE columns and Merkle layers. The reference recomputes it in every
 // prove_brainfuck call (mod.rs:495-500); bench.py's headline number does the same (reuse only with --reuse-preprocessed).
 struct PreprocessedCache { bool enabled = false, valid = false; u32 lmr = 0; DTree tree; Arena keep; };
+static std::mutex g_cache_mutex;   // contexts may be driven from different host threads (bench.py --inflight)
 static std::map<Ctx*, PreprocessedCache>& preprocessed_caches() { static std::map<Ctx*, PreprocessedCache> m; return m; }
+static PreprocessedCache& preprocessed_cache_of(Ctx* c) { std::lock_guard<std::mutex> g(g_cache_mutex); return preprocessed_caches()[c]; }   // map nodes are address-stable
 
 struct PhaseTimes { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, decommit = 0, tables = 0, total = 0; };
 
@@ -282,7 +285,7 @@ struct HipProver {
 
         // ---- Phase 0: preprocessed IsFirst(LOG_MAX_ROWS ..= LOG_N_LANES) (mod.rs:495-500) ---------------------------------
         double t0 = now();
-        PreprocessedCache& cache = preprocessed_caches()[&c];
+        PreprocessedCache& cache = preprocessed_cache_of(&c);
         Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
         const bool reuse = cache.enabled && cache.valid && cache.lmr == log_max_rows;
         if (reuse) trees[0] = cache.tree;
@@ -834,8 +837,9 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
 extern "C" int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on) {
+    if (on) { preprocessed_cache_of(&ctx->c).enabled = true; return 0; }
+    std::lock_guard<std::mutex> g(g_cache_mutex);
     auto& caches = preprocessed_caches();
-    if (on) { caches[&ctx->c].enabled = true; return 0; }
     auto it = caches.find(&ctx->c);
     if (it != caches.end()) { if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream); it->second.keep.release(); caches.erase(it); }
     return 0;
