@@ -92,6 +92,38 @@ int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bit
 /* Decommitment reads: out_h[j] = col_d[idx_h[j]] for n positions of one column. */
 int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_h, size_t n, uint32_t* out_h);
 
+/* ---- per-component AIR operations (what `ComponentProver` / `LogupTraceGenerator` / `QuotientOps` of a HipBackend would call) ----
+ * component: 0 memory, 1 instruction, 2 program, 3 processor, 4 jump-if-not-zero, 5 jump-if-zero, 6 input, 7 left, 8 minus, 9 output,
+ * 10 plus, 11 right, 12 end_of_execution (the numbering of `bfhip_trace_column`). lookup_h = u32[24]: (z[4], alpha[4]) of the Memory, Instruction and Processor relations, in that order
+ * (mod.rs:589-597 draws them in this order). */
+
+/* Shape of one component: main-trace columns, logUp (secure) columns, constraints. Returns -1 for an unknown component. */
+int32_t bfhip_component_shape(int32_t component, uint32_t* n_main_cols, uint32_t* n_logup_cols, uint32_t* n_constraints);
+/* `interaction_trace_evaluation` of one component (e.g. memory/table.rs:485-518, processor/table.rs:456-529): LogupTraceGenerator
+ * new_col / write_frac / finalize_col / finalize_last. main_rows_h: n_main device pointers to row-granular columns (2^(log_size-4)
+ * rows). out_cols_h: 4 * n_logup device pointers to coordinate columns in bit-reversed circle-domain order; the last 4 (the prefix-
+ * summed column) hold 2^log_size cells, earlier ones are 16-lane replicated and are written row-granular (2^(log_size-4) cells).
+ * claimed_sum_h = u32[4] receives the component's claimed sum. */
+int32_t bfhip_logup_generate(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* const* main_rows_h, const uint32_t lookup_h[24],
+                             uint32_t* const* out_cols_h, uint32_t claimed_sum_h[4]);
+/* `ComponentProver::evaluate_constraint_quotients_on_domain` of one component (FrameworkComponent<XEval>, components/<name>/component.rs):
+ * every constraint of the component on CanonicCoset(log_size + 1).circle_domain(), each multiplied by its random-coefficient power
+ * and by the inverse of the trace-domain vanishing polynomial, added into acc_d (4 coordinate columns of 2^(log_size+1) cells).
+ * is_first_d: the preprocessed IsFirst LDE (2^(log_size+1) cells). main_lde_h / inter_lde_h: device pointers to the n_main and
+ * 4 * n_logup LDE columns; *_shifts_h (may be NULL = 0) give the replication shift of each (cell i is read at index i >> shift).
+ * coeffs_h = u32[4 * n_constraints]: the coefficient of constraint j in evaluation order (the caller reverses the accumulator's
+ * power slice the way `accum.columns()` does). claimed_sum_h = the component's logUp total. */
+int32_t bfhip_eval_constraints(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* is_first_d, const uint32_t* const* main_lde_h,
+                               const uint32_t* main_shifts_h, const uint32_t* const* inter_lde_h, const uint32_t* inter_shifts_h, const uint32_t lookup_h[24],
+                               const uint32_t claimed_sum_h[4], const uint32_t* coeffs_h, uint32_t* const acc_d[4]);
+/* `QuotientOps::accumulate_quotients` (compute_fri_quotients, reached from mod.rs:732) for the columns of one LDE size: n_cols
+ * columns of 2^log_size cells on CanonicCoset(log_size).circle_domain() (bit-reversed; col_shifts_h as above: 0 or >= 2, may be NULL).
+ * Column k has n_samples_h[k] samples; sample_points_h (u32[8] each: x[4] || y[4]) and sample_values_h (u32[4] each) list them column
+ * by column. Batches are formed per distinct point in BTreeMap order like ColumnSampleBatch::new_vec. out_d: 4 coordinate columns. */
+int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint32_t* const* cols_h, const uint32_t* col_shifts_h, uint32_t n_cols,
+                                   const uint32_t* n_samples_h, const uint32_t* sample_points_h, const uint32_t* sample_values_h,
+                                   const uint32_t random_coeff_h[4], uint32_t* const out_d[4]);
+
 /* prove_brainfuck (crates/brainfuck_prover/src/brainfuck_air/mod.rs:471-735), device resident: compiles and runs `code` on the
  * host VM (crates/brainfuck_vm), builds the 13 component tables, then commits, evaluates constraints, samples, builds the FRI
  * quotients, runs FRI, grinds and decommits on the GPU. *proof_json receives the serde_json form of BrainfuckProof (mod.rs:71-76),

@@ -256,6 +256,83 @@ int orc_assert_constraints(const char* code, const u8* input, size_t n_in, int c
     ORC_CATCH
 }
 
+// ---- per-component operations on caller-supplied columns (checkers for the bfhip per-component C ABI) -------------------------
+static InteractionElements elements_from(const u32* e) {
+    auto q = [&](int i) { return QM31::from_u32(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]); };
+    InteractionElements el;
+    el.memory = LookupElements::make(q(0), q(1)); el.instruction = LookupElements::make(q(2), q(3)); el.processor = LookupElements::make(q(4), q(5));
+    return el;
+}
+// gen_interaction_trace of one component. rows: n_main row-granular columns of n_rows (power of two) values, column-major.
+// out: 4 * n_logup full-size columns of 2^log_size cells (log_size = log2(n_rows) + 4), column-major. claimed = u32[4].
+int orc_logup_generate(int component, const u32* rows, size_t n_rows, const u32* elems24, u32* out, u32 claimed[4]) {
+    ORC_TRY
+    Table t; t.init(N_MAIN_COLS[component], n_rows);
+    for (size_t c = 0; c < t.cols.size(); c++) memcpy(t.cols[c].data(), rows + c * n_rows, n_rows * sizeof(u32));
+    QM31 cs;
+    auto cols = gen_interaction_trace(component, t, elements_from(elems24), &cs);
+    size_t n = size_t(1) << t.log_size();
+    for (size_t c = 0; c < cols.size(); c++) memcpy(out + c * n, cols[c].data(), n * sizeof(u32));
+    auto a = cs.to_u32(); for (int k = 0; k < 4; k++) claimed[k] = a[k];
+    return 0;
+    ORC_CATCH
+}
+// One component's share of compute_composition: acc (4 columns of 2^(log_size+1), column-major) += sum_j coeff[j] * constraint_j * denom_inv.
+// is_first, main (n_main columns) and inter (4 * n_logup columns) are full-size LDE columns of 2^(log_size+1) cells, column-major.
+int orc_eval_constraints(int component, u32 log_size, const u32* is_first, const u32* main, const u32* inter, const u32* elems24, const u32 claimed[4],
+                         const u32* coeffs, u32* acc) {
+    ORC_TRY
+    u32 eval_log = log_size + 1;
+    size_t n = size_t(1) << eval_log;
+    InteractionElements el = elements_from(elems24);
+    int nc = component_info(component).n_constraints;
+    std::vector<QM31> coeff(nc);
+    for (int j = 0; j < nc; j++) coeff[j] = QM31::from_u32(coeffs[4 * j], coeffs[4 * j + 1], coeffs[4 * j + 2], coeffs[4 * j + 3]);
+    CircleDomain ed = CanonicCoset{eval_log}.circle_domain();
+    M31 denom_inv[2];
+    for (int i = 0; i < 2; i++) denom_inv[i] = inv(coset_vanishing<M31>(CanonicCoset{log_size}.coset(), ed.at(i)));
+    std::vector<const u32*> tc(N_MAIN_COLS[component]), ic(4 * N_LOGUP_COLS[component]);
+    for (size_t k = 0; k < tc.size(); k++) tc[k] = main + k * n;
+    for (size_t k = 0; k < ic.size(); k++) ic[k] = inter + k * n;
+    QM31 total = QM31::from_u32(claimed[0], claimed[1], claimed[2], claimed[3]);
+#pragma omp parallel for schedule(static)
+    for (size_t row = 0; row < n; row++) {
+        DomainEvaluator de;
+        de.is_first_col = is_first; de.trace_cols = tc.data(); de.inter_cols = ic.data();
+        de.row = row; de.log_size = log_size; de.eval_log = eval_log; de.coeff = coeff.data();
+        de.total_sum = total;
+        eval_component(component, de, el);
+        QM31 v = QM31::from_u32(acc[row], acc[n + row], acc[2 * n + row], acc[3 * n + row]) + de.row_res * denom_inv[row >> log_size];
+        auto a = v.to_u32(); for (int k = 0; k < 4; k++) acc[k * n + row] = a[k];
+    }
+    return 0;
+    ORC_CATCH
+}
+// accumulate_quotients for n_cols full-size columns (2^log_size cells, column-major) with per-column samples listed column by column.
+int orc_accumulate_quotients(u32 log_size, const u32* cols, size_t n_cols, const u32* n_samples, const u32* points8, const u32* values4, const u32 random_coeff[4], u32* out) {
+    ORC_TRY
+    size_t n = size_t(1) << log_size;
+    std::vector<std::vector<PointSample>> samples(n_cols);
+    size_t si = 0;
+    auto q = [](const u32* p) { return QM31::from_u32(p[0], p[1], p[2], p[3]); };
+    for (size_t c = 0; c < n_cols; c++)
+        for (u32 s = 0; s < n_samples[c]; s++, si++) samples[c].push_back({PointQ(q(points8 + 8 * si), q(points8 + 8 * si + 4)), q(values4 + 4 * si)});
+    std::vector<const std::vector<PointSample>*> refs;
+    for (auto& v : samples) refs.push_back(&v);
+    auto sb = sample_batches(refs);
+    auto qc = quotient_constants(sb, q(random_coeff));
+    auto pts = domain_points(log_size);
+#pragma omp parallel for schedule(static)
+    for (size_t row = 0; row < n; row++) {
+        std::vector<u32> vals(n_cols);
+        for (size_t c = 0; c < n_cols; c++) vals[c] = cols[c * n + row];
+        auto a = accumulate_row_quotients(sb, vals.data(), qc, pts[bit_reverse_index((u32)row, log_size)]).to_u32();
+        for (int k = 0; k < 4; k++) out[k * n + row] = a[k];
+    }
+    return 0;
+    ORC_CATCH
+}
+
 // ---- prove / verify -----------------------------------------------------------------------------------------------------
 // Returns a malloc'd JSON string (free with orc_free). transcript_out (optional, malloc'd): "name:hexdigest\n" per tap.
 int orc_prove(const char* code, const u8* input, size_t n_in, u32 log_max_rows, char** json_out, size_t* json_len, char** transcript_out, double* seconds) {

@@ -147,6 +147,31 @@ class Context:
         _check(lib().bfhip_gather(self._h, ctypes.c_void_p(col_ptr), idx.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(idx.size), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    # -- per-component AIR operations (LogupTraceGenerator / ComponentProver / QuotientOps) --------------------------------------------
+    @staticmethod
+    def _u32s(values):
+        values = [int(v) for v in values]
+        return (ctypes.c_uint32 * len(values))(*values)
+
+    def logup_generate(self, component, log_size, main_row_ptrs, lookup24, out_col_ptrs):
+        """interaction_trace_evaluation of one component; returns its claimed sum (4 u32)."""
+        claimed = (ctypes.c_uint32 * 4)()
+        _check(lib().bfhip_logup_generate(self._h, component, log_size, self._ptr_array(main_row_ptrs), self._u32s(lookup24), self._ptr_array(out_col_ptrs), claimed))
+        return list(claimed)
+
+    def eval_constraints(self, component, log_size, is_first_ptr, main_lde_ptrs, inter_lde_ptrs, lookup24, claimed4, coeffs, acc_ptrs, main_shifts=None, inter_shifts=None):
+        """evaluate_constraint_quotients_on_domain of one component, accumulated into the 4 coordinate columns acc_ptrs."""
+        _check(lib().bfhip_eval_constraints(self._h, component, log_size, ctypes.c_void_p(is_first_ptr), self._ptr_array(main_lde_ptrs),
+                                            None if main_shifts is None else self._u32s(main_shifts), self._ptr_array(inter_lde_ptrs),
+                                            None if inter_shifts is None else self._u32s(inter_shifts), self._u32s(lookup24), self._u32s(claimed4),
+                                            self._u32s(coeffs), self._ptr_array(acc_ptrs)))
+
+    def accumulate_quotients(self, log_size, col_ptrs, n_samples, sample_points, sample_values, random_coeff4, out_ptrs, col_shifts=None):
+        """QuotientOps::accumulate_quotients for the columns of one LDE size."""
+        _check(lib().bfhip_accumulate_quotients(self._h, log_size, self._ptr_array(col_ptrs), None if col_shifts is None else self._u32s(col_shifts), len(col_ptrs),
+                                                self._u32s(n_samples), self._u32s(sample_points), self._u32s(sample_values), self._u32s(random_coeff4),
+                                                self._ptr_array(out_ptrs)))
+
     def twiddles(self):
         tw, itw, rl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
         _check(lib().bfhip_twiddles(self._h, ctypes.byref(tw), ctypes.byref(itw), ctypes.byref(rl)))

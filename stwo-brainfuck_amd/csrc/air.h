@@ -10,6 +10,7 @@
 namespace bf {
 
 enum ComponentId { C_MEMORY = 0, C_INSTRUCTION, C_PROGRAM, C_PROCESSOR, C_JNZ, C_JZ, C_INPUT, C_LEFT, C_MINUS, C_OUTPUT, C_PLUS, C_RIGHT, C_EOE, N_COMPONENTS };
+constexpr u32 LOG_N_LANES = 4;  // stwo simd::m31::LOG_N_LANES; every table row is broadcast to 16 cells (memory/table.rs:95-104)
 enum : u32 { OP_RIGHT = '>', OP_LEFT = '<', OP_PLUS = '+', OP_MINUS = '-', OP_PUTCHAR = '.', OP_READCHAR = ',', OP_JZ = '[', OP_JNZ = ']' };
 
 // (main columns, logUp columns) per component — TraceColumn::count() in each table.rs

@@ -1,6 +1,8 @@
 // C ABI (include/bfhip.h) over the gfx950 kernels. No torch types, plain pointers and sizes.
 #include "../../include/bfhip.h"
 #include "ctx.h"
+#include "host/circle.h"
+#include "host/quotients.h"
 #include <cstdio>
 #include <vector>
 
@@ -241,6 +243,109 @@ int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
     (void)hipFree(dreq); (void)hipFree(dout);
     BF_HIP(e);
+    return 0;
+    API_CATCH
+}
+
+// ---- per-component AIR operations ---------------------------------------------------------------------------------------------------
+static Lookups lookups_from_h(const uint32_t v[24]) {
+    Lookups el;
+    el.memory = make_lookup(q_make(v[0], v[1], v[2], v[3]), q_make(v[4], v[5], v[6], v[7]));
+    el.instruction = make_lookup(q_make(v[8], v[9], v[10], v[11]), q_make(v[12], v[13], v[14], v[15]));
+    el.processor = make_lookup(q_make(v[16], v[17], v[18], v[19]), q_make(v[20], v[21], v[22], v[23]));
+    return el;
+}
+static void check_component(int32_t component, uint32_t log_size, const Ctx& c, uint32_t extra_log) {
+    if (component < 0 || component >= N_COMPONENTS) throw HipError("unknown component");
+    if (log_size < LOG_N_LANES) throw HipError("component log_size below LOG_N_LANES (4)");
+    if (log_size + extra_log > c.tw_root_log + 1) throw HipError("log_size exceeds the context's twiddle tree");
+}
+int32_t bfhip_component_shape(int32_t component, uint32_t* n_main, uint32_t* n_logup, uint32_t* n_cons) {
+    if (component < 0 || component >= N_COMPONENTS) { g_err = "unknown component"; return -1; }
+    if (n_main) *n_main = n_main_cols(component);
+    if (n_logup) *n_logup = n_logup_cols(component);
+    if (n_cons) *n_cons = n_constraints(component);
+    return 0;
+}
+int32_t bfhip_logup_generate(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* const* main_rows_h, const uint32_t lookup_h[24],
+                             uint32_t* const* out_cols_h, uint32_t claimed_sum_h[4]) {
+    API_TRY
+    Ctx& c = ctx->c;
+    check_component(component, log_size, c, 0);
+    u32 log_rows = log_size - LOG_N_LANES;
+    size_t M = size_t(1) << log_rows;
+    LogupLaunch L{};
+    for (u32 j = 0; j < n_main_cols(component); j++) L.cols[j] = main_rows_h[j];
+    u32 nl = n_logup_cols(component);
+    for (u32 q = 0; q + 1 < nl; q++) for (int w = 0; w < 4; w++) L.out_rep[4 * q + w] = out_cols_h[4 * q + w];
+    for (int w = 0; w < 4; w++) L.out_last[w] = out_cols_h[4 * (nl - 1) + w];
+    // scratch: vrow[M], wloc[M], totals[M / 1024 + 2], claimed[1]
+    size_t n_tot = M / 1024 + 2;
+    uint4* scratch = nullptr;
+    BF_HIP(hipMalloc((void**)&scratch, sizeof(uint4) * (2 * M + n_tot + 1)));
+    L.vrow = scratch; L.wloc = scratch + M; L.totals = scratch + 2 * M; L.claimed = scratch + 2 * M + n_tot;
+    L.el = lookups_from_h(lookup_h); L.log_rows = log_rows; L.comp = component;
+    logup_generate(c.stream, L);
+    uint4 r;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&r, L.claimed, sizeof(uint4), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    (void)hipFree(scratch);
+    BF_HIP(e);
+    claimed_sum_h[0] = r.x; claimed_sum_h[1] = r.y; claimed_sum_h[2] = r.z; claimed_sum_h[3] = r.w;
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_eval_constraints(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* is_first_d, const uint32_t* const* main_lde_h,
+                               const uint32_t* main_shifts_h, const uint32_t* const* inter_lde_h, const uint32_t* inter_shifts_h, const uint32_t lookup_h[24],
+                               const uint32_t claimed_sum_h[4], const uint32_t* coeffs_h, uint32_t* const acc_d[4]) {
+    API_TRY
+    Ctx& c = ctx->c;
+    check_component(component, log_size, c, 1);
+    u32 eval_log = log_size + 1;
+    ConstraintLaunch L{};
+    L.is_first = is_first_d;
+    for (u32 j = 0; j < n_main_cols(component); j++) L.trace[j] = ColDesc{main_lde_h[j], main_shifts_h ? main_shifts_h[j] : 0u, 0};
+    for (u32 j = 0; j < 4 * n_logup_cols(component); j++) L.inter[j] = ColDesc{inter_lde_h[j], inter_shifts_h ? inter_shifts_h[j] : 0u, 0};
+    for (int w = 0; w < 4; w++) L.acc[w] = acc_d[w];
+    for (u32 j = 0; j < n_constraints(component); j++) L.coeff[j] = q_from_h(coeffs_h + 4 * j);
+    L.el = lookups_from_h(lookup_h); L.total_sum = q_from_h(claimed_sum_h); L.log_size = log_size;
+    // 1 / coset_vanishing(CanonicCoset(log_size).coset, eval_domain.at(i)) takes two values, by the parity of the (bit-reversed) cell index
+    for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log_size, canonic_domain_at(eval_log, i)));
+    c.stage_checkpoint();
+    eval_constraints(c.stream, component, c.stage(&L, 1), log_size);
+    BF_HIP(hipGetLastError());
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint32_t* const* cols_h, const uint32_t* col_shifts_h, uint32_t n_cols,
+                                   const uint32_t* n_samples_h, const uint32_t* sample_points_h, const uint32_t* sample_values_h,
+                                   const uint32_t random_coeff_h[4], uint32_t* const out_d[4]) {
+    API_TRY
+    Ctx& c = ctx->c;
+    if (log_size < 3 || log_size > c.tw_root_log + 1) throw HipError("accumulate_quotients: log_size outside the twiddle tree");
+    std::vector<ColDesc> descs(n_cols);
+    std::vector<std::vector<ColumnSample>> samples(n_cols);
+    size_t si = 0;
+    for (u32 k = 0; k < n_cols; k++) {
+        descs[k] = ColDesc{cols_h[k], col_shifts_h ? col_shifts_h[k] : 0u, 0};
+        if (descs[k].shift == 1) throw HipError("accumulate_quotients: column shift must be 0 or >= 2");
+        for (u32 s = 0; s < n_samples_h[k]; s++, si++) {
+            const uint32_t* p = sample_points_h + 8 * si;
+            samples[k].push_back({PtQ{q_from_h(p), q_from_h(p + 4)}, q_from_h(sample_values_h + 4 * si)});
+        }
+    }
+    std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
+    build_quotient_batches(samples, q_from_h(random_coeff_h), batches, entries);
+    c.stage_checkpoint();
+    QuotientArgs a{};
+    a.cols = n_cols ? c.stage(descs.data(), descs.size()) : nullptr;
+    a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
+    a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
+    a.n_batches = (u32)batches.size(); a.log = log_size; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;
+    for (int w = 0; w < 4; w++) a.out[w] = out_d[w];
+    accumulate_quotients(c.stream, a);
+    BF_HIP(hipGetLastError());
     return 0;
     API_CATCH
 }

@@ -1,0 +1,53 @@
+// Host-side preparation of the FRI-quotient kernel arguments: ColumnSampleBatch::new_vec + quotient_constants of stwo's
+// `core/pcs/quotients.rs` (called from `prover::prove`, reference mod.rs:732). A few hundred QM31 operations per proof; the per-row
+// work is k_quotients (quotient.hip).
+#pragma once
+#include "circle.h"
+#include "../kernels.h"
+#include <map>
+#include <vector>
+
+namespace bf {
+
+// Order of BTreeMap<CirclePoint<SecureField>, _>: derived Ord, x before y, coordinates in (a.a, a.b, b.a, b.b) order.
+struct PointLess {
+    bool operator()(const PtQ& a, const PtQ& b) const {
+        u32 av[8] = {a.x.a.a, a.x.a.b, a.x.b.a, a.x.b.b, a.y.a.a, a.y.a.b, a.y.b.a, a.y.b.b};
+        u32 bv[8] = {b.x.a.a, b.x.a.b, b.x.b.a, b.x.b.b, b.y.a.a, b.y.a.b, b.y.b.a, b.y.b.b};
+        for (int i = 0; i < 8; i++) if (av[i] != bv[i]) return av[i] < bv[i];
+        return false;
+    }
+};
+
+struct ColumnSample { PtQ point; Q31 value; };
+
+// samples[k] = the (point, value) samples of column k of one size group, in mask order.
+inline void build_quotient_batches(const std::vector<std::vector<ColumnSample>>& samples, Q31 random_coeff,
+                                   std::vector<QuotientBatch>& batches, std::vector<QuotientEntry>& entries) {
+    std::map<PtQ, std::vector<std::pair<u32, Q31>>, PointLess> by_point;
+    for (size_t k = 0; k < samples.size(); k++)
+        for (auto& s : samples[k]) by_point[s.point].push_back({(u32)k, s.value});
+    for (auto& kv : by_point) {
+        const PtQ& pt = kv.first;
+        QuotientBatch qb{};
+        qb.prx = pt.x.a; qb.pry = pt.y.a; qb.pix = pt.x.b; qb.piy = pt.y.b;
+        qb.a_sum = q_zero(); qb.b_sum = q_zero();
+        Q31 alpha = q_one();
+        for (auto& cv : kv.second) {
+            alpha = q_mul(alpha, random_coeff);
+            // complex_conjugate_line_coeffs: a = conj(v) - v, c = conj(P.y) - P.y, b = v*c - a*P.y; all scaled by alpha
+            Q31 a = q_sub(q_conj(cv.second), cv.second);
+            Q31 cc = q_sub(q_conj(pt.y), pt.y);
+            Q31 b = q_sub(q_mul(cv.second, cc), q_mul(a, pt.y));
+            qb.a_sum = q_add(qb.a_sum, q_mul(alpha, a));
+            qb.b_sum = q_add(qb.b_sum, q_mul(alpha, b));
+            QuotientEntry qe{}; qe.c = q_mul(alpha, cc); qe.col = cv.first;
+            entries.push_back(qe);
+        }
+        qb.batch_coeff = q_pow(random_coeff, kv.second.size());
+        qb.n_cols = (u32)kv.second.size();
+        batches.push_back(qb);
+    }
+}
+
+}  // namespace bf

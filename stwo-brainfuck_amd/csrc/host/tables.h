@@ -11,7 +11,6 @@
 
 namespace bf {
 
-constexpr u32 LOG_N_LANES = 4;  // stwo simd::m31::LOG_N_LANES; every table row is broadcast to 16 cells (memory/table.rs:95-104)
 
 static const char* const COMPONENT_NAMES[N_COMPONENTS] = {"memory", "instruction", "program", "processor", "jump_if_not_zero", "jump_if_zero",
     "input_instruction", "left_instruction", "minus_instruction", "output_instruction", "plus_instruction", "right_instruction", "end_of_execution"};
@@ -69,7 +68,7 @@ static inline Table memory_table(const std::vector<Registers>& trace) {
         put(e.clk, e.mp, e.mv, 0);
     }
     u32 lc = clk[w - 1], lp = mp[w - 1], lv = mv[w - 1];
-    for (size_t i = 1; w < rows; i++) put(madd(lc, (u32)i), lp, lv, 1);
+    for (size_t i = 1, n_pad = rows - w; i <= n_pad; i++) put(madd(lc, (u32)i), lp, lv, 1);
     // pairing with the next entry; the last row pairs with one more dummy (last.clk + 1, last.mp, last.mv)
     u32 *nclk = t.cols[4].data(), *nmp = t.cols[5].data(), *nmv = t.cols[6].data(), *nd = t.cols[7].data();
     for (size_t r = 0; r + 1 < rows; r++) { nclk[r] = clk[r + 1]; nmp[r] = mp[r + 1]; nmv[r] = mv[r + 1]; nd[r] = d[r + 1]; }

@@ -7,7 +7,7 @@
 // Montgomery factor of every CIOS step is m = -t0 and m * p touches only limbs 0, 6, 7. One Hades permutation (width 3, x^3 S-box,
 // 4 full + 83 partial + 4 full rounds, MDS [[3,1,1],[1,-1,1],[1,1,-2]]) is 214 field multiplications ≈ 90 k lane-ops: this hasher
 // is ~90x more VALU work per 64 hashed bytes than Blake2s — firmly VALU-bound. The permutation is pinned by the public Hades([0,0,0])
-// known-answer vector (oracle/poseidon252.py, tests/test_gpu_poseidon.py); the node layout is recalled from stwo (unpinned).
+// known-answer vector (tests/test_gpu_poseidon.py); the node layout is recalled from stwo (unpinned).
 #include "kernels.h"
 #include "poseidon_constants.h"
 #include <vector>

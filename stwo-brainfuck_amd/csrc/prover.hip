@@ -5,6 +5,7 @@
 #include "../../include/bfhip.h"
 #include "ctx.h"
 #include "host/circle.h"
+#include "host/quotients.h"
 #include "host/proof.h"
 #include "host/verifier.h"
 #include <map>
@@ -219,15 +220,6 @@ struct HipProver {
         t.mk = merkle_commit(t.evals, pinned_root);
         if (!pinned_root) ch.mix_root(t.mk.root);
     }
-
-    struct PointLess {
-        bool operator()(const PtQ& a, const PtQ& b) const {
-            u32 av[8] = {a.x.a.a, a.x.a.b, a.x.b.a, a.x.b.b, a.y.a.a, a.y.a.b, a.y.b.a, a.y.b.b};
-            u32 bv[8] = {b.x.a.a, b.x.a.b, b.x.b.a, b.x.b.b, b.y.a.a, b.y.a.b, b.y.b.a, b.y.b.b};
-            for (int i = 0; i < 8; i++) if (av[i] != bv[i]) return av[i] < bv[i];
-            return false;
-        }
-    };
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // Host table build + upload (outside the metric's timed region: "inputs already resident in HBM").
@@ -544,36 +536,16 @@ struct HipProver {
         for (size_t i = 0; i < flat.size();) {
             size_t j = i; u32 log = flat[i].col.log_size;
             while (j < flat.size() && flat[j].col.log_size == log) j++;
-            // ColumnSampleBatch::new_vec: group (column index in group, value) by point, ordered like BTreeMap<CirclePoint<QM31>, _>
-            std::map<PtQ, std::vector<std::pair<u32, Q31>>, PointLess> by_point;
+            // ColumnSampleBatch::new_vec + quotient_constants (host/quotients.h)
             std::vector<ColDesc> descs;
+            std::vector<std::vector<ColumnSample>> samples(j - i);
             for (size_t k = i; k < j; k++) {
                 descs.push_back(flat[k].col.desc());
                 const auto& pts = mask[flat[k].tree][flat[k].idx];
-                for (size_t s = 0; s < pts.size(); s++) by_point[points[pts[s]]].push_back({(u32)(k - i), pf.sampled_values[flat[k].tree][flat[k].idx][s]});
+                for (size_t s = 0; s < pts.size(); s++) samples[k - i].push_back({points[pts[s]], pf.sampled_values[flat[k].tree][flat[k].idx][s]});
             }
             std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
-            for (auto& kv : by_point) {
-                const PtQ& pt = kv.first;
-                QuotientBatch qb{};
-                qb.prx = pt.x.a; qb.pry = pt.y.a; qb.pix = pt.x.b; qb.piy = pt.y.b;
-                qb.a_sum = q_zero(); qb.b_sum = q_zero();
-                Q31 alpha = q_one();
-                for (auto& cv : kv.second) {
-                    alpha = q_mul(alpha, random_coeff);
-                    // complex_conjugate_line_coeffs: a = conj(v) - v, c = conj(P.y) - P.y, b = v*c - a*P.y; all scaled by alpha
-                    Q31 a = q_sub(q_conj(cv.second), cv.second);
-                    Q31 cc = q_sub(q_conj(pt.y), pt.y);
-                    Q31 b = q_sub(q_mul(cv.second, cc), q_mul(a, pt.y));
-                    qb.a_sum = q_add(qb.a_sum, q_mul(alpha, a));
-                    qb.b_sum = q_add(qb.b_sum, q_mul(alpha, b));
-                    QuotientEntry qe{}; qe.c = q_mul(alpha, cc); qe.col = cv.first;
-                    entries.push_back(qe);
-                }
-                qb.batch_coeff = q_pow(random_coeff, kv.second.size());
-                qb.n_cols = (u32)kv.second.size();
-                batches.push_back(qb);
-            }
+            build_quotient_batches(samples, random_coeff, batches, entries);
             c.stage_checkpoint();
             DSecure q; q.log_size = log;
             for (int w = 0; w < 4; w++) q.c[w] = c.alloc_u32(size_t(1) << log);

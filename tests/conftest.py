@@ -110,6 +110,35 @@ class Oracle:
         self._chk(self.L.orc_circle_evaluate(a.ctypes.data_as(ctypes.c_void_p), log_size, log_eval, ctypes.c_size_t(a.shape[0]), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
+    # ---- per-component operations (checkers for bfhip_logup_generate / bfhip_eval_constraints / bfhip_accumulate_quotients) ----
+    def logup_generate(self, component: int, rows: np.ndarray, elems24):
+        """rows: (n_main, n_rows) row-granular columns. Returns ((4 * n_logup, 16 * n_rows) full-size columns, claimed[4])."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        n_logup = 3 if component == 3 else 1
+        out = np.zeros((4 * n_logup, 16 * rows.shape[1]), dtype=np.uint32)
+        claimed = (ctypes.c_uint32 * 4)()
+        self._chk(self.L.orc_logup_generate(component, rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(rows.shape[1]), (ctypes.c_uint32 * 24)(*[int(v) for v in elems24]),
+                                            out.ctypes.data_as(ctypes.c_void_p), claimed))
+        return out, list(claimed)
+
+    def eval_constraints(self, component, log_size, is_first, main, inter, elems24, claimed4, coeffs, acc):
+        """All columns full size (2^(log_size+1)); acc (4, 2^(log_size+1)) is updated in place and returned."""
+        is_first = np.ascontiguousarray(is_first, dtype=np.uint32); main = np.ascontiguousarray(main, dtype=np.uint32)
+        inter = np.ascontiguousarray(inter, dtype=np.uint32); acc = np.ascontiguousarray(acc, dtype=np.uint32).copy()
+        coeffs = [int(v) for v in coeffs]
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        self._chk(self.L.orc_eval_constraints(component, log_size, p(is_first), p(main), p(inter), (ctypes.c_uint32 * 24)(*[int(v) for v in elems24]),
+                                              (ctypes.c_uint32 * 4)(*[int(v) for v in claimed4]), (ctypes.c_uint32 * len(coeffs))(*coeffs), p(acc)))
+        return acc
+
+    def accumulate_quotients(self, log_size, cols, n_samples, points, values, random_coeff4):
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        out = np.zeros((4, 1 << log_size), dtype=np.uint32)
+        u = lambda v: (ctypes.c_uint32 * len(v))(*[int(x) for x in v])
+        self._chk(self.L.orc_accumulate_quotients(log_size, cols.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cols.shape[0]), u(n_samples), u(points), u(values),
+                                                  u(random_coeff4), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
 
 @pytest.fixture(scope="session")
 def oracle():

@@ -6,7 +6,9 @@ import re
 
 import pytest
 
-from conftest import ROOT
+import numpy as np
+
+from conftest import ROOT, P, splitmix_column
 
 LMR = 12   # LOG_MAX_ROWS for the CPU suite: the four e2e programs fit (largest component log 10..12); keeps a proof under a second
 
@@ -124,3 +126,35 @@ def test_air_rejects_corrupted_trace(oracle, component, col, row, val, constrain
     elems = [5, 1, 2, 3, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83]   # avoid zero logUp denominators
     rc, bad_row, bad_c = oracle.assert_constraints("+>,<[>+.<-]", b"\x01", component, elems=elems, corrupt=(col, row, val))
     assert rc == 1 and bad_c == constraint and bad_row // 16 == row
+
+
+def test_per_component_checkers_are_consistent(oracle):
+    """The per-component oracle entry points (checkers of bfhip_logup_generate / bfhip_eval_constraints): the 13 claimed sums
+    cancel for shared lookup elements, replicated logUp columns are 16-lane broadcasts, and constraint evaluation is additive in
+    the accumulator and linear in the random coefficients."""
+    code, inp = "+++>,<[>+.<-]", b"\x01"
+    elems = splitmix_column(31, 24).tolist()
+    total = np.zeros(4, dtype=object)
+    for comp in range(13):
+        rows = np.ascontiguousarray(oracle.table(code, inp, comp).T)
+        cols, claimed = oracle.logup_generate(comp, rows, elems)
+        for k in range(cols.shape[0] - 4):
+            assert np.array_equal(np.repeat(cols[k][::16], 16), cols[k])
+        assert cols[-4:, 1].tolist() == claimed                      # prefix_sum.at(1) is the last coset element (finalize_last)
+        total = (total + np.array(claimed, dtype=object)) % P
+    assert not total.any()
+
+    comp = 0
+    rows = np.ascontiguousarray(oracle.table(code, inp, comp).T)
+    log = int(np.log2(rows.shape[1])) + 4
+    n = 1 << (log + 1)
+    inter, claimed = oracle.logup_generate(comp, rows, elems)
+    lde = lambda c: oracle.evaluate(oracle.interpolate(c, log), log, log + 1)
+    one_hot = np.zeros((1, 1 << log), dtype=np.uint32); one_hot[0, 0] = 1
+    args = (comp, log, lde(one_hot)[0], lde(np.repeat(rows, 16, axis=1)), lde(inter), elems, claimed)
+    c1, c2 = splitmix_column(1, 48), splitmix_column(2, 48)
+    zero = np.zeros((4, n), dtype=np.uint32)
+    add = lambda a, b: ((a.astype(np.uint64) + b) % P).astype(np.uint32)
+    r1, r2 = oracle.eval_constraints(*args, c1, zero), oracle.eval_constraints(*args, c2, zero)
+    assert np.array_equal(oracle.eval_constraints(*args, add(c1, c2), zero), add(r1, r2))
+    assert np.array_equal(oracle.eval_constraints(*args, c2, r1), add(r1, r2))
