@@ -1,0 +1,27 @@
+"""-m gpu: randomized programs (tests/bf_fuzz.py, seeded): the device-resident proof is byte-identical to the oracle's, with
+either table builder, and the product's own verifier accepts it."""
+import pytest
+
+from bf_fuzz import random_program
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = list(range(100, 124))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_program_proof_matches_oracle(ctx, pkg, oracle, seed):
+    code, inp, _ = random_program(seed)
+    log_max_rows = max(max(oracle.log_sizes(code, inp)[0]), 8)
+    want, otr, _ = oracle.prove(code, inp, log_max_rows=log_max_rows)
+    got, tr = pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows, with_transcript=True)
+    diverged = next((k for k in otr if otr[k] != tr.get(k)), None)
+    assert diverged is None, f"{code!r}: transcript diverges at {diverged}"
+    assert got == want, code
+    assert pkg.verify_brainfuck(got, log_max_rows) == (True, "")
+    if seed % 4 == 0:                                              # host table builders instead of the GPU ones
+        pkg.set_table_builder(False)
+        try:
+            assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows) == want
+        finally:
+            pkg.set_table_builder(True)
