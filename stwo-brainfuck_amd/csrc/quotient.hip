@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             C31 dinv = {m_mul(den[r].a, ninv[r]), m_neg(m_mul(den[r].b, ninv[r]))};
-            acc[r] = q_add(q_mul(acc[r], qb.batch_coeff), q_mulc(num[r], dinv));
+            Q31 term = q_mulc(num[r], dinv);
+            acc[r] = b ? q_add(q_mul(acc[r], qb.batch_coeff), term) : term;   // 0 * coeff + term for the first batch
         }
     }
     *reinterpret_cast<uint4*>(a.out[0] + row0) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
