@@ -64,8 +64,11 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
 int32_t bfhip_broadcast16(bfhip_ctx* ctx, const uint32_t* rows_d, uint32_t* dst_d, size_t n_rows);
 /* ColumnOps::bit_reverse_column: dst[bit_reverse(i)] = src[i] (out of place), 2^log_size cells. */
 int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size);
-/* FieldOps::batch_inverse over M31 (used by LogupTraceGenerator::finalize_col, memory/table.rs:513): dst[i] = src[i]^-1, src[i] != 0. */
+/* FieldOps::batch_inverse over M31: dst[i] = src[i]^-1, src[i] != 0. */
 int32_t bfhip_batch_inverse_m31(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, size_t n);
+/* FieldOps::batch_inverse over QM31 (the PackedSecureField denominators of LogupTraceGenerator::finalize_col, memory/table.rs:513):
+ * 4 coordinate columns in, 4 out (may alias), n elements, none zero. */
+int32_t bfhip_batch_inverse_qm31(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], size_t n);
 /* AccumulationOps::accumulate: dst[i] += src[i] in M31. */
 int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d, size_t n);
 /* PolyOps::eval_at_point (CommitmentSchemeProver::prove_values): f(P) for P = (x, y) in QM31^2 given as u32[8] = x[4] || y[4];

@@ -109,6 +109,9 @@ class Context:
     def batch_inverse_m31(self, src_ptr, dst_ptr, n):
         _check(lib().bfhip_batch_inverse_m31(self._h, ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), ctypes.c_size_t(n)))
 
+    def batch_inverse_qm31(self, src_ptrs, dst_ptrs, n):
+        _check(lib().bfhip_batch_inverse_qm31(self._h, self._ptr_array(src_ptrs), self._ptr_array(dst_ptrs), ctypes.c_size_t(n)))
+
     def accumulate(self, dst_ptr, src_ptr, n):
         _check(lib().bfhip_accumulate(self._h, ctypes.c_void_p(dst_ptr), ctypes.c_void_p(src_ptr), ctypes.c_size_t(n)))
 

@@ -132,6 +132,9 @@ int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d
 int32_t bfhip_batch_inverse_m31(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, size_t n) {
     API_TRY batch_inverse_m31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
+int32_t bfhip_batch_inverse_qm31(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], size_t n) {
+    API_TRY batch_inverse_qm31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+}
 int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d, size_t n) {
     API_TRY accumulate(ctx->c.stream, dst_d, src_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }

@@ -76,6 +76,7 @@ struct GatherReq { const u32* base; u64 index; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);
 void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n);
+void batch_inverse_qm31(hipStream_t stream, const u32* const src[4], u32* const dst[4], u32 n);
 void bit_reverse(hipStream_t stream, const u32* src, u32* dst, u32 log);
 void one_hot(hipStream_t stream, u32* dst, u32 n);
 

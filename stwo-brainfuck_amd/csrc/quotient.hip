@@ -277,6 +277,37 @@ void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n) {
     hipLaunchKernelGGL(k_batch_inverse_m31, dim3((lanes + 255) / 256), dim3(256), 0, stream, src, dst, n);
 }
 
+// FieldOps::batch_inverse over QM31 (SecureColumnByCoords, 4 coordinate columns): one norm inversion per element; the M31 inversion
+// of 4 consecutive elements is shared (Montgomery trick) — values equal elementwise inverses.
+__global__ void __launch_bounds__(256) k_batch_inverse_qm31(const u32* s0, const u32* s1, const u32* s2, const u32* s3, u32* d0, u32* d1, u32* d2, u32* d3, u32 n) {   // dst may alias src
+    u32 base = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (base >= n) return;
+    u32 cnt = min(4u, n - base);
+    Q31 x[4]; C31 den[4]; u32 nrm[4], pre[4];
+    u32 acc = 1;
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        u32 i = base + (k < cnt ? k : 0);
+        x[k] = q_make(s0[i], s1[i], s2[i], s3[i]);
+        den[k] = c_sub(c_mul(x[k].a, x[k].a), c_mulR(c_mul(x[k].b, x[k].b)));      // a^2 - (2 + i) b^2 in CM31
+        nrm[k] = m_add(m_sqr(den[k].a), m_sqr(den[k].b));
+        pre[k] = acc; acc = m_mul(acc, nrm[k]);
+    }
+    u32 inv = m_inv(acc);
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        u32 ninv = m_mul(inv, pre[k]); inv = m_mul(inv, nrm[k]);
+        C31 dinv = {m_mul(den[k].a, ninv), m_neg(m_mul(den[k].b, ninv))};
+        Q31 r = {c_mul(x[k].a, dinv), c_neg(c_mul(x[k].b, dinv))};
+        if ((u32)k < cnt) { u32 i = base + k; d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b; }
+    }
+}
+void batch_inverse_qm31(hipStream_t stream, const u32* const src[4], u32* const dst[4], u32 n) {
+    if (!n) return;
+    u32 lanes = (n + 3) / 4;
+    hipLaunchKernelGGL(k_batch_inverse_qm31, dim3((lanes + 255) / 256), dim3(256), 0, stream, src[0], src[1], src[2], src[3], dst[0], dst[1], dst[2], dst[3], n);
+}
+
 // ColumnOps::bit_reverse_column (not on the prove path — the reference stores traces already bit-reversed — but part of the
 // backend surface): out-of-place permutation.
 __global__ void k_bit_reverse(const u32* __restrict__ src, u32* __restrict__ dst, u32 log) {

@@ -43,6 +43,21 @@ def test_batch_inverse_m31(ctx, n):
     ctx.free(p); ctx.free(q)
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 1001, 1 << 15])
+def test_batch_inverse_qm31(ctx, oracle, n):
+    cols = [splitmix_column(20 + k, n) for k in range(4)]
+    cols[0][cols[0] == 0] = 1
+    flat = np.ascontiguousarray(np.stack(cols, axis=1).reshape(-1))           # AoS for the oracle's qm31 op
+    want = np.zeros_like(flat)
+    oracle.L.orc_qm31_op(3, flat.ctypes.data_as(ctypes.c_void_p), None, want.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n))
+    src = [ctx.upload(c) for c in cols]
+    ctx.batch_inverse_qm31(src, src, n)                                        # in place
+    got = np.stack([ctx.download(p, n) for p in src], axis=1).reshape(-1)
+    assert np.array_equal(got, want)
+    for p in src:
+        ctx.free(p)
+
+
 def test_broadcast16_then_full_transform_equals_replicated_transform(ctx):
     log = 12
     rows = splitmix_column(66, 1 << (log - 4))

@@ -43,6 +43,15 @@ def test_inverse_of_two_is_reference_constant(oracle):
     assert m31(oracle, 3, np.array([2], dtype=np.uint32))[0] == 1073741824
 
 
+def test_qm31_product_known_answer(oracle):
+    """(1 + 2i + (3 + 4i)u) * (4 + 5i + (6 + 7i)u) = -71 + 93i + (-16 + 50i)u with u^2 = 2 + i — the worked product of upstream stwo's
+    qm31 unit test (core/fields/qm31.rs test_ops: qm31!(P - 71, 93, P - 16, 50)); checkable by hand."""
+    a = np.array([1, 2, 3, 4], dtype=np.uint32); b = np.array([4, 5, 6, 7], dtype=np.uint32)
+    assert qm31(oracle, 2, a, b).tolist() == [P - 71, 93, P - 16, 50]
+    assert qm31(oracle, 0, a, b).tolist() == [5, 7, 9, 11]
+    assert qm31(oracle, 1, a, b).tolist() == [P - 3] * 4
+
+
 def test_qm31_field_axioms(oracle):
     a = splitmix_column(3, 4 * 512); b = splitmix_column(4, 4 * 512); c = splitmix_column(5, 4 * 512)
     mul = lambda x, y: qm31(oracle, 2, x, y)
