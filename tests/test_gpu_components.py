@@ -99,7 +99,7 @@ def test_component_shape(pkg):
     import ctypes
     L = pkg.lib()
     a, b, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
-    assert L.bfhip_component_shape(3, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0 and (a.value, b.value, c.value) == (13, 3, 10)
+    assert L.bfhip_component_shape(3, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0 and (a.value, b.value, c.value) == (9, 3, 10)
     assert L.bfhip_component_shape(13, None, None, None) == -1
 
 
