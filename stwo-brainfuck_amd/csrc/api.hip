@@ -203,16 +203,22 @@ int32_t bfhip_hades_permutation(bfhip_ctx* ctx, const uint32_t in_h[24], uint32_
     API_CATCH
 }
 static Q31 q_from_h(const uint32_t v[4]) { return q_make(v[0], v[1], v[2], v[3]); }
+static const u32* stage_alpha(Ctx& c, const uint32_t alpha_h[4]) {
+    Q31 a = q_from_h(alpha_h), sq = q_mul(a, a);
+    u32 w[8] = {a.a.a, a.a.b, a.b.a, a.b.b, sq.a.a, sq.a.b, sq.b.a, sq.b.b};
+    c.stage_checkpoint();
+    return c.stage(w, 8);
+}
 int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
     API_TRY
     if (log_size < 1 || log_size > ctx->c.tw_root_log) throw HipError("fold_line: log_size outside the twiddle tree");
-    fold_line(ctx->c.stream, dst_d, src_d, q_from_h(alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
+    fold_line(ctx->c.stream, dst_d, src_d, stage_alpha(ctx->c, alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
     API_CATCH
 }
 int32_t bfhip_fold_circle_into_line(bfhip_ctx* ctx, uint32_t* const dst_d[4], const uint32_t* const src_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
     API_TRY
     if (log_size < 3 || log_size > ctx->c.tw_root_log + 1) throw HipError("fold_circle_into_line: log_size outside the twiddle tree");
-    fold_circle_into_line(ctx->c.stream, dst_d, src_d, q_from_h(alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
+    fold_circle_into_line(ctx->c.stream, dst_d, src_d, stage_alpha(ctx->c, alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
     API_CATCH
 }
 int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bits, uint64_t* nonce) {

@@ -42,6 +42,8 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift);
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
+// Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4].
+void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8);
 
 // poseidon.hip — Poseidon252 Merkle variant (BASELINE config 5; not used by the reference)
 void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log);
@@ -70,8 +72,9 @@ struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u3
 struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
 struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; };
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
-void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log);
-void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], Q31 alpha, const u32* itw, u32 tw_root_log, u32 log);
+// d_alpha8: device pointer to alpha[4] || alpha^2[4]
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
+void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
 struct GatherReq { const u32* base; u64 index; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);

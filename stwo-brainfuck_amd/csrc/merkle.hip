@@ -123,6 +123,39 @@ void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
     hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log);
 }
 
+// Blake2sChannel stepped on the device for the FRI commit phase (FriProver::commit: mix_root(layer root) then draw_felt per layer):
+// removes the device -> host -> device round trip between consecutive layers. One lane; two compressions plus rare redraws.
+// chan = digest[8] || n_sent. alpha_out = alpha[4] || alpha^2[4].
+__global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    u32 h[8], m[16], digest[8];
+    // mix_root: digest = Blake2s(digest || root), n_sent = 0
+    for (int k = 0; k < 8; k++) { m[k] = chan[k]; m[8 + k] = root[k]; h[k] = B2S_IV[k]; }
+    h[0] ^= 0x01010020u;
+    blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+    for (int k = 0; k < 8; k++) digest[k] = h[k];
+    // draw_felt: Blake2s(digest || n_sent as LE u32 || zero padding to 64 bytes), redrawn until all 8 words are < 2P
+    u32 n_sent = 0;
+    for (;;) {
+        for (int k = 0; k < 8; k++) { m[k] = digest[k]; m[8 + k] = 0; h[k] = B2S_IV[k]; }
+        m[8] = n_sent++;
+        h[0] ^= 0x01010020u;
+        blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+        bool ok = true;
+        for (int k = 0; k < 8; k++) ok = ok && h[k] < 2u * P31;
+        if (ok) break;
+    }
+    Q31 alpha = q_make(h[0] >= P31 ? h[0] - P31 : h[0], h[1] >= P31 ? h[1] - P31 : h[1], h[2] >= P31 ? h[2] - P31 : h[2], h[3] >= P31 ? h[3] - P31 : h[3]);
+    Q31 sq = q_mul(alpha, alpha);
+    alpha_out[0] = alpha.a.a; alpha_out[1] = alpha.a.b; alpha_out[2] = alpha.b.a; alpha_out[3] = alpha.b.b;
+    alpha_out[4] = sq.a.a; alpha_out[5] = sq.a.b; alpha_out[6] = sq.b.a; alpha_out[7] = sq.b.b;
+    for (int k = 0; k < 8; k++) chan[k] = digest[k];
+    chan[8] = n_sent;
+}
+void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8) {
+    hipLaunchKernelGGL(k_channel_mix_root_draw, dim3(1), dim3(64), 0, stream, d_chan, d_root, d_alpha8);
+}
+
 // Proof-of-work search (GrindOps::grind): smallest nonce whose mix_u64 digest has >= pow_bits trailing zero bits
 // (trailing_zeros of the first 16 digest bytes as LE u128). Each launch scans `span` nonces from `base`; the minimum hit is kept.
 __global__ void k_grind(const u32* __restrict__ digest, u64 base, u32 pow_bits, unsigned long long* __restrict__ best) {

@@ -604,42 +604,60 @@ struct HipProver {
     }
 
     void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf) {
-        // FriProver::commit — first layer: one Merkle tree over the coordinate columns of every quotient
+        // FriProver::commit — first layer: one Merkle tree over the coordinate columns of every quotient.
+        // The channel is stepped on the device through the whole commit phase (k_channel_mix_root_draw): per layer mix_root(root) and
+        // draw_felt() run as a one-lane kernel and the folds read alpha from device memory, so the ~25 layers are enqueued back to back
+        // with no host round trip. The roots arrive in pinned memory; the host channel replays the same steps afterwards and must end
+        // in the same state.
         std::vector<DCol> first_cols;
         for (auto& q : quotients) for (auto& col : secure_cols(q)) first_cols.push_back(col);
-        DevMerkle first_tree = merkle_commit(first_cols);
-        ch.mix_root(first_tree.root);
+        const size_t max_layers = 40;
+        Hash32* pinned_roots = reinterpret_cast<Hash32*>(c.h_small + 64);                       // [0] first layer, [1 + i] inner layer i
+        u32* pinned_chan = reinterpret_cast<u32*>(c.h_small + 64 + 32 * (max_layers + 1));      // digest[8] || n_sent
+        u32* d_chan = c.alloc_u32(16);
+        u32* d_alpha = c.alloc_u32(8 * (max_layers + 1));
+        memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
+        BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
+        DevMerkle first_tree = merkle_commit(first_cols, &pinned_roots[0]);
+        u32 cur_alpha = 0;
+        channel_mix_root_draw(c.stream, d_chan, first_tree.layers[0], d_alpha);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
         DSecure layer; layer.log_size = line_log;
         for (int w = 0; w < 4; w++) { layer.c[w] = c.alloc_u32(size_t(1) << line_log); BF_HIP(hipMemsetAsync(layer.c[w], 0, sizeof(u32) << line_log, c.stream)); }
         size_t qi = 0;
-        Q31 alpha = ch.draw_felt();
         u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
+        if (line_log > last_log + max_layers) throw HipError("FRI: too many layers");
         while (line_log > last_log) {
             while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
                 const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
-                fold_circle_into_line(c.stream, layer.c, src, alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size);
+                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size);
                 qi++;
             }
             Inner in; in.ev = layer;
-            in.tree = merkle_commit(secure_cols(layer));
-            ch.mix_root(in.tree.root);
-            alpha = ch.draw_felt();
+            in.tree = merkle_commit(secure_cols(layer), &pinned_roots[1 + inner.size()]);
+            cur_alpha++;
+            channel_mix_root_draw(c.stream, d_chan, in.tree.layers[0], d_alpha + 8 * cur_alpha);
             DSecure next; next.log_size = line_log - 1;
             for (int w = 0; w < 4; w++) next.c[w] = c.alloc_u32(size_t(1) << (line_log - 1));
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
-            fold_line(c.stream, next.c, src, alpha, c.d_itw, c.tw_root_log, line_log);
+            fold_line(c.stream, next.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, line_log);
             inner.push_back(in);
             layer = next; line_log--;
         }
         if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
+        BF_HIP(hipGetLastError());
+        BF_HIP(hipMemcpyAsync(pinned_chan, d_chan, 36, hipMemcpyDeviceToHost, c.stream));
         // last layer: 2^last_log evaluations -> line polynomial (host; LineEvaluation::interpolate on <= 2 values for the default config)
         {
             if (last_log != 1 || cfg.log_last_layer_degree_bound != 0) throw HipError("only the default FRI last-layer configuration is supported");
             std::vector<size_t> pos = {0, 1};
-            auto v = gather_secure(layer, pos);
+            auto v = gather_secure(layer, pos);          // synchronises: roots and the device channel state are on the host now
+            first_tree.root = pinned_roots[0];
+            ch.mix_root(first_tree.root); (void)ch.draw_felt();
+            for (size_t li = 0; li < inner.size(); li++) { inner[li].tree.root = pinned_roots[1 + li]; ch.mix_root(inner[li].tree.root); (void)ch.draw_felt(); }
+            if (memcmp(pinned_chan, ch.digest.b, 32) != 0 || pinned_chan[8] != ch.n_sent) throw HipError("FRI: device channel diverged from the host channel");
             // line_ifft on 2 values over LineDomain(half_odds(1)): c0 = (v0 + v1) / 2, c1 = (v0 - v1) / (2 x0) must vanish
             u32 inv2 = m_inv(2);
             Q31 c0 = q_mulm(q_add(v[0], v[1]), inv2);
