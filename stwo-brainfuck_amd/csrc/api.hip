@@ -12,6 +12,7 @@ static thread_local std::string g_err;
 void bfhip_set_error(const std::string& s) { g_err = s; }
 
 #define API_TRY try {
+#define API_CTX(ctx) try { if (!(ctx)) throw HipError("null context"); (ctx)->c.bind();
 #define API_CATCH } catch (const std::exception& e) { g_err = e.what(); return -1; } catch (...) { g_err = "unknown error"; return -1; }
 
 namespace bf {
@@ -73,24 +74,24 @@ int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx**
     API_CATCH
 }
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
-int32_t bfhip_ctx_sync(bfhip_ctx* ctx) { API_TRY ctx->c.sync(); return 0; API_CATCH }
+int32_t bfhip_ctx_sync(bfhip_ctx* ctx) { API_CTX(ctx) ctx->c.sync(); return 0; API_CATCH }
 
-int32_t bfhip_malloc(bfhip_ctx* ctx, size_t bytes, void** out_d) { API_TRY BF_HIP(hipSetDevice(ctx->c.device)); BF_HIP(hipMalloc(out_d, bytes ? bytes : 4)); return 0; API_CATCH }
-int32_t bfhip_free(bfhip_ctx* ctx, void* p) { API_TRY (void)ctx; BF_HIP(hipFree(p)); return 0; API_CATCH }
+int32_t bfhip_malloc(bfhip_ctx* ctx, size_t bytes, void** out_d) { API_CTX(ctx) BF_HIP(hipSetDevice(ctx->c.device)); BF_HIP(hipMalloc(out_d, bytes ? bytes : 4)); return 0; API_CATCH }
+int32_t bfhip_free(bfhip_ctx* ctx, void* p) { API_CTX(ctx) (void)ctx; BF_HIP(hipFree(p)); return 0; API_CATCH }
 int32_t bfhip_upload(bfhip_ctx* ctx, void* dst_d, const void* src_h, size_t bytes) {
-    API_TRY BF_HIP(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, ctx->c.stream)); ctx->c.sync(); return 0; API_CATCH
+    API_CTX(ctx) BF_HIP(hipMemcpyAsync(dst_d, src_h, bytes, hipMemcpyHostToDevice, ctx->c.stream)); ctx->c.sync(); return 0; API_CATCH
 }
 int32_t bfhip_download(bfhip_ctx* ctx, void* dst_h, const void* src_d, size_t bytes) {
-    API_TRY BF_HIP(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, ctx->c.stream)); ctx->c.sync(); return 0; API_CATCH
+    API_CTX(ctx) BF_HIP(hipMemcpyAsync(dst_h, src_d, bytes, hipMemcpyDeviceToHost, ctx->c.stream)); ctx->c.sync(); return 0; API_CATCH
 }
-int32_t bfhip_memset_zero(bfhip_ctx* ctx, void* dst_d, size_t bytes) { API_TRY BF_HIP(hipMemsetAsync(dst_d, 0, bytes, ctx->c.stream)); return 0; API_CATCH }
+int32_t bfhip_memset_zero(bfhip_ctx* ctx, void* dst_d, size_t bytes) { API_CTX(ctx) BF_HIP(hipMemsetAsync(dst_d, 0, bytes, ctx->c.stream)); return 0; API_CATCH }
 
 int32_t bfhip_twiddles(bfhip_ctx* ctx, const uint32_t** tw_d, const uint32_t** itw_d, uint32_t* root_log) {
-    API_TRY *tw_d = ctx->c.d_tw; *itw_d = ctx->c.d_itw; *root_log = ctx->c.tw_root_log; return 0; API_CATCH
+    API_CTX(ctx) *tw_d = ctx->c.d_tw; *itw_d = ctx->c.d_itw; *root_log = ctx->c.tw_root_log; return 0; API_CATCH
 }
 
 int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t* const* dst_cols_h, uint32_t n_cols, uint32_t log_size, int32_t replicated) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     if (replicated && log_size < 4) throw HipError("replicated columns need log_size >= 4");
     if (!replicated && log_size < 3) throw HipError("circle transforms need log_size >= 3");
@@ -106,7 +107,7 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
 }
 
 int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* const* dst_cols_h, uint32_t n_cols, uint32_t log_size, uint32_t log_eval, int32_t replicated) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     if (log_eval < log_size) throw HipError("log_eval < log_size");
     if (replicated && log_size < 4) throw HipError("replicated columns need log_size >= 4");
@@ -124,22 +125,22 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
 
 
 int32_t bfhip_broadcast16(bfhip_ctx* ctx, const uint32_t* rows_d, uint32_t* dst_d, size_t n_rows) {
-    API_TRY broadcast16(ctx->c.stream, rows_d, dst_d, (u32)(n_rows * 16)); BF_HIP(hipGetLastError()); return 0; API_CATCH
+    API_CTX(ctx) broadcast16(ctx->c.stream, rows_d, dst_d, (u32)(n_rows * 16)); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
 int32_t bfhip_bit_reverse(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, uint32_t log_size) {
-    API_TRY if (src_d == dst_d) throw HipError("bit_reverse is out of place"); bit_reverse(ctx->c.stream, src_d, dst_d, log_size); BF_HIP(hipGetLastError()); return 0; API_CATCH
+    API_CTX(ctx) if (src_d == dst_d) throw HipError("bit_reverse is out of place"); bit_reverse(ctx->c.stream, src_d, dst_d, log_size); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
 int32_t bfhip_batch_inverse_m31(bfhip_ctx* ctx, const uint32_t* src_d, uint32_t* dst_d, size_t n) {
-    API_TRY batch_inverse_m31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+    API_CTX(ctx) batch_inverse_m31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
 int32_t bfhip_batch_inverse_qm31(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], size_t n) {
-    API_TRY batch_inverse_qm31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+    API_CTX(ctx) batch_inverse_qm31(ctx->c.stream, src_d, dst_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
 int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d, size_t n) {
-    API_TRY accumulate(ctx->c.stream, dst_d, src_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
+    API_CTX(ctx) accumulate(ctx->c.stream, dst_d, src_d, (u32)n); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
 int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t log_size, int32_t replicated, const uint32_t point_h[8], uint32_t out_h[4]) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     if (replicated && log_size < 4) throw HipError("replicated columns need log_size >= 4");
     c.stage_checkpoint();
@@ -166,7 +167,7 @@ int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t l
 }
 int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
                                   uint32_t n_cols, void* out_hashes_d) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     c.stage_checkpoint();
     std::vector<ColDesc> d(n_cols);
@@ -179,7 +180,7 @@ int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void*
 }
 int32_t bfhip_merkle_commit_layer_poseidon252(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
                                              uint32_t n_cols, void* out_hashes_d) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     c.stage_checkpoint();
     std::vector<ColDesc> d(n_cols);
@@ -191,7 +192,7 @@ int32_t bfhip_merkle_commit_layer_poseidon252(bfhip_ctx* ctx, uint32_t log_size,
     API_CATCH
 }
 int32_t bfhip_hades_permutation(bfhip_ctx* ctx, const uint32_t in_h[24], uint32_t out_h[24]) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     c.stage_checkpoint();
     u32* din = (u32*)c.stage(in_h, 24);
@@ -210,19 +211,19 @@ static const u32* stage_alpha(Ctx& c, const uint32_t alpha_h[4]) {
     return c.stage(w, 8);
 }
 int32_t bfhip_fold_line(bfhip_ctx* ctx, const uint32_t* const src_d[4], uint32_t* const dst_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
-    API_TRY
+    API_CTX(ctx)
     if (log_size < 1 || log_size > ctx->c.tw_root_log) throw HipError("fold_line: log_size outside the twiddle tree");
     fold_line(ctx->c.stream, dst_d, src_d, stage_alpha(ctx->c, alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
     API_CATCH
 }
 int32_t bfhip_fold_circle_into_line(bfhip_ctx* ctx, uint32_t* const dst_d[4], const uint32_t* const src_d[4], uint32_t log_size, const uint32_t alpha_h[4]) {
-    API_TRY
+    API_CTX(ctx)
     if (log_size < 3 || log_size > ctx->c.tw_root_log + 1) throw HipError("fold_circle_into_line: log_size outside the twiddle tree");
     fold_circle_into_line(ctx->c.stream, dst_d, src_d, stage_alpha(ctx->c, alpha_h), ctx->c.d_itw, ctx->c.tw_root_log, log_size); BF_HIP(hipGetLastError()); return 0;
     API_CATCH
 }
 int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bits, uint64_t* nonce) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     c.stage_checkpoint();
     u32* d_digest = (u32*)c.stage(digest_h, 32);
@@ -240,7 +241,7 @@ int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bit
     API_CATCH
 }
 int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_h, size_t n, uint32_t* out_h) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     std::vector<GatherReq> req(n);
     for (size_t i = 0; i < n; i++) req[i] = GatherReq{col_d, idx_h[i]};
@@ -278,7 +279,7 @@ int32_t bfhip_component_shape(int32_t component, uint32_t* n_main, uint32_t* n_l
 }
 int32_t bfhip_logup_generate(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* const* main_rows_h, const uint32_t lookup_h[24],
                              uint32_t* const* out_cols_h, uint32_t claimed_sum_h[4]) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     check_component(component, log_size, c, 0);
     u32 log_rows = log_size - LOG_N_LANES;
@@ -308,7 +309,7 @@ int32_t bfhip_logup_generate(bfhip_ctx* ctx, int32_t component, uint32_t log_siz
 int32_t bfhip_eval_constraints(bfhip_ctx* ctx, int32_t component, uint32_t log_size, const uint32_t* is_first_d, const uint32_t* const* main_lde_h,
                                const uint32_t* main_shifts_h, const uint32_t* const* inter_lde_h, const uint32_t* inter_shifts_h, const uint32_t lookup_h[24],
                                const uint32_t claimed_sum_h[4], const uint32_t* coeffs_h, uint32_t* const acc_d[4]) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     check_component(component, log_size, c, 1);
     u32 eval_log = log_size + 1;
@@ -330,7 +331,7 @@ int32_t bfhip_eval_constraints(bfhip_ctx* ctx, int32_t component, uint32_t log_s
 int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint32_t* const* cols_h, const uint32_t* col_shifts_h, uint32_t n_cols,
                                    const uint32_t* n_samples_h, const uint32_t* sample_points_h, const uint32_t* sample_values_h,
                                    const uint32_t random_coeff_h[4], uint32_t* const out_d[4]) {
-    API_TRY
+    API_CTX(ctx)
     Ctx& c = ctx->c;
     if (log_size < 3 || log_size > c.tw_root_log + 1) throw HipError("accumulate_quotients: log_size outside the twiddle tree");
     std::vector<ColDesc> descs(n_cols);

@@ -44,6 +44,9 @@ struct Ctx {
 
     void init(int dev, u32 max_log_domain);
     void destroy();
+    // HIP's current device is per host thread: every C-ABI entry binds the calling thread to this context's GPU first, so that
+    // allocations (arena chunks, hipMalloc) land on the device the stream belongs to whichever thread drives the context.
+    void bind() { BF_HIP(hipSetDevice(device)); }
     void sync() { BF_HIP(hipStreamSynchronize(stream)); }
     // Copy a small host block to device scratch (valid until the next stage_reset()). Stream-ordered.
     template <class T>

@@ -156,29 +156,32 @@ __global__ void k_hades_once(const u32* __restrict__ in, u32* __restrict__ out, 
     for (int k = 0; k < 3; k++) { Fe y = fe_mul(s[k], one_plain, P); for (int i = 0; i < 8; i++) out[8 * k + i] = y.l[i]; }
 }
 
-static u32* g_poseidon_consts = nullptr;   // per process; tiny (8.8 KB)
+static u32* g_poseidon_consts[64] = {nullptr};   // per device; tiny (8.8 KB each), kept for the life of the process
 static std::mutex g_poseidon_mutex;
-static const u32* poseidon_consts(hipStream_t s) {
+static const u32* poseidon_consts() {
     std::lock_guard<std::mutex> guard(g_poseidon_mutex);
-    if (!g_poseidon_consts) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) throw std::runtime_error("hipGetDevice(poseidon constants)");
+    if (!g_poseidon_consts[dev]) {
         std::vector<u32> h;
         h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_R1, POSEIDON_R1 + 8); h.insert(h.end(), POSEIDON_R2, POSEIDON_R2 + 8);
         for (int r = 0; r < 273; r++) h.insert(h.end(), POSEIDON_ARK[r], POSEIDON_ARK[r] + 8);
-        if (hipMalloc((void**)&g_poseidon_consts, h.size() * sizeof(u32)) != hipSuccess) throw std::runtime_error("hipMalloc(poseidon constants)");
-        if (hipMemcpy(g_poseidon_consts, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("hipMemcpy(poseidon constants)");
+        u32* p = nullptr;
+        if (hipMalloc((void**)&p, h.size() * sizeof(u32)) != hipSuccess) throw std::runtime_error("hipMalloc(poseidon constants)");
+        if (hipMemcpy(p, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); throw std::runtime_error("hipMemcpy(poseidon constants)"); }
+        g_poseidon_consts[dev] = p;
     }
-    (void)s;
-    return g_poseidon_consts;
+    return g_poseidon_consts[dev];
 }
 
 void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log) {
     u32 n = 1u << log;
     u32 threads = n < 128 ? (n < 64 ? 64 : n) : 128;
     ProfScope ps(stream, "k_merkle_layer_poseidon", 0);
-    hipLaunchKernelGGL(k_merkle_layer_poseidon, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (u32*)out, (const u32*)prev, d_cols, ncols, n, poseidon_consts(stream));
+    hipLaunchKernelGGL(k_merkle_layer_poseidon, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (u32*)out, (const u32*)prev, d_cols, ncols, n, poseidon_consts());
 }
 void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24) {
-    hipLaunchKernelGGL(k_hades_once, dim3(1), dim3(64), 0, stream, d_in24, d_out24, poseidon_consts(stream));
+    hipLaunchKernelGGL(k_hades_once, dim3(1), dim3(64), 0, stream, d_in24, d_out24, poseidon_consts());
 }
 
 }  // namespace bf

@@ -755,6 +755,7 @@ extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint
         *n_rows = col.stored();
         if (out_h) {
             if (cap < col.stored()) { bfhip_set_error("capacity"); return -2; }
+            ctx->c.bind();
             BF_HIP(hipMemcpyAsync(out_h, col.ptr, col.stored() * sizeof(u32), hipMemcpyDeviceToHost, ctx->c.stream));
             ctx->c.sync();
         }
@@ -780,6 +781,7 @@ static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_j
 extern "C" int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, bfhip_trace** out,
                                        uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
     try {
+        ctx->c.bind();
         std::vector<u32> ins = compile(code);
         Machine m(ins, std::vector<u8>(input, input + n_input));
         m.execute();
@@ -798,6 +800,7 @@ extern "C" int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* t) { (void)c
 extern "C" int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                                       char** transcript, double* phase_seconds) {
     try {
+        ctx->c.bind();
         HipProver pv(ctx->c, log_max_rows);
         pv.want_transcript = transcript != nullptr;
         BrainfuckProof bp = pv.prove(trace->in);
@@ -810,6 +813,7 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
                                           char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
     TraceInput in;
     try {
+        ctx->c.bind();
         HipProver pv(ctx->c, log_max_rows);
         pv.want_transcript = transcript != nullptr;
         // VM run + table build + upload happen while the GPU already works on the preprocessed commitment
