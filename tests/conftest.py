@@ -38,6 +38,8 @@ class Oracle:
         self.L.orc_last_error.restype = ctypes.c_char_p
         self.L.orc_channel_new.restype = ctypes.c_void_p
         self.L.orc_channel_grind.restype = ctypes.c_uint64
+        # OpenMP over every hardware thread of a large host is slower than a few threads for these sizes (fork/join per loop)
+        self.L.orc_set_threads(min(os.cpu_count() or 1, 16))
 
     def _chk(self, rc):
         if rc < 0:
