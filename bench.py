@@ -45,16 +45,22 @@ def cpu_baseline():
     orc = Oracle()
     path = os.path.join(ROOT, "tests", "golden", "programs", "collatz.bf")
     code = open(path).read()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 64)   # the port's OpenMP loops stop scaling beyond a few dozen threads
-    orc.L.orc_set_threads(cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     log_sizes, steps = orc.log_sizes(code, b"7\n")
     main_cols = [8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7]
     inter_cols = [4, 4, 4, 12, 4, 4, 4, 4, 4, 4, 4, 4, 4]
     cells = sum((m + i) << l for m, i, l in zip(main_cols, inter_cols, log_sizes))
-    _, _, sec = orc.prove(code, b"7\n", log_max_rows=max(log_sizes))
-    return {"value": cells / sec, "unit": "trace cells/s", "cores": cores, "kind": "port",
-            "sample": f"collatz.bf input '7\\n' ({steps} VM steps, {cells} cells, LOG_MAX_ROWS={max(log_sizes)}), one proof, {sec:.1f} s, OpenMP over {cores} threads"}
+    # the port's OpenMP loops stop scaling at a few dozen threads: try a few team sizes and report the best one
+    best_sec, best_threads, tried = None, 1, []
+    for threads in sorted({min(avail, t) for t in (16, 32, 64)}):
+        orc.L.orc_set_threads(threads)
+        _, _, sec = orc.prove(code, b"7\n", log_max_rows=max(log_sizes))
+        tried.append(f"{threads}t {sec:.1f}s")
+        if best_sec is None or sec < best_sec:
+            best_sec, best_threads = sec, threads
+    return {"value": cells / best_sec, "unit": "trace cells/s", "cores": best_threads, "kind": "port",
+            "sample": f"collatz.bf input '7\\n' ({steps} VM steps, {cells} cells, LOG_MAX_ROWS={max(log_sizes)}), one proof per OpenMP team size "
+                      f"({', '.join(tried)}), best reported"}
 
 
 def main():
