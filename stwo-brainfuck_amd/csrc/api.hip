@@ -25,6 +25,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
     device = dev;
     BF_HIP(hipSetDevice(dev));
     BF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    for (auto& e : ev) BF_HIP(hipEventCreate(&e));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
     BF_HIP(hipHostMalloc((void**)&h_small, 4096));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
@@ -50,10 +52,13 @@ void Ctx::init(int dev, u32 max_log_domain) {
 
 void Ctx::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
+    if (stream2) (void)hipStreamSynchronize(stream2);
     arena.release();
     (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_small) (void)hipHostFree(h_small);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -34,6 +34,9 @@ struct Arena {
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase
+    bool side_busy = false;         // work enqueued on stream2 may still read parameter blocks from the staging ring
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
     u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
     u32* d_tw = nullptr; u32* d_itw = nullptr;
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
@@ -61,7 +64,9 @@ struct Ctx {
     }
     // Called at the start of every high-level operation: recycles the staging ring once it is half full (after a sync, so no
     // in-flight kernel still reads parameter blocks from it).
-    void stage_checkpoint() { if (stage_used > stage_bytes / 2) { sync(); stage_used = 0; } }
+    void stage_checkpoint() {
+        if (stage_used > stage_bytes / 2) { sync(); if (side_busy) BF_HIP(hipStreamSynchronize(stream2)); stage_used = 0; }
+    }
     u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
 };
 

@@ -276,57 +276,82 @@ struct HipProver {
         BrainfuckProof bp;
 
         // ---- Phase 0: preprocessed IsFirst(LOG_MAX_ROWS ..= LOG_N_LANES) (mod.rs:495-500) ---------------------------------
+        // Trace independent, and nothing on the GPU depends on its root: it is enqueued on the side stream and runs beside the
+        // caller's trace preparation (get_input) and the main-trace phase; both roots are read after ONE synchronisation and mixed
+        // in protocol order (root0, claim, root1).
         double t0 = now();
         PreprocessedCache& cache = preprocessed_cache_of(&c);
         Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
+        Hash32* pinned_root1 = pinned_root0 + 1;
         const bool reuse = cache.enabled && cache.valid && cache.lmr == log_max_rows;
+        BF_HIP(hipEventRecord(c.ev[0], c.stream));
         if (reuse) trees[0] = cache.tree;
         else {
-            if (cache.enabled) { cache.keep.reset(); std::swap(c.arena, cache.keep); }   // build the tree in memory that survives arena.reset()
-            for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
-                DCol p; p.log_size = log; p.shift = 0; p.ptr = c.alloc_u32(p.stored());
-                one_hot(c.stream, p.ptr, 1u << log);
-                trees[0].polys.push_back(p);
-            }
-            fft_cols(true, trees[0].polys, trees[0].polys);
-            commit_tree(trees[0], pinned_root0);
-            if (cache.enabled) std::swap(c.arena, cache.keep);
+            BF_HIP(hipStreamWaitEvent(c.stream2, c.ev[0], 0));       // stream2 starts after whatever preceded this proof on the main stream
+            std::swap(c.stream, c.stream2); c.side_busy = true;
+            try {
+                if (cache.enabled) { cache.keep.reset(); std::swap(c.arena, cache.keep); }   // build the tree in memory that survives arena.reset()
+                for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
+                    DCol p; p.log_size = log; p.shift = 0; p.ptr = c.alloc_u32(p.stored());
+                    one_hot(c.stream, p.ptr, 1u << log);
+                    trees[0].polys.push_back(p);
+                }
+                fft_cols(true, trees[0].polys, trees[0].polys);
+                commit_tree(trees[0], pinned_root0);
+                if (cache.enabled) std::swap(c.arena, cache.keep);
+                BF_HIP(hipEventRecord(c.ev[1], c.stream));
+            } catch (...) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; throw; }
+            std::swap(c.stream, c.stream2);
         }
-        const TraceInput& in = get_input();
-        c.sync();
-        if (!reuse) {
-            trees[0].mk.root = *pinned_root0;
-            if (cache.enabled) { cache.tree = trees[0]; cache.lmr = log_max_rows; cache.valid = true; }
-        }
-        ch.mix_root(trees[0].mk.root);
-        tap("root0");
-        tm.preprocessed = now() - t0;
+        auto join_side = [&]() { if (c.side_busy) { (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } };
+        const TraceInput* in_p = nullptr;
+        try { in_p = &get_input(); } catch (...) { join_side(); throw; }
+        const TraceInput& in = *in_p;
 
         // ---- Phase 1: main trace (mod.rs:506-583) -----------------------------------------------------------------------------
-        t0 = now();
         const std::vector<std::vector<DCol>>& rows = in.rows;   // row-granular table columns (also feed the logUp pass)
         size_t main_off[N_COMPONENTS], inter_off[N_COMPONENTS];
         {
             size_t mo = 0, io = 0;
             for (int k = 0; k < N_COMPONENTS; k++) { main_off[k] = mo; inter_off[k] = io; mo += n_main_cols(k); io += 4 * n_logup_cols(k); }
         }
-        for (int k = 0; k < N_COMPONENTS; k++) {
-            bp.log_sizes[k] = in.log_sizes[k];
-            if (bp.log_sizes[k] > log_max_rows) throw HipError("a component exceeds LOG_MAX_ROWS");
-            for (u32 j = 0; j < n_main_cols(k); j++) {
-                DCol p = rows[k][j]; p.ptr = c.alloc_u32(p.stored());
-                trees[1].polys.push_back(p);
+        try {
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                bp.log_sizes[k] = in.log_sizes[k];
+                if (bp.log_sizes[k] > log_max_rows) throw HipError("a component exceeds LOG_MAX_ROWS");
+                for (u32 j = 0; j < n_main_cols(k); j++) {
+                    DCol p = rows[k][j]; p.ptr = c.alloc_u32(p.stored());
+                    trees[1].polys.push_back(p);
+                }
             }
+            {
+                std::vector<DCol> src;
+                for (int k = 0; k < N_COMPONENTS; k++) for (auto& r : rows[k]) src.push_back(r);
+                fft_cols(true, src, trees[1].polys);
+            }
+            commit_tree(trees[1], pinned_root1);
+            BF_HIP(hipEventRecord(c.ev[2], c.stream));
+            c.sync();
+        } catch (...) { join_side(); throw; }
+        join_side();
+        if (!reuse) {
+            trees[0].mk.root = *pinned_root0;
+            if (cache.enabled) { cache.tree = trees[0]; cache.lmr = log_max_rows; cache.valid = true; }
         }
-        {
-            std::vector<DCol> src;
-            for (int k = 0; k < N_COMPONENTS; k++) for (auto& r : rows[k]) src.push_back(r);
-            fft_cols(true, src, trees[1].polys);
-        }
+        trees[1].mk.root = *pinned_root1;
+        ch.mix_root(trees[0].mk.root);
+        tap("root0");
         for (int k = 0; k < N_COMPONENTS; k++) ch.mix_u64(bp.log_sizes[k]);   // claim.mix_into (mod.rs:102-116)
-        commit_tree(trees[1]);
+        ch.mix_root(trees[1].mk.root);
         tap("root1");
-        tm.main_trace = now() - t0;
+        {   // GPU-side durations of the two overlapped phases; the host wall time of the pair is split in that proportion
+            float ms0 = 0.f, ms1 = 0.f;
+            if (!reuse) BF_HIP(hipEventElapsedTime(&ms0, c.ev[0], c.ev[1]));
+            BF_HIP(hipEventElapsedTime(&ms1, c.ev[0], c.ev[2]));
+            double wall = now() - t0, tot = (double)ms0 + (double)ms1;
+            tm.preprocessed = tot > 0 ? wall * ms0 / tot : 0.0;
+            tm.main_trace = wall - tm.preprocessed;
+        }
 
         // ---- Phase 2: interaction trace (mod.rs:589-723) ------------------------------------------------------------------------
         t0 = now();
