@@ -57,8 +57,8 @@ def test_collatz_matches_oracle(ctx, pkg, oracle):
 
 
 def test_fib19_full_size_proof_verifies(pkg, oracle):
-    """BASELINE config 2 at full size (LOG_MAX_ROWS = 24, 2^24-row memory component): too big for the CPU prover in a test, so the
-    size-independent property is used: the oracle's verifier accepts the HIP proof, and rejects it after a one-word change."""
+    """BASELINE config 2 at full size (LOG_MAX_ROWS = 24, 2^24-row memory component): the oracle's verifier accepts the HIP proof and
+    rejects it after a one-word change, and the proof bytes hash to the committed digest of the oracle's own proof of this workload."""
     c = pkg.Context(0, max_log_domain=26)
     try:
         tr = pkg.Trace(c, _prog("fib19.bf"))
@@ -71,6 +71,11 @@ def test_fib19_full_size_proof_verifies(pkg, oracle):
         assert not oracle.verify(bad, 24)[0]
         proof2, _ = tr.prove(24)
         assert proof2 == proof        # deterministic
+        # byte parity at full size: the oracle's own proof of this workload, as a committed digest (it needs minutes of CPU time;
+        # tests/golden/make_fib19_proof_digest.py)
+        import hashlib, json
+        want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))
+        assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["sha256"]
         tr.close()
     finally:
         c.close()
