@@ -44,9 +44,9 @@ def _simulate(code, inp, max_steps):
     return steps
 
 
-def _body(rng, depth):
+def _body(rng, depth, scale=1):
     out = []
-    for _ in range(rng.randint(1, 6)):
+    for _ in range(rng.randint(1, 6 * scale)):
         r = rng.random()
         if r < 0.18 and depth < 2:
             k = rng.randint(1, 2)
@@ -59,12 +59,13 @@ def _body(rng, depth):
     return "".join(out)
 
 
-def random_program(seed, max_steps=400):
-    """Deterministic in `seed`: (code, input bytes, executed steps)."""
+def random_program(seed, max_steps=400, min_steps=1):
+    """Deterministic in (seed, max_steps, min_steps): (code, input bytes, executed steps), min_steps <= steps <= max_steps."""
     rng = random.Random(seed)
+    scale = 1 if max_steps <= 1000 else 3
     while True:
-        code = "+" * rng.randint(0, 4) + _body(rng, 0) + rng.choice(["", ".", "+.", ">+"])
+        code = "+" * rng.randint(0, 4 * scale) + _body(rng, 0, scale) + rng.choice(["", ".", "+.", ">+"])
         inp = bytes(rng.randrange(256) for _ in range(code.count(",") * 8))
         steps = _simulate(code, inp, max_steps)
-        if steps is not None and steps >= 1:
+        if steps is not None and steps >= min_steps:
             return code, inp[: max(1, len(inp))], steps

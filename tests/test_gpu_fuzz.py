@@ -6,12 +6,12 @@ from bf_fuzz import random_program
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = list(range(100, 124))
+SEEDS = [(s, 400) for s in range(100, 164)] + [(s, 6000) for s in range(200, 216)]   # (seed, step bound)
 
 
-@pytest.mark.parametrize("seed", SEEDS)
-def test_random_program_proof_matches_oracle(ctx, pkg, oracle, seed):
-    code, inp, _ = random_program(seed)
+@pytest.mark.parametrize("seed,max_steps", SEEDS)
+def test_random_program_proof_matches_oracle(ctx, pkg, oracle, seed, max_steps):
+    code, inp, _ = random_program(seed, max_steps, min_steps=max_steps // 20)
     log_max_rows = max(max(oracle.log_sizes(code, inp)[0]), 8)
     want, otr, _ = oracle.prove(code, inp, log_max_rows=log_max_rows)
     got, tr = pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows, with_transcript=True)
