@@ -56,6 +56,31 @@ def test_collatz_matches_oracle(ctx, pkg, oracle):
     assert got == want
 
 
+def _integration_programs():
+    import json
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    return [(e["program"], bytes(e["input"]), bytes(e["expected"])) for e in v["vm_outputs"] if e["program"] != "fib19.bf"]
+
+
+@pytest.mark.parametrize("name,inp,expected", _integration_programs(), ids=[p[0] for p in _integration_programs()])
+def test_integration_programs_match_oracle(pkg, oracle, name, inp, expected):
+    """Every program of the reference's VM integration tests (crates/brainfuck_vm/tests/integration.rs:12-104; fib19 is covered at
+    full size below): the VM output is the pinned one and the device-resident proof equals the oracle's, at the smallest LOG_MAX_ROWS
+    that fits the trace."""
+    code = _prog(name)
+    out, _ = oracle.run(code, inp)
+    assert out == expected
+    lmr = max(oracle.log_sizes(code, inp)[0])
+    c = pkg.Context(0, max_log_domain=lmr + 2)
+    try:
+        got = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
+    finally:
+        c.close()
+    want, _, _ = oracle.prove(code, inp, log_max_rows=lmr)
+    assert got == want
+    assert pkg.verify_brainfuck(got, lmr) == (True, "")
+
+
 def test_fib19_full_size_proof_verifies(pkg, oracle):
     """BASELINE config 2 at full size (LOG_MAX_ROWS = 24, 2^24-row memory component): the oracle's verifier accepts the HIP proof and
     rejects it after a one-word change, and the proof bytes hash to the committed digest of the oracle's own proof of this workload."""
