@@ -44,14 +44,22 @@ __device__ __forceinline__ void blake2s_compress(u32 h[8], const u32 m[16], u32 
     h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
+// Column pointers come out of a descriptor in memory, so the compiler only knows them as generic pointers and would emit FLAT loads
+// with 64-bit VGPR addresses; they are HBM pointers, so say so (address space 1 = global): global_load with a uniform SGPR base and
+// a 32-bit VGPR byte offset (columns hold < 2^30 cells).
+typedef const __attribute__((address_space(1))) char* global_bytes_t;
+typedef const __attribute__((address_space(1))) u32* global_u32_t;
+__device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
+    const u32 byte_off = (i >> d.shift) << 2;
+    return *(global_u32_t)((global_bytes_t)(unsigned long long)d.ptr + byte_off);
+}
+
 // One Merkle layer of 2^log nodes. prev == nullptr for the deepest layer. Requires has_prev || ncols > 0 ... or hashes the empty string.
 // Replication-aware: when every input of a layer is replicated (row-granular columns and/or a replicated child layer), nodes
 // i and i' with i >> out_shift == i' >> out_shift hash identical messages, so only 2^(log - out_shift) nodes are computed and
 // stored; readers index `node >> shift`. Hash values are exactly those of the full layer.
-__global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
-                                                      u32 out_shift, u32 prev_shift) {
-    u32 st = blockIdx.x * blockDim.x + threadIdx.x;
-    if (st >= n_stored) return;
+__device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
+                                            u32 out_shift, u32 prev_shift) {
     const u32 i = st << out_shift;          // representative node of this stored slot
     u32 h[8];
 #pragma unroll
@@ -74,11 +82,18 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
     // remaining message: column values, 16 words per block (zero padded)
     for (;;) {
 #pragma unroll
-        for (int w = 0; w < 16; w++) {
-            u32 c = c0 + w;
-            u32 v = 0;
-            if (c < ncols) { ColDesc cd = cols[c]; v = cd.ptr[i >> cd.shift]; }
-            m[w] = v;
+        for (int g = 0; g < 4; g++) {
+            // columns are absorbed 4 at a time: one uniform branch, four descriptor loads and four value loads issued back to back
+            // (a branch + scalar-load round trip per column serialises the latency); a partial group re-reads its last column
+            const u32 cb = c0 + 4 * g;
+            if (cb < ncols) {
+                const u32 lastc = ncols - 1;
+                const ColDesc d0 = cols[cb], d1 = cols[min(cb + 1, lastc)], d2 = cols[min(cb + 2, lastc)], d3 = cols[min(cb + 3, lastc)];
+                // 32-bit byte offsets (columns hold < 2^30 cells) on a uniform base pointer: SGPR-base + VGPR-offset addressing, no
+                // 64-bit VALU address arithmetic per column
+                const u32 v0 = ld_col(d0, i), v1 = ld_col(d1, i), v2 = ld_col(d2, i), v3 = ld_col(d3, i);
+                m[4 * g] = v0; m[4 * g + 1] = cb + 1 < ncols ? v1 : 0u; m[4 * g + 2] = cb + 2 < ncols ? v2 : 0u; m[4 * g + 3] = cb + 3 < ncols ? v3 : 0u;
+            } else { m[4 * g] = 0; m[4 * g + 1] = 0; m[4 * g + 2] = 0; m[4 * g + 3] = 0; }
         }
         u32 take = min(64u, total_bytes - done);
         done += take; c0 += 16;
@@ -88,6 +103,11 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
     }
     out[2 * (size_t)st] = make_uint4(h[0], h[1], h[2], h[3]);
     out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+}
+// Grid-stride over the stored nodes: large layers give every lane several nodes, which amortises wave launch and the kernel prologue.
+__global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
+                                                      u32 out_shift, u32 prev_shift) {
+    for (u32 st = blockIdx.x * blockDim.x + threadIdx.x; st < n_stored; st += gridDim.x * blockDim.x) merkle_node(st, out, prev, cols, ncols, out_shift, prev_shift);
 }
 
 // Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
@@ -111,12 +131,17 @@ __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ l
     }
 }
 
+#ifndef MERKLE_NODES_PER_LANE
+#define MERKLE_NODES_PER_LANE 4
+#endif
 // col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift) {
     u32 n = (1u << log) >> out_shift;
     u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
     ProfScope ps(stream, "k_merkle_layer", (prev ? 64.0 * n : 0.0) + 32.0 * n + col_bytes);
-    hipLaunchKernelGGL(k_merkle_layer, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift);
+    u32 blocks = (n + threads - 1) / threads;
+    if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
+    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift);
 }
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
     ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));
