@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libbfhip.so")
+_LIB_PATH = os.environ.get("BFHIP_LIBRARY") or os.path.join(_HERE, "libbfhip.so")   # BFHIP_LIBRARY: A/B runs of another build
 _lib = None
 
 P = (1 << 31) - 1

@@ -24,12 +24,11 @@ struct DomainEval : LogupState<DomainEval, Fm> {
     typedef Fm F;
     const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0; Q31 res;
     __device__ DomainEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { res = q_zero(); total_sum = a_.total_sum; }
-    __device__ __forceinline__ Fm is_first() { return {a.is_first[row]}; }
-    __device__ __forceinline__ Fm trace() { ColDesc c = a.trace[ti++]; return {c.ptr[row >> c.shift]}; }
+    __device__ __forceinline__ Fm is_first() { return {as_global(a.is_first)[row]}; }
+    __device__ __forceinline__ Fm trace() { return {ld_col(a.trace[ti++], row)}; }
     __device__ __forceinline__ Fm cst(u32 k) { return {k}; }
     __device__ __forceinline__ Q31 rd(int i0, u32 r) {
-        return q_make(a.inter[i0].ptr[r >> a.inter[i0].shift], a.inter[i0 + 1].ptr[r >> a.inter[i0 + 1].shift],
-                      a.inter[i0 + 2].ptr[r >> a.inter[i0 + 2].shift], a.inter[i0 + 3].ptr[r >> a.inter[i0 + 3].shift]);
+        return q_make(ld_col(a.inter[i0], r), ld_col(a.inter[i0 + 1], r), ld_col(a.inter[i0 + 2], r), ld_col(a.inter[i0 + 3], r));
     }
     __device__ __forceinline__ Fq inter_cur() { Fq v{rd(ii, row)}; ii += 4; return v; }
     __device__ __forceinline__ void inter_cur_prev(Fq& cur, Fq& prev) {
@@ -53,10 +52,11 @@ __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __res
     DomainEval e(a, row);
     air_eval<COMP>(e, a.el);
     Q31 r = q_mulm(e.res, a.denom_inv[row >> a.log_size]);
-    a.acc[0][row] = m_add(a.acc[0][row], r.a.a);
-    a.acc[1][row] = m_add(a.acc[1][row], r.a.b);
-    a.acc[2][row] = m_add(a.acc[2][row], r.b.a);
-    a.acc[3][row] = m_add(a.acc[3][row], r.b.b);
+    g_u32p acc0 = as_global(a.acc[0]), acc1 = as_global(a.acc[1]), acc2 = as_global(a.acc[2]), acc3 = as_global(a.acc[3]);
+    acc0[row] = m_add(acc0[row], r.a.a);
+    acc1[row] = m_add(acc1[row], r.a.b);
+    acc2[row] = m_add(acc2[row], r.b.a);
+    acc3[row] = m_add(acc3[row], r.b.b);
 }
 
 template <int COMP>

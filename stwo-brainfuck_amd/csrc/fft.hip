@@ -124,13 +124,13 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
     const u32 col0 = blockIdx.y * a.cols_per_block;
     const u32 col1 = min(a.ncols, col0 + a.cols_per_block);
     for (u32 col = col0; col < col1; col++) {
-        const u32* src = a.src[col];
-        u32* dst = a.dst[col];
+        g_cu32p src = as_global(a.src[col]);
+        g_u32p dst = as_global(a.dst[col]);
         __syncthreads();  // s_tw ready / previous column's stores done reading s_val
         // ---- load tile (16 B per lane) -----------------------------------------------------------------------------
         for (u32 e4 = t * 4; e4 < tile_n; e4 += 4 * FFT_THREADS) {
             u32 gidx = lo ? (base | ((e4 >> c) << lo) | (e4 & ((1u << c) - 1))) : (base + e4);
-            uint4 v = *reinterpret_cast<const uint4*>(src + (gidx & a.src_mask));
+            uint4 v = ld16(src + (gidx & a.src_mask));
             *reinterpret_cast<uint4*>(&s_val[e4]) = v;
         }
         __syncthreads();
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
             u32 gidx = lo ? (base | ((e4 >> c) << lo) | (e4 & ((1u << c) - 1))) : (base + e4);
             uint4 v = *reinterpret_cast<uint4*>(&s_val[e4]);
             if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
-            *reinterpret_cast<uint4*>(dst + gidx) = v;
+            st16(dst + gidx, v);
         }
     }
 }
@@ -223,13 +223,13 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[4096u - (4096u >> layer) + idx]; };
     const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     for (u32 col = col0; col < col1; col++) {
-        const u32* src = a.src[col];
-        u32* dst = a.dst[col];
+        g_cu32p src = as_global(a.src[col]);
+        g_u32p dst = as_global(a.dst[col]);
         __syncthreads();
         u32 r[4][4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint4 v = *reinterpret_cast<const uint4*>(src + ((base + 1024 * q + 4 * t) & a.src_mask));
+            uint4 v = ld16(src + ((base + 1024 * q + 4 * t) & a.src_mask));
             r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
         }
         // ---- register stage on the 16-byte groups: layers 0,1 (cells 4t..4t+3 of each quarter q) and 10,11 (across q) --------
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
         for (int q = 0; q < 4; q++) {
             uint4 v = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
             if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
-            *reinterpret_cast<uint4*>(dst + base + 1024 * q + 4 * t) = v;
+            st16(dst + base + 1024 * q + 4 * t, v);
         }
     }
 }
@@ -320,8 +320,8 @@ __global__ void __launch_bounds__(128, 4) k_fft_strided7(PassArgs a) {
     const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     const u32 l4 = 4 * (t & 7), r4 = t >> 3;      // 16-byte phase: rows m = 8*r4 + q (q = 0..7), cells l4..l4+3
     for (u32 col = col0; col < col1; col++) {
-        const u32* src = a.src[col];
-        u32* dst = a.dst[col];
+        g_cu32p src = as_global(a.src[col]);
+        g_u32p dst = as_global(a.dst[col]);
         __syncthreads();
         auto wide_stage = [&](u32 (&r)[8][4]) {   // layers 0..2 over q
 #pragma unroll
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(128, 4) k_fft_strided7(PassArgs a) {
         if (INV) {
             u32 r[8][4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<const uint4*>(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+            for (int q = 0; q < 8; q++) { uint4 v = ld16(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
             wide_stage(r);
 #pragma unroll
             for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(128, 4) k_fft_strided7(PassArgs a) {
             for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
             wide_stage(r);
 #pragma unroll
-            for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(dst + (base | ((8 * r4 + q) << lo) | l4)) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+            for (int q = 0; q < 8; q++) st16(dst + (base | ((8 * r4 + q) << lo) | l4), make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]));
         }
     }
 }

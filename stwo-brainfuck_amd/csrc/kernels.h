@@ -29,6 +29,27 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(s); }
 };
 
+// ---- global address space --------------------------------------------------------------------------------------------------------
+// A pointer read out of a descriptor / pointer array in HBM is only known to the compiler as a generic pointer, for which it emits
+// FLAT loads and stores: 64-bit VGPR addressing, and they count on lgkmcnt as well as vmcnt, so every wait for an LDS operation
+// also waits for the outstanding column traffic. All such pointers are HBM pointers; casting them to address space 1 gives
+// global_load / global_store (SGPR base + 32-bit VGPR offset where the base is uniform).
+#if defined(__HIPCC__)
+#define BF_GLOBAL __attribute__((address_space(1)))
+typedef u32 bf_u32x4 __attribute__((ext_vector_type(4)));
+typedef BF_GLOBAL u32* g_u32p;
+typedef const BF_GLOBAL u32* g_cu32p;
+__device__ __forceinline__ g_cu32p as_global(const u32* p) { return (g_cu32p)(unsigned long long)p; }
+__device__ __forceinline__ g_u32p as_global(u32* p) { return (g_u32p)(unsigned long long)p; }
+__device__ __forceinline__ uint4 ld16(g_cu32p p) { bf_u32x4 v = *(const BF_GLOBAL bf_u32x4*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void st16(g_u32p p, uint4 v) { bf_u32x4 w = {v.x, v.y, v.z, v.w}; *(BF_GLOBAL bf_u32x4*)p = w; }
+// value of cell i of a column: 32-bit byte offset (columns hold < 2^30 cells) on the descriptor's base pointer
+__device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
+    const u32 byte_off = (i >> d.shift) << 2;
+    return *(g_cu32p)((const BF_GLOBAL char*)(unsigned long long)d.ptr + byte_off);
+}
+#endif
+
 // fft.hip
 void gen_twiddles(hipStream_t stream, u32* d_tw, u32* d_itw, u32 R, const uint2* d_tlo, const uint2* d_thi);
 // Batched transform of `ncols` columns of 2^log cells. inverse: evaluations (bit-reversed) -> coefficients, scaled by 2^-log.

@@ -44,16 +44,6 @@ __device__ __forceinline__ void blake2s_compress(u32 h[8], const u32 m[16], u32 
     h[4] ^= v4 ^ v12; h[5] ^= v5 ^ v13; h[6] ^= v6 ^ v14; h[7] ^= v7 ^ v15;
 }
 
-// Column pointers come out of a descriptor in memory, so the compiler only knows them as generic pointers and would emit FLAT loads
-// with 64-bit VGPR addresses; they are HBM pointers, so say so (address space 1 = global): global_load with a uniform SGPR base and
-// a 32-bit VGPR byte offset (columns hold < 2^30 cells).
-typedef const __attribute__((address_space(1))) char* global_bytes_t;
-typedef const __attribute__((address_space(1))) u32* global_u32_t;
-__device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
-    const u32 byte_off = (i >> d.shift) << 2;
-    return *(global_u32_t)((global_bytes_t)(unsigned long long)d.ptr + byte_off);
-}
-
 // One Merkle layer of 2^log nodes. prev == nullptr for the deepest layer. Requires has_prev || ncols > 0 ... or hashes the empty string.
 // Replication-aware: when every input of a layer is replicated (row-granular columns and/or a replicated child layer), nodes
 // i and i' with i >> out_shift == i' >> out_shift hash identical messages, so only 2^(log - out_shift) nodes are computed and

@@ -149,11 +149,11 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
             const QuotientEntry qe = a.entries[e];
             ColDesc cd = a.cols[qe.col];
             if (cd.shift == 0) {
-                uint4 v = *reinterpret_cast<const uint4*>(cd.ptr + row0);
+                uint4 v = ld16(as_global(cd.ptr) + row0);
                 num[0] = q_add(num[0], q_mulm(qe.c, v.x)); num[1] = q_add(num[1], q_mulm(qe.c, v.y));
                 num[2] = q_add(num[2], q_mulm(qe.c, v.z)); num[3] = q_add(num[3], q_mulm(qe.c, v.w));
             } else {
-                Q31 t = q_mulm(qe.c, cd.ptr[row0 >> cd.shift]);    // shift >= 2: the 4 rows share one stored cell
+                Q31 t = q_mulm(qe.c, ld_col(cd, row0));    // shift >= 2: the 4 rows share one stored cell
 #pragma unroll
                 for (int r = 0; r < 4; r++) num[r] = q_add(num[r], t);
             }
