@@ -28,7 +28,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
-    BF_HIP(hipHostMalloc((void**)&h_small, 4096));
+    BF_HIP(hipHostMalloc((void**)&h_small, h_small_bytes));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
     // point tables: G^a and G^(b << 16) for the M31 circle generator G = (2, 1268011823)
     std::vector<uint2> tlo(1 << 16), thi(1 << 15);

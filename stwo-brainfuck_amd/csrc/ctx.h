@@ -42,7 +42,10 @@ struct Ctx {
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
     Arena arena;
     // pinned staging for pointer arrays / small parameter blocks
-    char* h_small = nullptr;   // 4 KiB pinned scratch for deferred tiny device->host results
+    // Pinned scratch for device->host results. [0, 4096): fixed slots for deferred tiny results (tree roots, FRI roots, channel
+    // state); [4096, h_small_bytes): bounce buffer of read_back(). A pageable destination would make every such copy a blocking,
+    // internally staged transfer.
+    char* h_small = nullptr; size_t h_small_bytes = 256 << 10;
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
 
     void init(int dev, u32 max_log_domain);
@@ -68,6 +71,16 @@ struct Ctx {
         if (stage_used > stage_bytes / 2) { sync(); if (side_busy) BF_HIP(hipStreamSynchronize(stream2)); stage_used = 0; }
     }
     u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
+    // Stream-ordered device -> host read of a small result through the pinned bounce buffer; returns after the data has arrived.
+    void read_back(void* dst_h, const void* src_d, size_t bytes) {
+        const size_t cap = h_small_bytes - 4096;
+        for (size_t o = 0; o < bytes; o += cap) {
+            size_t n = bytes - o < cap ? bytes - o : cap;
+            BF_HIP(hipMemcpyAsync(h_small + 4096, (const char*)src_d + o, n, hipMemcpyDeviceToHost, stream));
+            sync();
+            memcpy((char*)dst_h + o, h_small + 4096, n);
+        }
+    }
 };
 
 }  // namespace bf

@@ -46,8 +46,7 @@ struct Gather {
             GatherReq* d = c.stage(reqs.data() + o, n);
             u32* dout = c.alloc_u32(n);
             gather_u32(c.stream, d, (u32)n, dout);
-            BF_HIP(hipMemcpyAsync(out.data() + o, dout, n * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
-            c.sync();
+            c.read_back(out.data() + o, dout, n * sizeof(u32));
         }
         return out;
     }
@@ -155,8 +154,7 @@ struct HipProver {
         }
         BF_HIP(hipGetLastError());
         if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
-        BF_HIP(hipMemcpyAsync(mk.root.b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream));
-        c.sync();
+        c.read_back(mk.root.b, mk.layers[0], 32);
         return mk;
     }
 
@@ -386,8 +384,7 @@ struct HipProver {
         BF_HIP(hipGetLastError());
         {
             uint4 h_claimed[N_COMPONENTS];
-            BF_HIP(hipMemcpyAsync(h_claimed, d_claimed, sizeof(h_claimed), hipMemcpyDeviceToHost, c.stream));
-            c.sync();
+            c.read_back(h_claimed, d_claimed, sizeof(h_claimed));
             for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
         }
         trees[2].polys = inter_vals;          // interpolate in place
@@ -530,17 +527,15 @@ struct HipProver {
                     partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
                     jobs.push_back(j);
                 }
-        uint4* d_factors = (uint4*)c.arena.alloc(factors.size() * sizeof(uint4));
-        BF_HIP(hipMemcpyAsync(d_factors, factors.data(), factors.size() * sizeof(uint4), hipMemcpyHostToDevice, c.stream));
-        EvalJob* d_jobs = (EvalJob*)c.arena.alloc(jobs.size() * sizeof(EvalJob));
-        BF_HIP(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(EvalJob), hipMemcpyHostToDevice, c.stream));
+        c.stage_checkpoint();
+        const uint4* d_factors = c.stage(factors.data(), factors.size());     // through the pinned staging ring (no pageable copies)
+        const EvalJob* d_jobs = c.stage(jobs.data(), jobs.size());
         void* d_partials = c.arena.alloc(size_t(partial_off) * sizeof(uint4));
         uint4* d_out = (uint4*)c.arena.alloc(jobs.size() * sizeof(uint4));
         eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
         BF_HIP(hipGetLastError());
         std::vector<uint4> out(jobs.size());
-        BF_HIP(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(uint4), hipMemcpyDeviceToHost, c.stream));
-        c.sync();
+        c.read_back(out.data(), d_out, out.size() * sizeof(uint4));
         pf.sampled_values.resize(trees.size());
         size_t ji = 0;
         for (size_t t = 0; t < trees.size(); t++) {
@@ -703,8 +698,7 @@ struct HipProver {
             const u32 span = 1u << 16;
             for (u64 base = 0; best == ~0ull; base += span) {
                 grind_span(c.stream, d_digest, base, span, cfg.pow_bits, d_best);
-                BF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c.stream));
-                c.sync();
+                c.read_back(&best, d_best, 8);
             }
             pf.proof_of_work = best;
             ch.mix_u64(best);
