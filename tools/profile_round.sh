@@ -1,0 +1,31 @@
+#!/bin/bash
+# Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repository root):
+#   gpurun -- 'bash tools/profile_round.sh r01'
+# Writes into gpurun_out/<round>/ ; copy what should be judged into profiles/.
+set -u
+R=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$R
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+# 1. headline bench line (roofline measured live with HIP events, CPU baseline on the host cores)
+python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; tail -1 "$OUT/bench.log" > "$OUT/${R}_bench.json"
+# 2. same command under rocprofv3 --kernel-trace --stats (per-kernel average durations must agree with the roofline object)
+rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+tail -1 "$OUT/bench_under_rocprof.log" > "$OUT/${R}_bench_under_rocprof.json"
+cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
+python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_stats/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
+# 3. HBM traffic counters, one pass each, kernel trace only
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_$C.log" 2>&1
+done
+python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/pmc_traffic.json"
+# 4. FFT kernel run (BASELINE config 3 (i)), Merkle shapes, one-call end-to-end, large synthetic trace
+python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
+python3 "$ROOT/tools/merkle_shapes.py" > "$OUT/${R}_merkle_shapes.txt" 2>&1
+python3 "$ROOT/tools/trace_time.py" > "$OUT/${R}_one_call.txt" 2>&1
+python3 "$ROOT/tools/big_trace.py" > "$OUT/${R}_big_trace.json" 2> "$OUT/big_trace.err"
+for n in 2 3; do python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --inflight $n 2>/dev/null | tail -1 > "$OUT/${R}_bench_inflight$n.json"; done
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events 2>/dev/null | tail -1 > "$OUT/${R}_bench_no_events.json"
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --reuse-preprocessed 2>/dev/null | tail -1 > "$OUT/${R}_bench_reuse_preprocessed.json"
+ls -la "$OUT"
