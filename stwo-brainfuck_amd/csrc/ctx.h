@@ -54,13 +54,21 @@ struct Ctx {
     // allocations (arena chunks, hipMalloc) land on the device the stream belongs to whichever thread drives the context.
     void bind() { BF_HIP(hipSetDevice(device)); }
     void sync() { BF_HIP(hipStreamSynchronize(stream)); }
-    // Copy a small host block to device scratch (valid until the next stage_reset()). Stream-ordered.
+    // Copy a small host block to device scratch (valid until the ring is recycled by stage_checkpoint()). Stream-ordered.
+    // Between stage_begin() and stage_end() the blocks are only written to the pinned ring and ONE copy moves them all at
+    // stage_end(): every separate copy is a ~5 us blit on the GPU timeline, and a proof stages ~150 blocks.
+    int stage_batch_depth = 0; size_t stage_batch_lo = 0;
+    void stage_begin() { if (stage_batch_depth++ == 0) stage_batch_lo = stage_used; }
+    void stage_end() {
+        if (--stage_batch_depth == 0 && stage_used > stage_batch_lo)
+            BF_HIP(hipMemcpyAsync(d_stage + stage_batch_lo, h_stage + stage_batch_lo, stage_used - stage_batch_lo, hipMemcpyHostToDevice, stream));
+    }
     template <class T>
     T* stage(const T* host, size_t n) {
         size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
         if (stage_used + bytes > stage_bytes) throw HipError("staging buffer exhausted (call stage_checkpoint() between operations)");
         memcpy(h_stage + stage_used, host, n * sizeof(T));
-        BF_HIP(hipMemcpyAsync(d_stage + stage_used, h_stage + stage_used, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        if (stage_batch_depth == 0) BF_HIP(hipMemcpyAsync(d_stage + stage_used, h_stage + stage_used, n * sizeof(T), hipMemcpyHostToDevice, stream));
         T* r = reinterpret_cast<T*>(d_stage + stage_used);
         stage_used += bytes;
         return r;
@@ -68,7 +76,7 @@ struct Ctx {
     // Called at the start of every high-level operation: recycles the staging ring once it is half full (after a sync, so no
     // in-flight kernel still reads parameter blocks from it).
     void stage_checkpoint() {
-        if (stage_used > stage_bytes / 2) { sync(); if (side_busy) BF_HIP(hipStreamSynchronize(stream2)); stage_used = 0; }
+        if (stage_batch_depth == 0 && stage_used > stage_bytes / 2) { sync(); if (side_busy) BF_HIP(hipStreamSynchronize(stream2)); stage_used = 0; }
     }
     u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
     // Stream-ordered device -> host read of a small result through the pinned bounce buffer; returns after the data has arrived.
@@ -81,6 +89,14 @@ struct Ctx {
             memcpy((char*)dst_h + o, h_small + 4096, n);
         }
     }
+};
+
+// Scope of one staging batch: blocks staged inside are moved by one copy at end(); an exception unwinds the batch without copying.
+struct StageBatch {
+    Ctx& c; bool open = true;
+    explicit StageBatch(Ctx& c_) : c(c_) { c.stage_begin(); }
+    void end() { if (open) { open = false; c.stage_end(); } }
+    ~StageBatch() { if (open) { if (--c.stage_batch_depth < 0) c.stage_batch_depth = 0; } }
 };
 
 }  // namespace bf

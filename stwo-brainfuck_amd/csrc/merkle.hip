@@ -140,12 +140,13 @@ void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
 
 // Blake2sChannel stepped on the device for the FRI commit phase (FriProver::commit: mix_root(layer root) then draw_felt per layer):
 // removes the device -> host -> device round trip between consecutive layers. One lane; two compressions plus rare redraws.
-// chan = digest[8] || n_sent. alpha_out = alpha[4] || alpha^2[4].
-__global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out) {
+// chan = digest[8] || n_sent. alpha_out = alpha[4] || alpha^2[4]. root_out receives a copy of the root (the roots of all layers are
+// collected in one array and read back once).
+__global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out) {
     if (threadIdx.x || blockIdx.x) return;
     u32 h[8], m[16], digest[8];
     // mix_root: digest = Blake2s(digest || root), n_sent = 0
-    for (int k = 0; k < 8; k++) { m[k] = chan[k]; m[8 + k] = root[k]; h[k] = B2S_IV[k]; }
+    for (int k = 0; k < 8; k++) { m[k] = chan[k]; m[8 + k] = root[k]; root_out[k] = root[k]; h[k] = B2S_IV[k]; }   // root_out: contiguous copy for one read-back
     h[0] ^= 0x01010020u;
     blake2s_compress(h, m, 64, 0xFFFFFFFFu);
     for (int k = 0; k < 8; k++) digest[k] = h[k];
@@ -167,8 +168,8 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
     for (int k = 0; k < 8; k++) chan[k] = digest[k];
     chan[8] = n_sent;
 }
-void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8) {
-    hipLaunchKernelGGL(k_channel_mix_root_draw, dim3(1), dim3(64), 0, stream, d_chan, d_root, d_alpha8);
+void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {
+    hipLaunchKernelGGL(k_channel_mix_root_draw, dim3(1), dim3(64), 0, stream, d_chan, d_root, d_alpha8, d_root_copy);
 }
 
 // Proof-of-work search (GrindOps::grind): smallest nonce whose mix_u64 digest has >= pow_bits trailing zero bits

@@ -118,7 +118,8 @@ struct HipProver {
 
     // ---- Merkle (a4) -----------------------------------------------------------------------------------------------------------
     // defer_root: leave the 32-byte root copy pending in pinned memory (*pinned_root) instead of synchronising the stream.
-    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr) {
+    // no_readback: the root stays on the device (the caller collects it; FRI commit phase).
+    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false) {
         std::vector<DCol> cols = cols_in;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
         c.stage_checkpoint();
@@ -142,17 +143,18 @@ struct HipProver {
         u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
         while (fused_top > 0 && mk.shifts[fused_top] != 0) fused_top--;   // the fused kernel expects un-replicated layers
         if (mk.shifts[fused_top] != 0) fused_top = 0;
+        StageBatch sb(c);
         const ColDesc* d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
+        void* const* dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
+        sb.end();
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
             merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
                          mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0);
         }
-        if (fused_top > 0) {
-            void* const* dl = (void* const*)c.stage(mk.layers.data(), mk.layers.size());
-            merkle_top(c.stream, dl, fused_top);
-        }
+        if (fused_top > 0) merkle_top(c.stream, dl, fused_top);
         BF_HIP(hipGetLastError());
+        if (no_readback) return mk;
         if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
         c.read_back(mk.root.b, mk.layers[0], 32);
         return mk;
@@ -467,6 +469,7 @@ struct HipProver {
         std::vector<DSecure> acc(max_log + 1);
         std::vector<bool> have(max_log + 1, false);
         u32 remaining = total;
+        std::vector<ConstraintLaunch> launches(N_COMPONENTS);
         for (int k = 0; k < N_COMPONENTS; k++) {
             u32 log = bp.log_sizes[k], eval_log = log + 1, nc = n_constraints(k);
             if (!have[eval_log]) {
@@ -485,9 +488,11 @@ struct HipProver {
             L.el = el; L.total_sum = bp.claimed_sums[k]; L.log_size = log;
             // denom_inv[i] = 1 / coset_vanishing(CanonicCoset(log).coset, eval_domain.at(i)), i in {0, 1} (bit-reversal of 2 entries = identity)
             for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log, canonic_domain_at(eval_log, i)));
-            c.stage_checkpoint();
-            eval_constraints(c.stream, k, c.stage(&L, 1), log);
+            launches[k] = L;
         }
+        c.stage_checkpoint();
+        const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());   // one copy for the 13 parameter blocks
+        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k]);
         BF_HIP(hipGetLastError());
         // finalize: ascending sizes; evaluate the running polynomial on the next populated size, add, interpolate
         bool cur_have = false; std::vector<DCol> cur(4);
@@ -528,8 +533,10 @@ struct HipProver {
                     jobs.push_back(j);
                 }
         c.stage_checkpoint();
+        StageBatch sb(c);
         const uint4* d_factors = c.stage(factors.data(), factors.size());     // through the pinned staging ring (no pageable copies)
         const EvalJob* d_jobs = c.stage(jobs.data(), jobs.size());
+        sb.end();
         void* d_partials = c.arena.alloc(size_t(partial_off) * sizeof(uint4));
         uint4* d_out = (uint4*)c.arena.alloc(jobs.size() * sizeof(uint4));
         eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
@@ -553,6 +560,9 @@ struct HipProver {
         for (size_t t = 0; t < trees.size(); t++) for (size_t i = 0; i < trees[t].evals.size(); i++) flat.push_back({trees[t].evals[i], t, i});
         std::stable_sort(flat.begin(), flat.end(), [](const FlatCol& a, const FlatCol& b) { return a.col.log_size > b.col.log_size; });
         std::vector<DSecure> out;
+        std::vector<QuotientArgs> launches;
+        c.stage_checkpoint();
+        StageBatch sb(c);
         for (size_t i = 0; i < flat.size();) {
             size_t j = i; u32 log = flat[i].col.log_size;
             while (j < flat.size() && flat[j].col.log_size == log) j++;
@@ -566,7 +576,6 @@ struct HipProver {
             }
             std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
             build_quotient_batches(samples, random_coeff, batches, entries);
-            c.stage_checkpoint();
             DSecure q; q.log_size = log;
             for (int w = 0; w < 4; w++) q.c[w] = c.alloc_u32(size_t(1) << log);
             QuotientArgs a{};
@@ -575,10 +584,12 @@ struct HipProver {
             a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
             a.n_batches = (u32)batches.size(); a.log = log; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;
             for (int w = 0; w < 4; w++) a.out[w] = q.c[w];
-            accumulate_quotients(c.stream, a);
+            launches.push_back(a);
             out.push_back(q);
             i = j;
         }
+        sb.end();                                   // one copy for the parameter blocks of every size group
+        for (auto& a : launches) accumulate_quotients(c.stream, a);
         BF_HIP(hipGetLastError());
         return out;
     }
@@ -636,11 +647,12 @@ struct HipProver {
         u32* pinned_chan = reinterpret_cast<u32*>(c.h_small + 64 + 32 * (max_layers + 1));      // digest[8] || n_sent
         u32* d_chan = c.alloc_u32(16);
         u32* d_alpha = c.alloc_u32(8 * (max_layers + 1));
+        u32* d_roots = c.alloc_u32(8 * (max_layers + 1));                                        // root copies, read back once
         memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
         BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
-        DevMerkle first_tree = merkle_commit(first_cols, &pinned_roots[0]);
+        DevMerkle first_tree = merkle_commit(first_cols, nullptr, /*no_readback=*/true);
         u32 cur_alpha = 0;
-        channel_mix_root_draw(c.stream, d_chan, first_tree.layers[0], d_alpha);
+        channel_mix_root_draw(c.stream, d_chan, first_tree.layers[0], d_alpha, d_roots);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
@@ -656,9 +668,9 @@ struct HipProver {
                 qi++;
             }
             Inner in; in.ev = layer;
-            in.tree = merkle_commit(secure_cols(layer), &pinned_roots[1 + inner.size()]);
+            in.tree = merkle_commit(secure_cols(layer), nullptr, /*no_readback=*/true);
             cur_alpha++;
-            channel_mix_root_draw(c.stream, d_chan, in.tree.layers[0], d_alpha + 8 * cur_alpha);
+            channel_mix_root_draw(c.stream, d_chan, in.tree.layers[0], d_alpha + 8 * cur_alpha, d_roots + 8 * (1 + inner.size()));
             DSecure next; next.log_size = line_log - 1;
             for (int w = 0; w < 4; w++) next.c[w] = c.alloc_u32(size_t(1) << (line_log - 1));
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
@@ -669,6 +681,7 @@ struct HipProver {
         if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
         BF_HIP(hipGetLastError());
         BF_HIP(hipMemcpyAsync(pinned_chan, d_chan, 36, hipMemcpyDeviceToHost, c.stream));
+        BF_HIP(hipMemcpyAsync(pinned_roots, d_roots, 32 * (1 + inner.size()), hipMemcpyDeviceToHost, c.stream));
         // last layer: 2^last_log evaluations -> line polynomial (host; LineEvaluation::interpolate on <= 2 values for the default config)
         {
             if (last_log != 1 || cfg.log_last_layer_degree_bound != 0) throw HipError("only the default FRI last-layer configuration is supported");

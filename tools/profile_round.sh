@@ -9,10 +9,10 @@ OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # 1. headline bench line (roofline measured live with HIP events, CPU baseline on the host cores)
-python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; tail -1 "$OUT/bench.log" > "$OUT/${R}_bench.json"
+python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.log" | tail -1 > "$OUT/${R}_bench.json"
 # 2. same command under rocprofv3 --kernel-trace --stats (per-kernel average durations must agree with the roofline object)
 rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
-tail -1 "$OUT/bench_under_rocprof.log" > "$OUT/${R}_bench_under_rocprof.json"
+grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
 python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_stats/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
 # 3. HBM traffic counters, one pass each, kernel trace only
