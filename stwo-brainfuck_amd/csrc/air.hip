@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __res
     air_eval<COMP>(e, a.el);
     Q31 r = q_mulm(e.res, a.denom_inv[row >> a.log_size]);
     g_u32p acc0 = as_global(a.acc[0]), acc1 = as_global(a.acc[1]), acc2 = as_global(a.acc[2]), acc3 = as_global(a.acc[3]);
+    if (a.overwrite) { acc0[row] = r.a.a; acc1[row] = r.a.b; acc2[row] = r.b.a; acc3[row] = r.b.b; return; }
     acc0[row] = m_add(acc0[row], r.a.a);
     acc1[row] = m_add(acc1[row], r.a.b);
     acc2[row] = m_add(acc2[row], r.b.a);

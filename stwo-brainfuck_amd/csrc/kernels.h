@@ -74,6 +74,7 @@ void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24);
 // air.hip
 struct ConstraintLaunch {
     const u32* is_first; ColDesc trace[13]; ColDesc inter[12]; u32* acc[4]; Q31 coeff[12]; Lookups el; Q31 total_sum; u32 denom_inv[2]; u32 log_size;
+    u32 overwrite;   // 1: acc = value (first component of an accumulator: no zero fill, no read); 0: acc += value
 };
 // `d_args` points to a ConstraintLaunch staged in device memory.
 void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size);
@@ -95,7 +96,8 @@ struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
 struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; };
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
 // d_alpha8: device pointer to alpha[4] || alpha^2[4]
-void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
+// fresh: dst holds nothing yet (treated as zero, not read)
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh = false);
 void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
 struct GatherReq { const u32* base; u64 index; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);

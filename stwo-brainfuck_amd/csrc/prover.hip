@@ -474,10 +474,11 @@ struct HipProver {
             u32 log = bp.log_sizes[k], eval_log = log + 1, nc = n_constraints(k);
             if (!have[eval_log]) {
                 acc[eval_log].log_size = eval_log;
-                for (int w = 0; w < 4; w++) { acc[eval_log].c[w] = c.alloc_u32(size_t(1) << eval_log); BF_HIP(hipMemsetAsync(acc[eval_log].c[w], 0, sizeof(u32) << eval_log, c.stream)); }
-                have[eval_log] = true;
+                for (int w = 0; w < 4; w++) acc[eval_log].c[w] = c.alloc_u32(size_t(1) << eval_log);
             }
             ConstraintLaunch L{};
+            L.overwrite = have[eval_log] ? 0u : 1u;      // the first component of a size writes the accumulator (no zero fill)
+            have[eval_log] = true;
             // accum.columns(): this component takes the LAST nc remaining powers and uses them reversed (constraint 0 <-> highest)
             for (u32 j = 0; j < nc; j++) L.coeff[j] = powers[remaining - 1 - j];
             remaining -= nc;
@@ -657,14 +658,16 @@ struct HipProver {
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
         DSecure layer; layer.log_size = line_log;
-        for (int w = 0; w < 4; w++) { layer.c[w] = c.alloc_u32(size_t(1) << line_log); BF_HIP(hipMemsetAsync(layer.c[w], 0, sizeof(u32) << line_log, c.stream)); }
+        for (int w = 0; w < 4; w++) layer.c[w] = c.alloc_u32(size_t(1) << line_log);
+        bool layer_fresh = true;                     // nothing folded into `layer` yet: the first circle fold writes it (no zero fill)
         size_t qi = 0;
         u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
         if (line_log > last_log + max_layers) throw HipError("FRI: too many layers");
         while (line_log > last_log) {
             while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
                 const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
-                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size);
+                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size, layer_fresh);
+                layer_fresh = false;
                 qi++;
             }
             Inner in; in.ev = layer;

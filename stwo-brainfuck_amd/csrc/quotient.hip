@@ -199,7 +199,7 @@ void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u32* const d1, u32* const d2, u32* const d3,
                                                                const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
-                                                               const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log) {
+                                                               const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log, u32 fresh) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << (log - 1))) return;
     const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]), alpha_sq = q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]);
@@ -210,8 +210,8 @@ __global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u3
     Q31 fp = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
     Q31 f0 = q_add(fp, fn), f1 = q_mulm(q_sub(fp, fn), yinv);
     Q31 fprime = q_add(q_mul(alpha, f1), f0);
-    Q31 dst = q_make(d0[i], d1[i], d2[i], d3[i]);
-    Q31 r = q_add(q_mul(dst, alpha_sq), fprime);
+    Q31 r = fprime;                                   // fresh destination: 0 * alpha^2 + f'
+    if (!fresh) { Q31 dst = q_make(d0[i], d1[i], d2[i], d3[i]); r = q_add(q_mul(dst, alpha_sq), fprime); }
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
 __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3,
@@ -228,10 +228,10 @@ __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
 // d_alpha8 = device pointer to alpha[4] || alpha^2[4] (written by k_channel_mix_root_draw or staged from the host)
-void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log) {
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh) {
     u32 n = 1u << (log - 1);
     hipLaunchKernelGGL(k_fold_circle_into_line, dim3((n + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3],
-                       d_alpha8, itw, 1u << tw_root_log, log);
+                       d_alpha8, itw, 1u << tw_root_log, log, fresh ? 1u : 0u);
 }
 void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log) {
     u32 n = 1u << (log - 1);
