@@ -207,30 +207,59 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
     __shared__ u32 s_tw[4096];
     const u32 t = threadIdx.x, k = a.k, tile = blockIdx.x;
     const u32 base = tile << 12;
-    // stage twiddles of local layers j < k: entry (j, q) at 4096 - 2^(12-j) + q, q < 2^(11-j); global h = (tile << (11-j)) + q
-    for (u32 e = t; e < 4096u - (4096u >> k); e += 256) {
-        u32 j = __clz(~(e << 20));
-        u32 q = e - (4096u - (4096u >> j));
-        u32 h = (tile << (11 - j)) + q;
-        u32 v;
-        if (a.circle && j == 0) {
-            const u32* l0 = layer_table(a, 1);
-            u32 x = l0[(h >> 2) * 2], y = l0[(h >> 2) * 2 + 1], sel = h & 3;
-            v = sel == 0 ? y : sel == 1 ? m_neg(y) : sel == 2 ? m_neg(x) : x;
-        } else v = layer_table(a, j)[h];
-        s_tw[e] = v;
+    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    // The tile of the next column is fetched while the current one is transformed (16 more registers, same occupancy): without it
+    // every column starts with an exposed HBM round trip, which costs ~25 % when a block has only a few columns.
+    uint4 nxt[4];
+    if (col0 < col1) {
+        g_cu32p src0 = as_global(a.src[col0]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = ld16(src0 + ((base + 1024 * q + 4 * t) & a.src_mask));
+    }
+    // stage twiddles of local layers j < k: entry (j, q) at 4096 - 2^(12-j) + q, q < 2^(11-j); global h = (tile << (11-j)) + q.
+    // 16 entries per lane with a compile-time layer for each slot (8 of layer 0, 4 of layer 1, 2 of layer 2, 1 of layer 3, 1 of the
+    // layers 4..11), so that the 16 loads are issued back to back and waited for once — a rolled loop serialises 16 memory round
+    // trips per block, which dominates when a batch has only a few columns per block.
+    {
+        u32 tw_r[16];
+        g_cu32p tw = as_global(a.tw);
+        auto table = [&](u32 j) -> g_cu32p { return tw + (layer_table(a, j) - a.tw); };
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const u32 j = s < 8 ? 0u : s < 12 ? 1u : s < 14 ? 2u : s < 15 ? 3u : 4u;            // slot -> layer (4 = "4 and above")
+            const u32 e = 256u * s + t;
+            u32 v = 0;
+            if (j < 4) {
+                if (j < k) {
+                    const u32 q = e - (4096u - (4096u >> j));
+                    const u32 h = (tile << (11 - j)) + q;
+                    if (j == 0 && a.circle) {
+                        g_cu32p l0 = table(1);
+                        const u32 x = l0[(h >> 2) * 2], y = l0[(h >> 2) * 2 + 1], sel = h & 3;
+                        v = sel == 0 ? y : sel == 1 ? m_neg(y) : sel == 2 ? m_neg(x) : x;
+                    } else v = table(j)[h];
+                }
+            } else if (e < 4096u - (4096u >> k)) {
+                const u32 jj = __clz(~(e << 20));
+                const u32 q = e - (4096u - (4096u >> jj));
+                v = table(jj)[(tile << (11 - jj)) + q];
+            }
+            tw_r[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) s_tw[256u * s + t] = tw_r[s];
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[4096u - (4096u >> layer) + idx]; };
-    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     for (u32 col = col0; col < col1; col++) {
-        g_cu32p src = as_global(a.src[col]);
         g_u32p dst = as_global(a.dst[col]);
         __syncthreads();
         u32 r[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint4 v = ld16(src + ((base + 1024 * q + 4 * t) & a.src_mask));
-            r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
+        for (int q = 0; q < 4; q++) { r[q][0] = nxt[q].x; r[q][1] = nxt[q].y; r[q][2] = nxt[q].z; r[q][3] = nxt[q].w; }
+        if (col + 1 < col1) {
+            g_cu32p srcn = as_global(a.src[col + 1]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) nxt[q] = ld16(srcn + ((base + 1024 * q + 4 * t) & a.src_mask));
         }
         // ---- register stage on the 16-byte groups: layers 0,1 (cells 4t..4t+3 of each quarter q) and 10,11 (across q) --------
         auto stage_low = [&]() {
