@@ -31,6 +31,7 @@ inline void build_quotient_batches(const std::vector<std::vector<ColumnSample>>&
         const PtQ& pt = kv.first;
         QuotientBatch qb{};
         qb.prx = pt.x.a; qb.pry = pt.y.a; qb.pix = pt.x.b; qb.piy = pt.y.b;
+        qb.kden = c_sub(c_mul(qb.prx, qb.piy), c_mul(qb.pry, qb.pix));   // constant part of the row denominators
         qb.a_sum = q_zero(); qb.b_sum = q_zero();
         Q31 alpha = q_one();
         for (auto& cv : kv.second) {

@@ -91,7 +91,7 @@ void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells)
 // quotient.hip
 struct EvalJob { const u32* coeffs; u32 log_n; u32 point; u32 factor_shift; u32 partial_off; };
 void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 total_partials, const void* d_factors, void* d_partials, void* d_out);
-struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; u32 pad_[3]; };
+struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; C31 kden; u32 pad_; };   // kden = prx * piy - pry * pix
 struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
 struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; };
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);

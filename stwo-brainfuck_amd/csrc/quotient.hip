@@ -162,10 +162,9 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             num[r] = q_sub(num[r], q_add(q_mulm(qb.a_sum, y[r]), qb.b_sum));
-            // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x   in CM31
-            C31 dx = qb.prx; dx.a = m_sub(dx.a, x[r]);
-            C31 dy = qb.pry; dy.a = m_sub(dy.a, y[r]);
-            den[r] = c_sub(c_mul(dx, qb.piy), c_mul(dy, qb.pix));
+            // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x in CM31 = kden - x * Pi.y + y * Pi.x (x, y in M31: 4 products instead of 8)
+            den[r].a = m_add(m_sub(qb.kden.a, m_mul(x[r], qb.piy.a)), m_mul(y[r], qb.pix.a));
+            den[r].b = m_add(m_sub(qb.kden.b, m_mul(x[r], qb.piy.b)), m_mul(y[r], qb.pix.b));
             nrm[r] = m_add(m_sqr(den[r].a), m_sqr(den[r].b));
         }
         u32 p01 = m_mul(nrm[0], nrm[1]), p012 = m_mul(p01, nrm[2]), inv_all = m_inv(m_mul(p012, nrm[3]));
