@@ -14,7 +14,9 @@ python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.
 rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
-python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_stats/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
+# 2b. idle-gap analysis of one proof without the event instrumentation
+rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --steps 3 --warmup 1 > /dev/null 2>&1
+python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_$C.log" 2>&1
