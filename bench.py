@@ -157,9 +157,10 @@ def main():
         avg_ms = d["total_ms"] / d["calls"]
         achieved = d["bytes"] / d["calls"] / (avg_ms * 1e-3) / 1e9
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # filled from the separate rocprofv3 --pmc passes, if committed
-        if os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path)).get(name, {}).get("hbm_bytes_per_launch")
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # from the separate rocprofv3 --pmc passes of the latest round
+        if pmc_files:
+            traffic = json.load(open(pmc_files[-1])).get(name, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
@@ -188,7 +189,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32 (M31 / QM31 modular arithmetic)",
-            "data": "fib19.bf execution trace (199246 VM steps); proof bytes identical to the CPU oracle on the oracle-sized parity programs",
+            "data": "fib19.bf execution trace (199246 VM steps); proof bytes identical to the CPU oracle's proof of this workload (tests/golden/fib19_lmr24_oracle_proof.json)",
             "config": {"workload": "fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, 1 proof per step",
                        "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
                        "component_log_sizes": trace.log_sizes, "parallelism": "replicas" if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",

@@ -21,7 +21,7 @@ python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | h
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > "$OUT/pmc_$C.log" 2>&1
 done
-python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/pmc_traffic.json"
+python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/${R}_pmc_traffic.json"
 # 4. FFT kernel run (BASELINE config 3 (i)), Merkle shapes, one-call end-to-end, large synthetic trace
 python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
 python3 "$ROOT/tools/merkle_shapes.py" > "$OUT/${R}_merkle_shapes.txt" 2>&1
