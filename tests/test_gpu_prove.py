@@ -141,6 +141,20 @@ def small_ctx(pkg):
     c.close()
 
 
+@pytest.mark.parametrize("code,inp", [("+", b""), (",", b"\x05"), ("+[-]", b""), ("++>+<[->+<]", b"")], ids=["+", ",", "+[-]", "move"])
+def test_smallest_log_max_rows(pkg, oracle, code, inp):
+    """LOG_MAX_ROWS exactly the largest component (6..9 here): the smallest preprocessed tree, transforms of 2^5..2^11 cells only,
+    FRI with very few layers; the context is created with the minimum twiddle tree that fits."""
+    lmr = max(oracle.log_sizes(code, inp)[0])
+    c = pkg.Context(0, max_log_domain=lmr + 2)
+    try:
+        got = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
+    finally:
+        c.close()
+    assert got == oracle.prove(code, inp, log_max_rows=lmr)[0]
+    assert pkg.verify_brainfuck(got, lmr) == (True, "")
+
+
 def test_trace_too_large_for_log_max_rows_is_an_error(pkg, small_ctx):
     with pytest.raises(pkg.BfhipError, match="LOG_MAX_ROWS"):
         pkg.prove_brainfuck("++++++++[>++++++++<-]>[<++++>-]", b"", ctx=small_ctx, log_max_rows=6)
