@@ -6,7 +6,7 @@ from bf_fuzz import random_program
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = [(s, 400) for s in range(100, 164)] + [(s, 6000) for s in range(200, 216)]   # (seed, step bound)
+SEEDS = [(s, 400) for s in range(100, 260)] + [(s, 6000) for s in range(300, 340)]   # (seed, step bound)
 
 
 @pytest.mark.parametrize("seed,max_steps", SEEDS)
