@@ -137,6 +137,20 @@ int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint
 int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
                               char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
 void bfhip_free_host(void* p);
+/* ---- one proof over several GPUs: row-sharded commitments --------------------------------------------------------------------------
+ * north_star: "columns shard across the GPUs of one node, Merkle root reduced via RCCL". Every rank of a shard group runs the same
+ * proof on the same trace (identical transcript), but of every large Merkle layer it hashes only its contiguous 1/count share of the
+ * nodes — hashing is >50 % of a proof. Two exchanges per proof path, both tiny and supplied by the host program as callbacks
+ * (torch.distributed / RCCL in bench.py; any MPI-like layer works):
+ *   allgather      — once per committed tree: every rank contributes its slice of the smallest sharded layer (256 nodes = 8 KiB);
+ *                    all ranks then finish the top of the tree redundantly and obtain the same root.
+ *   allreduce_max  — once per proof: the decommitment words (each hash witness is held by exactly one rank, zero elsewhere).
+ * count must be a power of two; rank < count. count = 1 (default) switches the mode off. Callbacks return 0 on success; buffers are
+ * host memory. The proof is byte-identical to the single-GPU proof. */
+typedef int32_t (*bfhip_allgather_fn)(void* user, const void* send_h, size_t bytes_per_rank, void* recv_h);
+typedef int32_t (*bfhip_allreduce_max_u32_fn)(void* user, uint32_t* buf_h, size_t n);
+int32_t bfhip_ctx_set_shard(bfhip_ctx* ctx, uint32_t rank, uint32_t count, bfhip_allgather_fn allgather, bfhip_allreduce_max_u32_fn allreduce_max, void* user);
+
 /* Optional (off by default): keep the preprocessed tree (IsFirst(LOG_MAX_ROWS..=4): polynomials, LDE columns, Merkle layers, root) of
  * the first proof in the context and reuse it for later proofs with the same LOG_MAX_ROWS. The reference recommits it in every
  * prove_brainfuck call (mod.rs:495-500); proof bytes are identical either way. Call with on = 0 before bfhip_ctx_destroy to release it. */

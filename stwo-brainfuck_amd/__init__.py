@@ -62,6 +62,41 @@ class Context:
     def sync(self):
         _check(lib().bfhip_ctx_sync(self._h))
 
+    # -- one proof over several GPUs (bfhip_ctx_set_shard) ---------------------------------------------------------------------------
+    _ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+    _ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+    def set_shard(self, rank, count, allgather=None, allreduce_max=None):
+        """Makes this context rank `rank` of a group of `count` contexts (one per GPU) that prove ONE trace together.
+        allgather(send: bytes) -> bytes of all ranks in rank order; allreduce_max(values: np.ndarray[uint32]) -> element-wise maximum
+        over the ranks. count = 1 switches the mode off."""
+        if count == 1:
+            _check(lib().bfhip_ctx_set_shard(self._h, 0, 1, None, None, None))
+            self._shard_cbs = None
+            return
+
+        def _ag(_user, send_p, nbytes, recv_p):
+            try:
+                out = allgather(ctypes.string_at(send_p, nbytes))
+                if len(out) != nbytes * count:
+                    return -2
+                ctypes.memmove(recv_p, out, len(out))
+                return 0
+            except Exception:      # an exception must not unwind through the C frames
+                return -1
+
+        def _ar(_user, buf_p, n):
+            try:
+                arr = np.ctypeslib.as_array(ctypes.cast(buf_p, ctypes.POINTER(ctypes.c_uint32)), shape=(n,))
+                arr[:] = allreduce_max(arr.copy())
+                return 0
+            except Exception:
+                return -1
+
+        cbs = (self._ALLGATHER(_ag), self._ALLREDUCE(_ar))
+        _check(lib().bfhip_ctx_set_shard(self._h, rank, count, cbs[0], cbs[1], None))
+        self._shard_cbs = cbs       # keep the thunks alive as long as the context uses them
+
     # -- buffers ---------------------------------------------------------------------------------------------------
     def malloc(self, nbytes):
         p = ctypes.c_void_p()

@@ -79,6 +79,20 @@ int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx**
     API_CATCH
 }
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
+int32_t bfhip_ctx_set_shard(bfhip_ctx* ctx, uint32_t rank, uint32_t count, bfhip_allgather_fn allgather, bfhip_allreduce_max_u32_fn allreduce_max, void* user) {
+    API_CTX(ctx)
+    if (count == 0 || (count & (count - 1)) != 0 || count > 256) throw HipError("shard count must be a power of two <= 256");
+    if (rank >= count) throw HipError("shard rank out of range");
+    if (count > 1 && (!allgather || !allreduce_max)) throw HipError("a shard group needs both exchange callbacks");
+    ShardGroup g;
+    g.rank = rank; g.count = count; g.log_count = 0;
+    while ((1u << g.log_count) < count) g.log_count++;
+    g.allgather = allgather; g.allreduce_max = allreduce_max; g.user = user;
+    ctx->c.sync();
+    ctx->c.shard = g;
+    return 0;
+    API_CATCH
+}
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx) { API_CTX(ctx) ctx->c.sync(); return 0; API_CATCH }
 
 int32_t bfhip_malloc(bfhip_ctx* ctx, size_t bytes, void** out_d) { API_CTX(ctx) BF_HIP(hipSetDevice(ctx->c.device)); BF_HIP(hipMalloc(out_d, bytes ? bytes : 4)); return 0; API_CATCH }

@@ -31,8 +31,17 @@ struct Arena {
     void release() { for (auto& c : chunks) (void)hipFree(c.base); chunks.clear(); total_used = 0; }
 };
 
+// One proof over several GPUs (include/bfhip.h: bfhip_ctx_set_shard): this rank's place in the group and the two host-side exchanges.
+struct ShardGroup {
+    u32 rank = 0, count = 1, log_count = 0;
+    int (*allgather)(void* user, const void* send_h, size_t bytes_per_rank, void* recv_h) = nullptr;
+    int (*allreduce_max)(void* user, u32* buf_h, size_t n) = nullptr;
+    void* user = nullptr;
+};
+
 struct Ctx {
     int device = 0;
+    ShardGroup shard;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase
     bool side_busy = false;         // work enqueued on stream2 may still read parameter blocks from the staging ring

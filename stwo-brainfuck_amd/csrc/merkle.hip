@@ -95,9 +95,10 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
     out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]);
 }
 // Grid-stride over the stored nodes: large layers give every lane several nodes, which amortises wave launch and the kernel prologue.
+// [first, first + n_stored) is the range of stored nodes this launch computes (the whole layer, or one rank's share of it).
 __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
-                                                      u32 out_shift, u32 prev_shift) {
-    for (u32 st = blockIdx.x * blockDim.x + threadIdx.x; st < n_stored; st += gridDim.x * blockDim.x) merkle_node(st, out, prev, cols, ncols, out_shift, prev_shift);
+                                                      u32 out_shift, u32 prev_shift, u32 first) {
+    for (u32 st = blockIdx.x * blockDim.x + threadIdx.x; st < n_stored; st += gridDim.x * blockDim.x) merkle_node(first + st, out, prev, cols, ncols, out_shift, prev_shift);
 }
 
 // Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
@@ -125,13 +126,16 @@ __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ l
 #define MERKLE_NODES_PER_LANE 4
 #endif
 // col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift) {
-    u32 n = (1u << log) >> out_shift;
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
+                  u32 first, u32 count) {
+    const u32 total = (1u << log) >> out_shift;
+    const u32 n = count ? count : total;                 // count == 0: the whole layer
     u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
-    ProfScope ps(stream, "k_merkle_layer", (prev ? 64.0 * n : 0.0) + 32.0 * n + col_bytes);
+    const double frac = (double)n / (double)total;
+    ProfScope ps(stream, "k_merkle_layer", ((prev ? 64.0 * total : 0.0) + 32.0 * total + col_bytes) * frac);
     u32 blocks = (n + threads - 1) / threads;
     if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
-    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift);
+    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u);
 }
 void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
     ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));

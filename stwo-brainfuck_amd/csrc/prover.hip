@@ -29,7 +29,9 @@ struct DCol {
     size_t stored() const { return size_t(1) << (log_size - shift); }
     ColDesc desc() const { return ColDesc{ptr, shift, 0}; }
 };
-struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; };   // layer k: node i stored at i >> shifts[k]
+// layer k: node i stored at i >> shifts[k]. In a shard group (Ctx::shard.count > 1) the layers k with band_lo < k <= band_hi hold only this
+// rank's contiguous share of the nodes (node i belongs to rank i >> (k - log2 count)); layer band_lo and everything below is complete.
+struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; int band_lo = 0, band_hi = -1; };
 struct DTree { std::vector<DCol> polys, evals; DevMerkle mk; };
 struct DSecure { u32* c[4]; u32 log_size; };
 
@@ -48,6 +50,9 @@ struct Gather {
             gather_u32(c.stream, d, (u32)n, dout);
             c.read_back(out.data() + o, dout, n * sizeof(u32));
         }
+        // shard group: every word is either identical on all ranks (column values, complete layers) or held by one rank and zero
+        // elsewhere (hashes of share-wise layers) — an element-wise maximum completes it everywhere
+        if (c.shard.count > 1 && !out.empty() && c.shard.allreduce_max(c.shard.user, out.data(), out.size()) != 0) throw HipError("shard group: all-reduce failed");
         return out;
     }
 };
@@ -147,10 +152,30 @@ struct HipProver {
         const ColDesc* d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
         void* const* dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
         sb.end();
+        // Shard group: the un-replicated layers with at least 256 nodes per rank are hashed share-wise; the smallest of them is
+        // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
+        const ShardGroup& sg = c.shard;
+        if (sg.count > 1) {
+            int hi = -1;
+            for (int log = (int)mk.max_log; log >= 0; log--) if (mk.shifts[log] == 0) { hi = log; break; }
+            int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
+            if (hi >= lo) { mk.band_hi = hi; mk.band_lo = lo; }
+        }
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
+            const bool share = log >= mk.band_lo && log <= mk.band_hi;
+            const u32 per_rank = share ? (1u << (log - sg.log_count)) : 0u;
             merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
-                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0);
+                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
+            if (share && log == mk.band_lo) {
+                const size_t slice = (size_t(32) << log) >> sg.log_count;
+                std::vector<u8> mine(slice), everyone(slice * sg.count);
+                c.read_back(mine.data(), reinterpret_cast<const u8*>(mk.layers[log]) + sg.rank * slice, slice);
+                if (sg.allgather(sg.user, mine.data(), slice, everyone.data()) != 0) throw HipError("shard group: all-gather failed");
+                c.stage_checkpoint();
+                const u8* staged = c.stage(everyone.data(), everyone.size());
+                BF_HIP(hipMemcpyAsync(mk.layers[log], staged, everyone.size(), hipMemcpyDeviceToDevice, c.stream));
+            }
         }
         if (fused_top > 0) merkle_top(c.stream, dl, fused_top);
         BF_HIP(hipGetLastError());
@@ -189,7 +214,14 @@ struct HipProver {
                 if (prev_hashes) {
                     for (size_t child = 2 * node; child <= 2 * node + 1; child++) {
                         if (pi < last.size() && last[pi] == child) pi++;
-                        else { size_t f = g.reqs.size(); for (u32 w = 0; w < 8; w++) g.add(prev_hashes, (child >> prev_shift) * 8 + w); slots.push_back({0, f}); }
+                        else {
+                            // in a shard group a hash of a share-wise layer is held by one rank only; the others request a zero
+                            const bool shared_layer = log + 1 > mk.band_lo && log + 1 <= mk.band_hi;
+                            const bool mine = !shared_layer || (child >> (log + 1 - c.shard.log_count)) == c.shard.rank;
+                            size_t f = g.reqs.size();
+                            for (u32 w = 0; w < 8; w++) g.add(mine ? prev_hashes : nullptr, (child >> prev_shift) * 8 + w);
+                            slots.push_back({0, f});
+                        }
                     }
                 }
                 bool queried = qi < colq.size() && colq[qi] == node;

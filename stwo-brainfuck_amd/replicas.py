@@ -49,3 +49,29 @@ def aggregate_units(units_this_rank: int, dist=None, backend_tensor=None) -> int
     t = torch.tensor([float(units_this_rank)], dtype=torch.float64) if backend_tensor is None else backend_tensor(float(units_this_rank))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def shard_exchanges(dist, device=None):
+    """The two exchanges of a shard group (Context.set_shard) over torch.distributed: RCCL when `device` is a CUDA device
+    (backend "nccl"), gloo on CPU tensors otherwise. Returns (allgather, allreduce_max)."""
+    import numpy as np
+    import torch
+
+    world = dist.get_world_size()
+
+    def allgather(send: bytes) -> bytes:
+        t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+        if device is not None:
+            t = t.to(device)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return b"".join(o.cpu().numpy().tobytes() for o in outs)
+
+    def allreduce_max(values):
+        t = torch.from_numpy(values.astype(np.int64))     # u32 values as int64: MAX is then the unsigned maximum on every backend
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().numpy().astype(np.uint32)
+
+    return allgather, allreduce_max

@@ -68,6 +68,14 @@ assert len(calls) == 4 and last[0] == "proof"
 assert dt >= 0.02 * 2 * 3 * 0.9, dt          # MAX over ranks: the slow rank (rank 1) sets the time
 assert cells == 2001
 assert rep.rank_device(rank, 8) == rank
+# the two exchanges of a shard group (one proof over several GPUs) over gloo
+import numpy as np
+allgather, allreduce_max = rep.shard_exchanges(dist)
+got = allgather(bytes([rank]) * 5)
+assert got == b"\x00" * 5 + b"\x01" * 5, got
+vals = np.array([0, 7, 0xFFFFFFFF, 3], dtype=np.uint32) if rank == 0 else np.array([5, 0, 1, 3], dtype=np.uint32)
+red = allreduce_max(vals)
+assert red.dtype == np.uint32 and red.tolist() == [5, 7, 0xFFFFFFFF, 3], red
 print("ok", rank, round(dt, 3))
 dist.destroy_process_group()
 """
