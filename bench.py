@@ -4,7 +4,8 @@
 A "step" is one complete proof (preprocessed commitment .. decommitment, crates/brainfuck_prover/src/brainfuck_air/mod.rs:493-734)
 of one trace whose row-granular table columns are already resident in HBM. Workload at N=1: BASELINE.json configs[1]
 (fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, LOG_MAX_ROWS = 24).
-N > 1: one process per GPU, every rank proves its own independent trace ("replicas only", weak scaling).
+N > 1: one process per GPU. Default: every rank proves its own independent trace (replicas, weak scaling, no data-path collective).
+--shard: the N ranks prove ONE trace together (shard group, strong scaling).
 
 Prints ONE JSON line on rank 0 (driver contract). The roofline object is measured live with HIP events on the library's stream;
 the cpu_baseline object times the CPU oracle ("port") on a bounded sample on the host cores of the same box.
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--kernel-events", default="dominant", choices=["dominant", "all"], help="HIP-event timing of the dominant kernel only (default, ~1%% overhead) or of every kernel (~10%%)")
     ap.add_argument("--reuse-preprocessed", action="store_true", help="NOT the headline: keep the program-independent preprocessed tree across proofs (a deployment option; the reference recommits it per proof)")
     ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + HIP stream each); >1 reports pipelined throughput, no roofline")
+    ap.add_argument("--shard", action="store_true", help="NOT the default: with --gpus N > 1 the N ranks prove ONE trace together (shard group: share-wise Merkle layers, "
+                    "one all-gather per tree, one max-reduce per proof; strong scaling of a single proof) instead of N independent replicas")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
     args = ap.parse_args()
@@ -129,6 +132,12 @@ def main():
     spec = importlib.util.spec_from_file_location("stwo_brainfuck_amd_replicas", os.path.join(ROOT, "stwo-brainfuck_amd", "replicas.py"))
     replicas = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(replicas)
+    sharded = args.shard and dist is not None and world > 1
+    if sharded:
+        if args.inflight > 1:
+            raise SystemExit("--shard and --inflight are exclusive")
+        dev = torch.device("cuda", device) if args.dist_backend == "nccl" else None
+        ctx.set_shard(rank, world, *replicas.shard_exchanges(dist, dev))
 
     def sync():
         ctx.sync()
@@ -144,7 +153,8 @@ def main():
     cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
     dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync,
                                                 backend_tensor=cuda_t, on_timed_start=start_events)
-    total_cells = replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=cuda_t)
+    # replicas: every rank proves its own trace (units add up); shard group: all ranks prove the same one
+    total_cells = trace.cells if sharded else replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=cuda_t)
 
     roofline = None
     if not args.no_kernel_events:
@@ -186,13 +196,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "u32 (M31 / QM31 modular arithmetic)",
             "data": "fib19.bf execution trace (199246 VM steps); proof bytes identical to the CPU oracle's proof of this workload (tests/golden/fib19_lmr24_oracle_proof.json)",
             "config": {"workload": "fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, 1 proof per step",
                        "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
-                       "component_log_sizes": trace.log_sizes, "parallelism": "replicas" if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
+                       "component_log_sizes": trace.log_sizes, "parallelism": ("shard group: one proof over all ranks, share-wise Merkle layers" if sharded else "replicas") if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
                        "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()}},
             "roofline": roofline,
         }
@@ -201,6 +211,8 @@ def main():
         print(json.dumps(out), flush=True)
     if args.reuse_preprocessed:
         lib.bfhip_ctx_reuse_preprocessed(ctx._h, 0)
+    if sharded:
+        ctx.set_shard(0, 1)
     for c2, t2 in extra:
         t2.close(); c2.close()
     trace.close()
