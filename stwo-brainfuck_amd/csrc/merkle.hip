@@ -91,8 +91,10 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
         if (last) break;
     }
-    out[2 * (size_t)st] = make_uint4(h[0], h[1], h[2], h[3]);
-    out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+    // write-once data that the next launch (not this one) reads: non-temporal stores keep it from displacing the inputs in L2
+    bf_u32x4 lo4 = {h[0], h[1], h[2], h[3]}, hi4 = {h[4], h[5], h[6], h[7]};
+    __builtin_nontemporal_store(lo4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st));
+    __builtin_nontemporal_store(hi4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st + 1));
 }
 // Grid-stride over the stored nodes: large layers give every lane several nodes, which amortises wave launch and the kernel prologue.
 // [first, first + n_stored) is the range of stored nodes this launch computes (the whole layer, or one rank's share of it).
