@@ -22,8 +22,25 @@ typedef ConstraintLaunch ConstraintArgs;   // lives in HBM (staged by the host);
 
 struct DomainEval : LogupState<DomainEval, Fm> {
     typedef Fm F;
-    const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0; Q31 res;
-    __device__ DomainEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { res = q_zero(); total_sum = a_.total_sum; }
+    const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0;
+    // sum_j coeff_j * c_j. Base-field constraints (all but the logUp ones) are accumulated as four 64-bit dot products with lazy
+    // reduction: a product of canonical values is < 2^62, so three of them fit on top of a folded accumulator (< 2^34) before the
+    // next fold x -> (x & P) + (x >> 31). One multiply-add per coordinate instead of a full modular multiply and add; the canonical
+    // result is the same.
+    u64 acc[4] = {0, 0, 0, 0}; int pending = 0; Q31 res_ext;
+    __device__ DomainEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { res_ext = q_zero(); total_sum = a_.total_sum; }
+    __device__ __forceinline__ void fold() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = (acc[k] & P31) + (acc[k] >> 31);
+        pending = 0;
+    }
+    __device__ __forceinline__ static u32 canon(u64 x) {
+        x = (x & P31) + (x >> 31);                 // < 2^31 + 2^33
+        x = (x & P31) + (x >> 31);                 // < 2^31 + 8
+        u32 r = (u32)x;
+        return r >= P31 ? r - P31 : r;
+    }
+    __device__ __forceinline__ Q31 result() { return q_add(q_make(canon(acc[0]), canon(acc[1]), canon(acc[2]), canon(acc[3])), res_ext); }
     __device__ __forceinline__ Fm is_first() { return {as_global(a.is_first)[row]}; }
     __device__ __forceinline__ Fm trace() { return {ld_col(a.trace[ti++], row)}; }
     __device__ __forceinline__ Fm cst(u32 k) { return {k}; }
@@ -40,8 +57,13 @@ struct DomainEval : LogupState<DomainEval, Fm> {
         u32 pr = bit_rev(pd, el);
         cur.v = rd(ii, row); prev.v = rd(ii, pr); ii += 4;
     }
-    __device__ __forceinline__ void constraint(Fm c) { res = q_add(res, q_mulm(a.coeff[ci++], c.v)); }
-    __device__ __forceinline__ void constraint(Fq c) { res = q_add(res, q_mul(a.coeff[ci++], c.v)); }
+    __device__ __forceinline__ void constraint(Fm c) {
+        const Q31 k = a.coeff[ci++];
+        if (pending == 3) fold();
+        acc[0] += (u64)k.a.a * c.v; acc[1] += (u64)k.a.b * c.v; acc[2] += (u64)k.b.a * c.v; acc[3] += (u64)k.b.b * c.v;
+        pending++;
+    }
+    __device__ __forceinline__ void constraint(Fq c) { res_ext = q_add(res_ext, q_mul(a.coeff[ci++], c.v)); }
 };
 
 template <int COMP>
@@ -51,7 +73,7 @@ __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __res
     if (row >= (2u << a.log_size)) return;
     DomainEval e(a, row);
     air_eval<COMP>(e, a.el);
-    Q31 r = q_mulm(e.res, a.denom_inv[row >> a.log_size]);
+    Q31 r = q_mulm(e.result(), a.denom_inv[row >> a.log_size]);
     g_u32p acc0 = as_global(a.acc[0]), acc1 = as_global(a.acc[1]), acc2 = as_global(a.acc[2]), acc3 = as_global(a.acc[3]);
     if (a.overwrite) { acc0[row] = r.a.a; acc1[row] = r.a.b; acc2[row] = r.b.a; acc3[row] = r.b.b; return; }
     acc0[row] = m_add(acc0[row], r.a.a);
