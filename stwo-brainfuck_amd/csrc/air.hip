@@ -31,16 +31,10 @@ struct DomainEval : LogupState<DomainEval, Fm> {
     __device__ DomainEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { res_ext = q_zero(); total_sum = a_.total_sum; }
     __device__ __forceinline__ void fold() {
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] = (acc[k] & P31) + (acc[k] >> 31);
+        for (int k = 0; k < 4; k++) acc[k] = m_fold(acc[k]);
         pending = 0;
     }
-    __device__ __forceinline__ static u32 canon(u64 x) {
-        x = (x & P31) + (x >> 31);                 // < 2^31 + 2^33
-        x = (x & P31) + (x >> 31);                 // < 2^31 + 8
-        u32 r = (u32)x;
-        return r >= P31 ? r - P31 : r;
-    }
-    __device__ __forceinline__ Q31 result() { return q_add(q_make(canon(acc[0]), canon(acc[1]), canon(acc[2]), canon(acc[3])), res_ext); }
+    __device__ __forceinline__ Q31 result() { return q_add(q_make(m_canon(acc[0]), m_canon(acc[1]), m_canon(acc[2]), m_canon(acc[3])), res_ext); }
     __device__ __forceinline__ Fm is_first() { return {as_global(a.is_first)[row]}; }
     __device__ __forceinline__ Fm trace() { return {ld_col(a.trace[ti++], row)}; }
     __device__ __forceinline__ Fm cst(u32 k) { return {k}; }

@@ -23,6 +23,10 @@ constexpr u32 P31 = 0x7fffffffu;
 
 BF_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; u32 t = s - P31; return t < s ? t : s; }           // min(s, s-P) with wraparound
 BF_HD u32 m_sub(u32 a, u32 b) { u32 s = a - b; u32 t = s + P31; return t < s ? t : s; }           // a-b or a-b+P
+// Lazy reduction for dot products: a product of canonical values is < 2^62, so three products fit on top of a folded accumulator
+// (< 2^34) in 64 bits; m_fold brings an accumulator back below 2^34, m_canon to the canonical representative.
+BF_HD u64 m_fold(u64 x) { return (x & P31) + (x >> 31); }
+BF_HD u32 m_canon(u64 x) { x = m_fold(m_fold(x)); u32 r = (u32)x; return r >= P31 ? r - P31 : r; }   // x < 2^64 -> < 2^34 -> < 2^31 + 8
 BF_HD u32 m_neg(u32 a) { return a ? P31 - a : 0; }
 BF_HD u32 m_reduce64(u64 x) {  // x < P^2 -> [0, P)
     u32 lo = (u32)x & P31, hi = (u32)(x >> 31);

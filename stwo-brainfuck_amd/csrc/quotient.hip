@@ -144,20 +144,39 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
     u32 e = 0;
     for (u32 b = 0; b < a.n_batches; b++) {
         const QuotientBatch qb = a.batches[b];
-        Q31 num[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
+        // numerators sum_k c_k * f_k(row): 64-bit dot products with lazy reduction (m31.h: m_fold / m_canon), folded every third column;
+        // columns stored once per 4+ rows go into one accumulator shared by the lane's 4 rows
+        u64 n64[4][4], s64[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { n64[r][0] = 0; n64[r][1] = 0; n64[r][2] = 0; n64[r][3] = 0; }
+        s64[0] = 0; s64[1] = 0; s64[2] = 0; s64[3] = 0;
+        u32 pending = 0;
         for (u32 k = 0; k < qb.n_cols; k++, e++) {
             const QuotientEntry qe = a.entries[e];
             ColDesc cd = a.cols[qe.col];
-            if (cd.shift == 0) {
-                uint4 v = ld16(as_global(cd.ptr) + row0);
-                num[0] = q_add(num[0], q_mulm(qe.c, v.x)); num[1] = q_add(num[1], q_mulm(qe.c, v.y));
-                num[2] = q_add(num[2], q_mulm(qe.c, v.z)); num[3] = q_add(num[3], q_mulm(qe.c, v.w));
-            } else {
-                Q31 t = q_mulm(qe.c, ld_col(cd, row0));    // shift >= 2: the 4 rows share one stored cell
+            if (pending == 3) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) num[r] = q_add(num[r], t);
+                for (int r = 0; r < 4; r++) { n64[r][0] = m_fold(n64[r][0]); n64[r][1] = m_fold(n64[r][1]); n64[r][2] = m_fold(n64[r][2]); n64[r][3] = m_fold(n64[r][3]); }
+                s64[0] = m_fold(s64[0]); s64[1] = m_fold(s64[1]); s64[2] = m_fold(s64[2]); s64[3] = m_fold(s64[3]);
+                pending = 0;
+            }
+            pending++;
+            const u32 c0 = qe.c.a.a, c1 = qe.c.a.b, c2 = qe.c.b.a, c3 = qe.c.b.b;
+            if (cd.shift == 0) {
+                const uint4 v = ld16(as_global(cd.ptr) + row0);
+                const u32 vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) { n64[r][0] += (u64)c0 * vr[r]; n64[r][1] += (u64)c1 * vr[r]; n64[r][2] += (u64)c2 * vr[r]; n64[r][3] += (u64)c3 * vr[r]; }
+            } else {
+                const u32 v = ld_col(cd, row0);            // shift >= 2: the 4 rows share one stored cell
+                s64[0] += (u64)c0 * v; s64[1] += (u64)c1 * v; s64[2] += (u64)c2 * v; s64[3] += (u64)c3 * v;
             }
         }
+        Q31 num[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            num[r] = q_make(m_canon(m_fold(n64[r][0]) + m_fold(s64[0])), m_canon(m_fold(n64[r][1]) + m_fold(s64[1])),
+                            m_canon(m_fold(n64[r][2]) + m_fold(s64[2])), m_canon(m_fold(n64[r][3]) + m_fold(s64[3])));
         C31 den[4]; u32 nrm[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
