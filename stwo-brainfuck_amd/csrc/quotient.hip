@@ -40,14 +40,21 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __r
     if (base < n) {
         if (n >= 16) {
             const uint4* src = reinterpret_cast<const uint4*>(job.coeffs + base);
+            // 16-term dot product (QM31 weights x M31 coefficients) in 64-bit accumulators with lazy reduction (m31.h)
+            u64 a64[4] = {0, 0, 0, 0};
 #pragma unroll
             for (u32 v4 = 0; v4 < 4; v4++) {
-                uint4 c = src[v4];
-                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 0), c.x));
-                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 1), c.y));
-                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 2), c.z));
-                acc = q_add(acc, q_mulm(ld_q(s_w, v4 * 4 + 3), c.w));
+                const uint4 c = src[v4];
+                const u32 cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (u32 j = 0; j < 4; j++) {
+                    const u32 idx = v4 * 4 + j;
+                    if (idx % 3 == 0 && idx) { a64[0] = m_fold(a64[0]); a64[1] = m_fold(a64[1]); a64[2] = m_fold(a64[2]); a64[3] = m_fold(a64[3]); }
+                    const Q31 w = ld_q(s_w, idx);
+                    a64[0] += (u64)w.a.a * cv[j]; a64[1] += (u64)w.a.b * cv[j]; a64[2] += (u64)w.b.a * cv[j]; a64[3] += (u64)w.b.b * cv[j];
+                }
             }
+            acc = q_make(m_canon(a64[0]), m_canon(a64[1]), m_canon(a64[2]), m_canon(a64[3]));
         } else {
             for (u32 k = 0; k < n; k++) acc = q_add(acc, q_mulm(ld_q(s_w, k), job.coeffs[k]));
         }
