@@ -47,6 +47,22 @@ template <class F> BF_HD Fq combine7(const Lookup& l, F a, F b, F c, F d, F e, F
            Fq{l.alpha_pow[5]} * f + Fq{l.alpha_pow[6]} * g - Fq{l.z};
 }
 
+// Base-field arguments (the constraint kernels: every LDE row): the sum alpha^i * v_i is a dot product of QM31 constants with M31
+// values — four 64-bit accumulators with lazy reduction (m31.h: m_fold / m_canon) instead of a modular multiply-add per term and
+// coordinate. Same canonical value as the generic form above (which the out-of-domain evaluator, F = QM31, keeps using).
+template <int N> BF_HD Fq combine_base(const Lookup& l, const u32 (&v)[N]) {
+    u64 acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (i && i % 3 == 0) { acc[0] = m_fold(acc[0]); acc[1] = m_fold(acc[1]); acc[2] = m_fold(acc[2]); acc[3] = m_fold(acc[3]); }
+        const Q31 a = l.alpha_pow[i];
+        acc[0] += (u64)a.a.a * v[i]; acc[1] += (u64)a.a.b * v[i]; acc[2] += (u64)a.b.a * v[i]; acc[3] += (u64)a.b.b * v[i];
+    }
+    return Fq{q_sub(q_make(m_canon(acc[0]), m_canon(acc[1]), m_canon(acc[2]), m_canon(acc[3])), l.z)};
+}
+BF_HD Fq combine3(const Lookup& l, Fm a, Fm b, Fm c) { const u32 v[3] = {a.v, b.v, c.v}; return combine_base<3>(l, v); }
+BF_HD Fq combine7(const Lookup& l, Fm a, Fm b, Fm c, Fm d, Fm e, Fm f, Fm g) { const u32 v[7] = {a.v, b.v, c.v, d.v, e.v, f.v, g.v}; return combine_base<7>(l, v); }
+
 // Evaluator concept E:
 //   typename E::F;  F is_first();  F trace();  F cst(u32);
 //   void constraint(F) / constraint(Fq);
