@@ -48,6 +48,12 @@ __device__ __forceinline__ void blake2s_compress(u32 h[8], const u32 m[16], u32 
 // Replication-aware: when every input of a layer is replicated (row-granular columns and/or a replicated child layer), nodes
 // i and i' with i >> out_shift == i' >> out_shift hash identical messages, so only 2^(log - out_shift) nodes are computed and
 // stored; readers index `node >> shift`. Hash values are exactly those of the full layer.
+// write-once data that the next launch (not this one) reads: non-temporal stores keep it from displacing the inputs in L2
+__device__ __forceinline__ void store_hash(uint4* __restrict__ out, u32 st, const u32 (&h)[8]) {
+    bf_u32x4 lo4 = {h[0], h[1], h[2], h[3]}, hi4 = {h[4], h[5], h[6], h[7]};
+    __builtin_nontemporal_store(lo4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st));
+    __builtin_nontemporal_store(hi4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st + 1));
+}
 __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
                                             u32 out_shift, u32 prev_shift) {
     const u32 i = st << out_shift;          // representative node of this stored slot
@@ -67,7 +73,7 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         done = 64;
         bool last = total_bytes == 64;
         blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
-        if (last) { out[2 * (size_t)st] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)st + 1] = make_uint4(h[4], h[5], h[6], h[7]); return; }
+        if (last) { store_hash(out, st, h); return; }
     }
     // remaining message: column values, 16 words per block (zero padded)
     for (;;) {
@@ -91,10 +97,7 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
         if (last) break;
     }
-    // write-once data that the next launch (not this one) reads: non-temporal stores keep it from displacing the inputs in L2
-    bf_u32x4 lo4 = {h[0], h[1], h[2], h[3]}, hi4 = {h[4], h[5], h[6], h[7]};
-    __builtin_nontemporal_store(lo4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st));
-    __builtin_nontemporal_store(hi4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st + 1));
+    store_hash(out, st, h);
 }
 // Grid-stride over the stored nodes: large layers give every lane several nodes, which amortises wave launch and the kernel prologue.
 // [first, first + n_stored) is the range of stored nodes this launch computes (the whole layer, or one rank's share of it).
