@@ -14,6 +14,8 @@ struct ColDesc { const u32* ptr; u32 shift; u32 pad_; };
 // prof.hip — optional per-kernel HIP-event timing (bench.py roofline)
 int prof_mode();
 void prof_enable(int mode);
+void prof_run_begin(hipStream_t s, const char* name);   // mode 2: one event pair for a run of back-to-back launches of one kernel
+void prof_run_end(hipStream_t s);
 void prof_begin(hipStream_t s, const char* name, double bytes);
 void prof_end(hipStream_t s);
 void prof_collect();

@@ -161,6 +161,7 @@ struct HipProver {
             int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
             if (hi >= lo) { mk.band_hi = hi; mk.band_lo = lo; }
         }
+        prof_run_begin(c.stream, "k_merkle_layer");
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
@@ -168,6 +169,7 @@ struct HipProver {
             merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
                          mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
             if (share && log == mk.band_lo) {
+                prof_run_end(c.stream);
                 const size_t slice = (size_t(32) << log) >> sg.log_count;
                 std::vector<u8> mine(slice), everyone(slice * sg.count);
                 c.read_back(mine.data(), reinterpret_cast<const u8*>(mk.layers[log]) + sg.rank * slice, slice);
@@ -177,6 +179,7 @@ struct HipProver {
                 BF_HIP(hipMemcpyAsync(mk.layers[log], staged, everyone.size(), hipMemcpyDeviceToDevice, c.stream));
             }
         }
+        prof_run_end(c.stream);
         if (fused_top > 0) merkle_top(c.stream, dl, fused_top);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
