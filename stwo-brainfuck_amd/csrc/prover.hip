@@ -530,19 +530,19 @@ struct HipProver {
         const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());   // one copy for the 13 parameter blocks
         for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k]);
         BF_HIP(hipGetLastError());
-        // finalize: ascending sizes; evaluate the running polynomial on the next populated size, add, interpolate
+        // finalize (DomainEvaluationAccumulator::finalize): ascending sizes; the reference evaluates the running polynomial on the next
+        // populated size, adds the evaluations and interpolates the sum. Interpolation is linear and evaluating a polynomial on a larger
+        // domain is zero-extension of its coefficients (CirclePoly::extend), so interpolate(values + evaluate(prev)) =
+        // interpolate(values) + extend(prev): one inverse transform per size and an addition over the *smaller* size — no forward
+        // transform, no full-size accumulate. Exact field arithmetic: the coefficients are the same.
         bool cur_have = false; std::vector<DCol> cur(4);
         for (u32 log = 1; log <= max_log; log++) {
             if (!have[log]) continue;
             std::vector<DCol> vals(4);
             for (int w = 0; w < 4; w++) { vals[w].ptr = acc[log].c[w]; vals[w].log_size = log; vals[w].shift = 0; }
-            if (cur_have) {
-                std::vector<DCol> tmp(4);
-                for (int w = 0; w < 4; w++) { tmp[w].log_size = log; tmp[w].shift = 0; tmp[w].ptr = c.alloc_u32(size_t(1) << log); }
-                fft_cols(false, cur, tmp);
-                for (int w = 0; w < 4; w++) accumulate(c.stream, vals[w].ptr, tmp[w].ptr, 1u << log);
-            }
             fft_cols(true, vals, vals);
+            if (cur_have)
+                for (int w = 0; w < 4; w++) accumulate(c.stream, vals[w].ptr, cur[w].ptr, 1u << cur[w].log_size);
             cur = vals; cur_have = true;
         }
         trees[3].polys = cur;
