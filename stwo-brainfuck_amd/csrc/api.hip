@@ -263,7 +263,7 @@ int32_t bfhip_gather(bfhip_ctx* ctx, const uint32_t* col_d, const uint64_t* idx_
     API_CTX(ctx)
     Ctx& c = ctx->c;
     std::vector<GatherReq> req(n);
-    for (size_t i = 0; i < n; i++) req[i] = GatherReq{col_d, idx_h[i]};
+    for (size_t i = 0; i < n; i++) req[i] = GatherReq{col_d, idx_h[i], (u32)i, 1u};
     GatherReq* dreq = nullptr; u32* dout = nullptr;
     BF_HIP(hipMalloc((void**)&dreq, sizeof(GatherReq) * (n + 1)));
     hipError_t e = hipMalloc((void**)&dout, sizeof(u32) * (n + 1));

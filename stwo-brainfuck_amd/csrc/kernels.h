@@ -103,7 +103,8 @@ void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
 // fresh: dst holds nothing yet (treated as zero, not read)
 void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh = false);
 void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
-struct GatherReq { const u32* base; u64 index; };
+// out[out_off + w] = base[index + w] for w < n_words (n_words = 1: a column cell, 8: a hash); base == nullptr reads as zeros
+struct GatherReq { const u32* base; u64 index; u32 out_off; u32 n_words; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);
 void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n);

@@ -37,22 +37,23 @@ struct DSecure { u32* c[4]; u32 log_size; };
 
 struct Gather {
     std::vector<GatherReq> reqs;
-    size_t add(const u32* base, u64 idx) { reqs.push_back({base, idx}); return reqs.size() - 1; }
+    u32 n_words = 0;
+    // each returns the position of the first gathered word in the output of run()
+    size_t add(const u32* base, u64 idx) { reqs.push_back({base, idx, n_words, 1u}); n_words += 1; return n_words - 1; }
+    size_t add_hash(const u32* layer, u64 node_slot, bool mine) { reqs.push_back({mine ? layer : nullptr, node_slot * 8, n_words, 8u}); n_words += 8; return n_words - 8; }
     size_t add_col(const DCol& col, u64 cell) { return add(col.ptr, cell >> col.shift); }
     std::vector<u32> run(Ctx& c) {
-        std::vector<u32> out(reqs.size());
-        const size_t CH = 32768;
-        for (size_t o = 0; o < reqs.size(); o += CH) {
-            size_t n = std::min(CH, reqs.size() - o);
-            c.stage_checkpoint();
-            GatherReq* d = c.stage(reqs.data() + o, n);
-            u32* dout = c.alloc_u32(n);
-            gather_u32(c.stream, d, (u32)n, dout);
-            c.read_back(out.data() + o, dout, n * sizeof(u32));
-        }
+        std::vector<u32> out(n_words);
+        if (reqs.empty()) return out;
+        c.stage_checkpoint();
+        if (reqs.size() * sizeof(GatherReq) > c.stage_bytes / 4) throw HipError("decommitment: too many gather requests");
+        GatherReq* d = c.stage(reqs.data(), reqs.size());
+        u32* dout = c.alloc_u32(n_words);
+        gather_u32(c.stream, d, (u32)reqs.size(), dout);
+        c.read_back(out.data(), dout, n_words * sizeof(u32));
         // shard group: every word is either identical on all ranks (column values, complete layers) or held by one rank and zero
         // elsewhere (hashes of share-wise layers) — an element-wise maximum completes it everywhere
-        if (c.shard.count > 1 && !out.empty() && c.shard.allreduce_max(c.shard.user, out.data(), out.size()) != 0) throw HipError("shard group: all-reduce failed");
+        if (c.shard.count > 1 && c.shard.allreduce_max(c.shard.user, out.data(), out.size()) != 0) throw HipError("shard group: all-reduce failed");
         return out;
     }
 };
@@ -193,21 +194,27 @@ struct HipProver {
     typedef std::function<void(const std::vector<u32>&)> Finisher;
     Finisher decommit(Gather& g, const DevMerkle& mk, const std::vector<DCol>& cols_in, const std::map<u32, std::vector<size_t>>& queries_per_log,
                       std::vector<u32>* queried_values, MerkleDecommitment* dec) {
-        std::vector<DCol> cols = cols_in;
-        std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
+        // host time matters here (the GPU is idle while the decommitment is planned): no per-layer allocations, no copy when the
+        // columns already come in descending size order
+        auto by_size = [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; };
+        std::vector<DCol> sorted_copy;
+        if (!std::is_sorted(cols_in.begin(), cols_in.end(), by_size)) { sorted_copy = cols_in; std::stable_sort(sorted_copy.begin(), sorted_copy.end(), by_size); }
+        const std::vector<DCol>& cols = sorted_copy.empty() ? cols_in : sorted_copy;
         struct Slot { int kind; size_t first; };   // kind 0: hash witness (8 words), 1: column witness, 2: queried value
         std::vector<Slot> slots;
+        slots.reserve(256);
         size_t ci = 0;
-        std::vector<size_t> last;
+        std::vector<size_t> last, total;
+        std::vector<DCol> lc;
         static const std::vector<size_t> empty;
         for (int log = (int)mk.max_log; log >= 0; log--) {
-            std::vector<DCol> lc;
+            lc.clear();
             while (ci < cols.size() && cols[ci].log_size == (u32)log) lc.push_back(cols[ci++]);
             const u32* prev_hashes = log < (int)mk.max_log ? mk.layers[log + 1] : nullptr;
             const u32 prev_shift = log < (int)mk.max_log ? mk.shifts[log + 1] : 0;
             auto it = queries_per_log.find((u32)log);
             const std::vector<size_t>& colq = it == queries_per_log.end() ? empty : it->second;
-            std::vector<size_t> total;
+            total.clear();
             size_t pi = 0, qi = 0;
             while (pi < last.size() || qi < colq.size()) {
                 size_t node;
@@ -221,9 +228,7 @@ struct HipProver {
                             // in a shard group a hash of a share-wise layer is held by one rank only; the others request a zero
                             const bool shared_layer = log + 1 > mk.band_lo && log + 1 <= mk.band_hi;
                             const bool mine = !shared_layer || (child >> (log + 1 - c.shard.log_count)) == c.shard.rank;
-                            size_t f = g.reqs.size();
-                            for (u32 w = 0; w < 8; w++) g.add(mine ? prev_hashes : nullptr, (child >> prev_shift) * 8 + w);
-                            slots.push_back({0, f});
+                            slots.push_back({0, g.add_hash(prev_hashes, child >> prev_shift, mine)});
                         }
                     }
                 }
@@ -232,9 +237,9 @@ struct HipProver {
                 for (auto& col : lc) { size_t f = g.add_col(col, node); slots.push_back({queried ? 2 : 1, f}); }
                 total.push_back(node);
             }
-            last = total;
+            std::swap(last, total);
         }
-        return [slots, queried_values, dec](const std::vector<u32>& data) {
+        return [slots = std::move(slots), queried_values, dec](const std::vector<u32>& data) {
             for (auto& s : slots) {
                 if (s.kind == 0) { Hash32 h; memcpy(h.b, &data[s.first], 32); dec->hash_witness.push_back(h); }
                 else if (s.kind == 1) dec->column_witness.push_back(data[s.first]);
@@ -651,7 +656,7 @@ struct HipProver {
         }
     }
     Finisher gather_secure_deferred(Gather& g, const DSecure& s, const std::vector<size_t>& pos, std::vector<Q31>* out) {
-        size_t first = g.reqs.size();
+        size_t first = g.n_words;
         for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
         size_t n = pos.size();
         return [first, n, out](const std::vector<u32>& d) { for (size_t k = 0; k < n; k++) out->push_back(q_make(d[first + 4 * k], d[first + 4 * k + 1], d[first + 4 * k + 2], d[first + 4 * k + 3])); };

@@ -270,7 +270,8 @@ __global__ void k_gather(const GatherReq* __restrict__ req, u32 n, u32* __restri
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     GatherReq r = req[j];
-    out[j] = r.base ? r.base[r.index] : 0u;      // null base: a word another rank of the shard group owns (filled in by the max-reduce)
+    // null base: words another rank of the shard group owns (filled in by the max-reduce)
+    for (u32 w = 0; w < r.n_words; w++) out[r.out_off + w] = r.base ? r.base[r.index + w] : 0u;
 }
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out) {
     if (!n) return;
