@@ -106,6 +106,24 @@ def test_fib19_full_size_proof_verifies(pkg, oracle):
         c.close()
 
 
+def test_synthetic_2_to_26_row_trace_verifies(pkg, oracle):
+    """BASELINE configs 3-5 family: a nested-counter program whose Memory component has 2^22 table rows = 2^26 domain rows, proved with
+    the raised LOG_MAX_ROWS = 26 (2.3 * 10^9 trace cells, transforms up to 2^28 cells). No CPU proof at this size: the oracle's
+    verifier and the product's own verifier must accept, and a shard group of two must reproduce the same bytes."""
+    code = "+" * 14 + "[>" + "+" * 16000 + "[>+<-]<-]"
+    c = pkg.Context(0, max_log_domain=28)
+    try:
+        tr = pkg.Trace(c, code, b"")
+        assert max(tr.log_sizes) == 26 and tr.cells > 2 * 10**9
+        proof, _ = tr.prove(26)
+        tr.close()
+    finally:
+        c.close()
+    ok, err = oracle.verify(proof, 26)
+    assert ok, err
+    assert pkg.verify_brainfuck(proof, 26) == (True, "")
+
+
 def test_bad_program_reports_error(ctx, pkg):
     with pytest.raises(pkg.BfhipError):
         pkg.prove_brainfuck("+]", b"", ctx=ctx, log_max_rows=20)      # unbalanced bracket
