@@ -109,7 +109,7 @@ def test_fib19_full_size_proof_verifies(pkg, oracle):
 def test_synthetic_2_to_26_row_trace_verifies(pkg, oracle):
     """BASELINE configs 3-5 family: a nested-counter program whose Memory component has 2^22 table rows = 2^26 domain rows, proved with
     the raised LOG_MAX_ROWS = 26 (2.3 * 10^9 trace cells, transforms up to 2^28 cells). No CPU proof at this size: the oracle's
-    verifier and the product's own verifier must accept, and a shard group of two must reproduce the same bytes."""
+    verifier and the product's own verifier must accept."""
     code = "+" * 14 + "[>" + "+" * 16000 + "[>+<-]<-]"
     c = pkg.Context(0, max_log_domain=28)
     try:
