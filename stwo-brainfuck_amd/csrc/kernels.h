@@ -65,7 +65,8 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
 // first/count: range of stored nodes to compute (count == 0: the whole layer) — a rank of a shard group computes its share only
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
                   u32 first = 0, u32 count = 0);
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log);
+// d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32* d_chan = nullptr, u32* d_alpha8 = nullptr, u32* d_root_copy = nullptr);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.

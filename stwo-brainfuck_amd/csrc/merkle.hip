@@ -135,53 +135,11 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
     for (; st < n_stored; st += stride) merkle_node(first + st, out, prev, cols, ncols, out_shift, prev_shift);
 }
 
-// Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
-__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log) {
-    for (int lg = (int)top_log - 1; lg >= 0; lg--) {
-        const uint4* prev = layers[lg + 1];
-        uint4* out = layers[lg];
-        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
-            u32 h[8], m[16];
-#pragma unroll
-            for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
-            h[0] ^= 0x01010020u;
-            uint4 a = prev[4 * i], b = prev[4 * i + 1], c = prev[4 * i + 2], d = prev[4 * i + 3];
-            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
-            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-            blake2s_compress(h, m, 64, 0xFFFFFFFFu);
-            out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
-#ifndef MERKLE_NODES_PER_LANE
-#define MERKLE_NODES_PER_LANE 4
-#endif
-// col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
-void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
-                  u32 first, u32 count) {
-    const u32 total = (1u << log) >> out_shift;
-    const u32 n = count ? count : total;                 // count == 0: the whole layer
-    u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
-    const double frac = (double)n / (double)total;
-    ProfScope ps(stream, "k_merkle_layer", ((prev ? 64.0 * total : 0.0) + 32.0 * total + col_bytes) * frac);
-    u32 blocks = (n + threads - 1) / threads;
-    if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
-    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u);
-}
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log) {
-    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));
-    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log);
-}
-
 // Blake2sChannel stepped on the device for the FRI commit phase (FriProver::commit: mix_root(layer root) then draw_felt per layer):
 // removes the device -> host -> device round trip between consecutive layers. One lane; two compressions plus rare redraws.
 // chan = digest[8] || n_sent. alpha_out = alpha[4] || alpha^2[4]. root_out receives a copy of the root (the roots of all layers are
 // collected in one array and read back once).
-__global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out) {
-    if (threadIdx.x || blockIdx.x) return;
+__device__ void channel_step(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out) {
     u32 h[8], m[16], digest[8];
     // mix_root: digest = Blake2s(digest || root), n_sent = 0
     for (int k = 0; k < 8; k++) { m[k] = chan[k]; m[8 + k] = root[k]; root_out[k] = root[k]; h[k] = B2S_IV[k]; }   // root_out: contiguous copy for one read-back
@@ -206,6 +164,55 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
     for (int k = 0; k < 8; k++) chan[k] = digest[k];
     chan[8] = n_sent;
 }
+__global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    channel_step(chan, root, alpha_out, root_out);
+}
+
+// Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
+// With chan != nullptr the workgroup's first lane then performs the channel step on the fresh root (FRI commit phase): one launch less
+// per layer on the latency-bound path root -> alpha -> next fold.
+__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log, u32* chan, u32* alpha_out, u32* root_out) {
+    for (int lg = (int)top_log - 1; lg >= 0; lg--) {
+        const uint4* prev = layers[lg + 1];
+        uint4* out = layers[lg];
+        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
+            u32 h[8], m[16];
+#pragma unroll
+            for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
+            h[0] ^= 0x01010020u;
+            uint4 a = prev[4 * i], b = prev[4 * i + 1], c = prev[4 * i + 2], d = prev[4 * i + 3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+            blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+            out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (chan && threadIdx.x == 0) channel_step(chan, reinterpret_cast<const u32*>(layers[0]), alpha_out, root_out);
+}
+
+#ifndef MERKLE_NODES_PER_LANE
+#define MERKLE_NODES_PER_LANE 4
+#endif
+// col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
+void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
+                  u32 first, u32 count) {
+    const u32 total = (1u << log) >> out_shift;
+    const u32 n = count ? count : total;                 // count == 0: the whole layer
+    u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
+    const double frac = (double)n / (double)total;
+    ProfScope ps(stream, "k_merkle_layer", ((prev ? 64.0 * total : 0.0) + 32.0 * total + col_bytes) * frac);
+    u32 blocks = (n + threads - 1) / threads;
+    if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
+    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u);
+}
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32* d_chan, u32* d_alpha8, u32* d_root_copy) {
+    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log, d_chan, d_alpha8, d_root_copy);
+}
+
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {
     hipLaunchKernelGGL(k_channel_mix_root_draw, dim3(1), dim3(64), 0, stream, d_chan, d_root, d_alpha8, d_root_copy);
 }

@@ -125,7 +125,9 @@ struct HipProver {
     // ---- Merkle (a4) -----------------------------------------------------------------------------------------------------------
     // defer_root: leave the 32-byte root copy pending in pinned memory (*pinned_root) instead of synchronising the stream.
     // no_readback: the root stays on the device (the caller collects it; FRI commit phase).
-    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false) {
+    // step: FRI commit phase — the device channel mixes the root and draws the next alpha right behind the tree (fused into the top kernel).
+    struct ChannelStep { u32* chan; u32* alpha8; u32* root_copy; };
+    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
         std::vector<DCol> cols = cols_in;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
         c.stage_checkpoint();
@@ -181,7 +183,8 @@ struct HipProver {
             }
         }
         prof_run_end(c.stream);
-        if (fused_top > 0) merkle_top(c.stream, dl, fused_top);
+        if (fused_top > 0) merkle_top(c.stream, dl, fused_top, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
+        else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
         if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
@@ -691,9 +694,9 @@ struct HipProver {
         u32* d_roots = c.alloc_u32(8 * (max_layers + 1));                                        // root copies, read back once
         memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
         BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
-        DevMerkle first_tree = merkle_commit(first_cols, nullptr, /*no_readback=*/true);
         u32 cur_alpha = 0;
-        channel_mix_root_draw(c.stream, d_chan, first_tree.layers[0], d_alpha, d_roots);
+        ChannelStep step0{d_chan, d_alpha, d_roots};
+        DevMerkle first_tree = merkle_commit(first_cols, nullptr, /*no_readback=*/true, &step0);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
@@ -711,9 +714,9 @@ struct HipProver {
                 qi++;
             }
             Inner in; in.ev = layer;
-            in.tree = merkle_commit(secure_cols(layer), nullptr, /*no_readback=*/true);
             cur_alpha++;
-            channel_mix_root_draw(c.stream, d_chan, in.tree.layers[0], d_alpha + 8 * cur_alpha, d_roots + 8 * (1 + inner.size()));
+            ChannelStep step{d_chan, d_alpha + 8 * cur_alpha, d_roots + 8 * (1 + inner.size())};
+            in.tree = merkle_commit(secure_cols(layer), nullptr, /*no_readback=*/true, &step);
             DSecure next; next.log_size = line_log - 1;
             for (int w = 0; w < 4; w++) next.c[w] = c.alloc_u32(size_t(1) << (line_log - 1));
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
