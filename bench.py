@@ -70,6 +70,14 @@ def cpu_baseline():
                       f"({', '.join(tried)}), best reported" + note}
 
 
+def pick_device(local_rank, n_visible, override=None):
+    """One process per GPU: rank r drives device LOCAL_RANK. A launcher that narrows each rank's view to its own GPU
+    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) leaves one visible device, numbered 0, on every rank."""
+    if override is not None:
+        return override
+    return local_rank if local_rank < n_visible else local_rank % max(n_visible, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +105,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        device = local_rank if args.device is None else args.device
+        device = pick_device(local_rank, torch.cuda.device_count(), args.device)
         torch.cuda.set_device(device)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
@@ -107,7 +115,7 @@ def main():
     pkg = load_package()
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    device = local_rank if args.device is None else args.device
+    device = pick_device(local_rank, pkg.device_count(), args.device)
     ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK
     trace = pkg.Trace(ctx, FIB19, b"")          # VM + table build + upload: outside the timed region (inputs resident in HBM)
     lib = pkg.lib()
