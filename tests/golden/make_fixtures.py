@@ -19,6 +19,21 @@ TRACE_A = [
 PROC_A = [r + [0, TRACE_A[i + 1][0] if i + 1 < len(TRACE_A) else 12] for i, r in enumerate(TRACE_A)]
 PROC_A += [[12 + k, 13, 0, 0, 0, 0, 0, 1, 13 + k] for k in range(4)]
 
+# instruction/table.rs:611-744: entries (ip, ci, ni) of "+>,<[>+.<-]" with input [1]; executed instructions appear twice (program + trace)
+_A = [(0, 43, 62), (1, 62, 44), (2, 44, 60), (3, 60, 91), (4, 91, 12)]
+INS_A = [list(e) + [0] for e in _A for _ in range(2)] + [[5, 12, 62, 0]] + \
+        [list(e) + [0] for e in [(6, 62, 43), (7, 43, 46), (8, 46, 60), (9, 60, 45), (10, 45, 93), (11, 93, 6)] for _ in range(2)] + \
+        [[12, 6, 0, 0], [13, 0, 0, 0]] + [[13, 0, 0, 1]] * 7
+# instruction/table.rs:746-804: "[-]" with no input — only the first instruction is executed
+INS_B = [[0, 91, 4, 0], [0, 91, 4, 0], [1, 4, 45, 0], [2, 45, 93, 0], [3, 93, 2, 0], [4, 2, 0, 0], [5, 0, 0, 0], [5, 0, 0, 1]]
+
+
+def pair_rows(entries):
+    """InstructionTable::from(intermediate) — instruction/table.rs:116-145."""
+    nxt = entries[1:] + [[entries[-1][0], 0, 0, 1]]
+    return [a + b for a, b in zip(entries, nxt)]
+
+
 vectors = {
     "compile": [  # crates/brainfuck_vm/src/compiler.rs:62-79
         {"code": "++>,<[>+.<-]", "expected": [43, 43, 62, 44, 60, 91, 13, 62, 43, 46, 60, 45, 93, 7]},
@@ -56,6 +71,21 @@ vectors = {
          "component": 4, "code": "++>,<[>+.<-]", "input": [1],
          # (clk, ip, ci, ni, mp, mv, mvi, next_clk, next_ip, next_mp, next_mv, d, is_mv_zero)
          "expected": [[11, 12, 93, 7, 0, 1, 1, 12, 7, 0, 1, 0, 0], [17, 12, 93, 7, 0, 0, 0, 18, 14, 0, 0, 0, 1]]},
+        # Instruction table: the reference test pins the *intermediate* table (ip, ci, ni, d): program and trace merged, sorted by
+        # (ip, clk), padded with dummies (d = 1) to a power of two; the table row is (entry r || entry r+1) and the last row pairs
+        # with new_dummy(last ip) (instruction/table.rs:116-145). The expected rows below are that pairing applied to the pinned entries.
+        {"cite": "crates/brainfuck_prover/src/components/instruction/table.rs:611-744 (test_instruction_intermediate_table_from_registers_example_program) + pairing :116-145",
+         "component": 1, "code": "+>,<[>+.<-]", "input": [1], "expected": pair_rows(INS_A)},
+        {"cite": "crates/brainfuck_prover/src/components/instruction/table.rs:746-804 (test_instruction_table_program_unused_instruction) + pairing :116-145",
+         "component": 1, "code": "[-]", "input": [], "expected": pair_rows(INS_B)},
+        {"cite": "crates/brainfuck_prover/src/components/program/table.rs:357-382 (test_program_table_from_program_memory)",
+         "component": 2, "code": "+>-", "input": [1],
+         # (ip, ci, ni, d); the padding row is new_dummy(last ip)
+         "expected": [[0, 43, 62, 0], [1, 62, 45, 0], [2, 45, 0, 0], [2, 0, 0, 1]]},
+        {"cite": "crates/brainfuck_prover/src/components/processor/instructions/end_of_execution/table.rs:339-370 (test_end_of_execution_table_from_registers_example_program)",
+         "component": 12, "code": "+>,<[>+.<-]", "input": [1],
+         # (clk, ip, ci, ni, mp, mv, mvi)
+         "expected": [[11, 13, 0, 0, 0, 0, 0]]},
     ],
     # component log sizes measured for the bundled programs — SURVEY.md Appendix A.3 (derived from the reference's padding rules)
     "log_sizes": [

@@ -53,3 +53,26 @@ def test_proof_identical_with_either_table_builder(pkg, oracle, big_ctx):
     assert a == b
     want, _, _ = oracle.prove(code, inp, log_max_rows=17)
     assert b == want
+
+
+def _golden_tables():
+    import json
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    return [t for t in v["tables"] if "code" in t]
+
+
+@pytest.mark.parametrize("v", _golden_tables(), ids=lambda v: f"component{v['component']}:{v['code']}")
+def test_gpu_tables_match_the_reference_vectors(pkg, big_ctx, v):
+    """The device table builders against the rows the reference's own unit tests pin (tests/golden/reference_vectors.json: processor,
+    left, jump-if-not-zero, instruction x2, program, end-of-execution) — the same vectors that pin the oracle and the host builders."""
+    pkg.set_table_builder(True)
+    t = pkg.Trace(big_ctx, v["code"], bytes(v["input"]))
+    try:
+        want = np.array(v["expected"], dtype=np.uint32)
+        got = np.stack([t.column(v["component"], c) for c in range(want.shape[1])], axis=1)
+        assert got.shape[0] >= want.shape[0]
+        assert np.array_equal(got[: want.shape[0]], want)
+        if got.shape[0] > want.shape[0]:      # fixtures of the per-instruction tables list the real rows only; the rest is padding (d = 1)
+            assert v["component"] in (4, 5, 6, 7, 8, 9, 10, 11)
+    finally:
+        t.close()
