@@ -30,7 +30,8 @@ int32_t bfhip_device_count(void);
 
 /* Context: owns the stream, the twiddle tree and scratch memory.
  * max_log_domain = log2 of the largest evaluation domain that will be used (reference: LOG_MAX_ROWS + log_blowup + 1 = 26, since
- * SimdBackend::precompute_twiddles(CanonicCoset::new(LOG_MAX_ROWS + log_blowup + 2).circle_domain().half_coset), mod.rs:480-484). */
+ * SimdBackend::precompute_twiddles(CanonicCoset::new(LOG_MAX_ROWS + log_blowup + 2).circle_domain().half_coset), mod.rs:480-484).
+ * Range [6, 29]: columns of up to 2^29 cells (LOG_MAX_ROWS <= 27). */
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);

@@ -21,7 +21,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device: the bfhip backend has no CPU fallback");
     if (dev < 0 || dev >= n) throw HipError("bad device id");
-    if (max_log_domain < 6 || max_log_domain > 30) throw HipError("max_log_domain out of range [6, 30]");
+    // columns are addressed with 32-bit byte offsets (kernels.h: ld_col): at most 2^29 cells per column
+    if (max_log_domain < 6 || max_log_domain > 29) throw HipError("max_log_domain out of range [6, 29]");
     device = dev;
     BF_HIP(hipSetDevice(dev));
     BF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
