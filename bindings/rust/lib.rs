@@ -1,0 +1,73 @@
+//! Safe Rust wrapper over `libbfhip.so` — the whole-path entry points of the MI355X backend (source only: the build image has no
+//! Rust toolchain). `bfhip_sys.rs` is generated from `include/bfhip.h` by `tools/gen_rust_ffi.py`.
+//!
+//! In `crates/brainfuck_prover` this replaces the body of `prove_brainfuck` (`brainfuck_air/mod.rs:471`):
+//! ```ignore
+//! let ctx = bfhip::Context::new(0, LOG_MAX_ROWS + 2)?;
+//! let json = ctx.prove_brainfuck(&code, &input, LOG_MAX_ROWS)?;
+//! let proof: BrainfuckProof<Blake2sMerkleHasher> = serde_json::from_slice(&json)?;   // same serde shape (mod.rs:71-99)
+//! ```
+#[path = "bfhip_sys.rs"]
+pub mod sys;
+
+use std::ffi::{c_char, c_void, CStr, CString};
+
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(sys::bfhip_last_error()).to_string_lossy().into_owned() }
+}
+
+/// One GPU + one HIP stream + the twiddle tree (`mod.rs:480-487`). Calls on a context are serial.
+pub struct Context(*mut sys::BfhipCtx);
+
+// A context may be moved to another thread; every entry point binds the calling thread to the context's GPU.
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn new(device_id: i32, max_log_domain: u32) -> Result<Self, String> {
+        let mut p = std::ptr::null_mut();
+        if unsafe { sys::bfhip_ctx_create(device_id, max_log_domain, &mut p) } != 0 {
+            return Err(last_error());
+        }
+        Ok(Context(p))
+    }
+
+    /// `prove_brainfuck` (`mod.rs:471-735`): compile, run, build the tables, commit, prove. Returns the serde-JSON proof bytes.
+    pub fn prove_brainfuck(&self, code: &str, input: &[u8], log_max_rows: u32) -> Result<Vec<u8>, String> {
+        let code = CString::new(code).map_err(|e| e.to_string())?;
+        let (mut js, mut len): (*mut c_char, usize) = (std::ptr::null_mut(), 0);
+        let rc = unsafe {
+            sys::bfhip_prove_brainfuck(self.0, code.as_ptr(), input.as_ptr(), input.len(), log_max_rows, &mut js, &mut len,
+                                       std::ptr::null_mut(), std::ptr::null_mut())
+        };
+        if rc != 0 {
+            return Err(last_error());   // "ConstraintsNotSatisfied", "a component exceeds LOG_MAX_ROWS", HIP errors, ...
+        }
+        let out = unsafe { std::slice::from_raw_parts(js as *const u8, len) }.to_vec();
+        unsafe { sys::bfhip_free_host(js as *mut c_void) };
+        Ok(out)
+    }
+
+    /// Keep the program-independent preprocessed tree across proofs (the reference recommits it in every call).
+    pub fn reuse_preprocessed(&self, on: bool) {
+        unsafe { sys::bfhip_ctx_reuse_preprocessed(self.0, on as i32) };
+    }
+}
+
+impl Drop for Context {
+    fn drop(&mut self) {
+        unsafe { sys::bfhip_ctx_destroy(self.0) };
+    }
+}
+
+/// `verify_brainfuck` (`mod.rs:738-797`), host only. `Err` carries the rejection reason.
+pub fn verify_brainfuck(proof_json: &[u8], log_max_rows: u32) -> Result<(), String> {
+    let mut err = vec![0u8; 256];
+    let rc = unsafe {
+        sys::bfhip_verify_brainfuck(proof_json.as_ptr() as *const c_char, proof_json.len(), log_max_rows, err.as_mut_ptr() as *mut c_char, err.len())
+    };
+    if rc == 0 {
+        Ok(())
+    } else {
+        Err(unsafe { CStr::from_ptr(err.as_ptr() as *const c_char) }.to_string_lossy().into_owned())
+    }
+}

@@ -89,3 +89,17 @@ def test_replicas_protocol_gloo_world2(tmp_path):
                         str(script), ROOT], capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_rust_ffi_is_in_step_with_the_header():
+    """bindings/rust/bfhip_sys.rs is generated from include/bfhip.h (tools/gen_rust_ffi.py): regenerating must reproduce the committed
+    file, and it must declare every function the header declares."""
+    import re
+    committed = open(os.path.join(ROOT, "bindings", "rust", "bfhip_sys.rs")).read()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_ffi.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(os.path.join(ROOT, "bindings", "rust", "bfhip_sys.rs")).read() == committed, "bfhip_sys.rs is stale: run tools/gen_rust_ffi.py"
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bfhip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(bfhip_\w+)\s*\(", header)) - {"bfhip_allgather_fn", "bfhip_allreduce_max_u32_fn"}
+    in_rust = set(re.findall(r"pub fn (bfhip_\w+)\(", committed))
+    assert declared == in_rust, declared ^ in_rust
