@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
 }
 
 template <bool INV>
-__global__ void __launch_bounds__(128, 4) k_fft_strided7(PassArgs a) {
+__global__ void __launch_bounds__(128, 3) k_fft_strided7(PassArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_val[4096];
     __shared__ u32 s_tw[128];
     const u32 t = threadIdx.x, lo = a.lo, tile = blockIdx.x;
