@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(128, 3) k_fft_strided7(PassArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 u32 m = 8 * e + mlow;
-                v[e] = from_global ? src[(base | (m << lo) | l) & a.src_mask] : s_val[32 * m + l];
+                v[e] = from_global ? __builtin_nontemporal_load(src + ((base | (m << lo) | l) & a.src_mask)) : s_val[32 * m + l];
             }
             radix16<INV>(v, 4, [&](int jl, int pe) -> u32 { return TW(3 + jl, pe); });
 #pragma unroll
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(128, 3) k_fft_strided7(PassArgs a) {
         if (INV) {
             u32 r[8][4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { uint4 v = ld16(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+            for (int q = 0; q < 8; q++) { uint4 v = ld16_stream(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
             wide_stage(r);
 #pragma unroll
             for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);

@@ -44,6 +44,7 @@ typedef const BF_GLOBAL u32* g_cu32p;
 __device__ __forceinline__ g_cu32p as_global(const u32* p) { return (g_cu32p)(unsigned long long)p; }
 __device__ __forceinline__ g_u32p as_global(u32* p) { return (g_u32p)(unsigned long long)p; }
 __device__ __forceinline__ uint4 ld16(g_cu32p p) { bf_u32x4 v = *(const BF_GLOBAL bf_u32x4*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 ld16_stream(g_cu32p p) { bf_u32x4 v = __builtin_nontemporal_load((const BF_GLOBAL bf_u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void st16(g_u32p p, uint4 v) { bf_u32x4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (BF_GLOBAL bf_u32x4*)p); }   // streamed: no reuse before eviction
 // value of cell i of a column: 32-bit byte offset (columns hold < 2^30 cells) on the descriptor's base pointer
 __device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
