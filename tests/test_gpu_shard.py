@@ -94,3 +94,35 @@ def test_shard_arguments_are_checked(pkg, ctx):
     with pytest.raises(pkg.BfhipError, match="rank"):
         ctx.set_shard(2, 2, lambda b: b, lambda v: v)
     ctx.set_shard(0, 1)
+
+
+def test_independent_contexts_prove_concurrently(pkg, oracle):
+    """Two contexts on one GPU driven from two host threads at the same time (bench.py --inflight): each proves its own program and
+    gets exactly the proof it gets alone — no shared mutable state between contexts."""
+    jobs = [("hello_kakarot.bf", b"", 17), ("collatz.bf", b"7\n", 21)]
+    codes = [open(os.path.join(PROGS, n)).read() for n, _, _ in jobs]
+    alone = []
+    for (name, inp, lmr), code in zip(jobs, codes):
+        c = pkg.Context(0, max_log_domain=lmr + 2)
+        alone.append(pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr))
+        c.close()
+    ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _, _, lmr in jobs]
+    out, errors = [[None] * 4, [None] * 4], []
+
+    def run(k):
+        try:
+            for r in range(4):
+                out[k][r] = pkg.prove_brainfuck(codes[k], jobs[k][1], ctx=ctxs[k], log_max_rows=jobs[k][2])
+        except Exception as e:
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
+    for k in range(2):
+        assert all(p == alone[k] for p in out[k])
