@@ -65,9 +65,9 @@ pub fn verify_brainfuck(proof_json: &[u8], log_max_rows: u32) -> Result<(), Stri
     let rc = unsafe {
         sys::bfhip_verify_brainfuck(proof_json.as_ptr() as *const c_char, proof_json.len(), log_max_rows, err.as_mut_ptr() as *mut c_char, err.len())
     };
-    if rc == 0 {
-        Ok(())
-    } else {
-        Err(unsafe { CStr::from_ptr(err.as_ptr() as *const c_char) }.to_string_lossy().into_owned())
+    match rc {
+        0 => Ok(()),
+        1 => Err(unsafe { CStr::from_ptr(err.as_ptr() as *const c_char) }.to_string_lossy().into_owned()),   // rejected: VerificationError name
+        _ => Err(last_error()),                                                                                // internal error
     }
 }

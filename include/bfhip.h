@@ -24,6 +24,30 @@ extern "C" {
 typedef struct bfhip_ctx bfhip_ctx;
 typedef struct bfhip_trace bfhip_trace;
 
+/* Byte-level conventions of the un-vendored stwo-prover @ 31e8dbc (Cargo.toml:41) that cannot be confirmed offline (SURVEY.md Appendix B.2;
+ * DESIGN.md section 6 lists every such point). Each is one named switch so that a comparison against a real stwo proof can flip one at a
+ * time. The zero value of every field is the default = the published stwo code of that period to the best of our reconstruction.
+ *  merkle_node_hash  Blake2sMerkleHasher::hash_node (core/vcs/blake2_merkle.rs), used by Blake2sMerkleChannel (mod.rs:56,486-487):
+ *      BFHIP_MERKLE_STWO_COMPRESS  state = 0^32; if children: state = compress(state, left || right, 0,0,0,0); then for the column values
+ *                                  in zero-padded chunks of 16 words: state = compress(state, chunk, 0,0,0,0). No parameter block, byte
+ *                                  counter or final flag (blake2s_ref::compress is the bare RFC 7693 F function).
+ *      BFHIP_MERKLE_RFC7693        node = Blake2s-256(left || right || LE u32 values), the standard hash of the same byte string.
+ *  mix_u64           Blake2sChannel::mix_u64 (core/channel/blake2s.rs), used for the claim (components/mod.rs:133) and the proof of work:
+ *      BFHIP_MIX_U64_COMPRESS      digest = compress(digest words, [n_lo, n_hi, 0 x 14], 0,0,0,0) — what SimdBackend's grind searches.
+ *      BFHIP_MIX_U64_HASH          digest = Blake2s-256(digest || LE64(n) zero padded to 32 bytes) (form of older revisions).
+ *  logup_mask_order  mask offsets of each component's last logUp column in LogupAtRow::finalize (reached from finalize_logup(),
+ *                    e.g. components/memory/component.rs:133): BFHIP_LOGUP_MASK_CUR_PREV = [0, -1], BFHIP_LOGUP_MASK_PREV_CUR = [-1, 0].
+ *                    Changes the order of those columns' two sampled values (and with it the transcript). */
+enum { BFHIP_MERKLE_STWO_COMPRESS = 0, BFHIP_MERKLE_RFC7693 = 1 };
+enum { BFHIP_MIX_U64_COMPRESS = 0, BFHIP_MIX_U64_HASH = 1 };
+enum { BFHIP_LOGUP_MASK_CUR_PREV = 0, BFHIP_LOGUP_MASK_PREV_CUR = 1 };
+typedef struct bfhip_conventions {
+    uint32_t merkle_node_hash;
+    uint32_t mix_u64;
+    uint32_t logup_mask_order;
+    uint32_t reserved[5];   /* must be zero */
+} bfhip_conventions;
+
 const char* bfhip_last_error(void);
 /* Number of visible HIP devices (0 when there is no GPU). */
 int32_t bfhip_device_count(void);
@@ -35,6 +59,9 @@ int32_t bfhip_device_count(void);
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
+/* Conventions used by every operation of this context (prover, bfhip_merkle_commit_layer, bfhip_grind). conv == NULL restores the defaults. */
+int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv);
+int32_t bfhip_ctx_get_conventions(bfhip_ctx* ctx, bfhip_conventions* out);
 
 /* Device buffers (ColumnOps storage: BaseColumn / SecureColumnByCoords live in HBM behind these). */
 int32_t bfhip_malloc(bfhip_ctx* ctx, size_t bytes, void** out_d);
@@ -76,8 +103,8 @@ int32_t bfhip_accumulate(bfhip_ctx* ctx, uint32_t* dst_d, const uint32_t* src_d,
  * coeffs_d holds 2^log_size coefficients (replicated != 0: the 2^(log_size-4) coefficients of index 0 mod 16). out_h = u32[4]. */
 int32_t bfhip_eval_at_point(bfhip_ctx* ctx, const uint32_t* coeffs_d, uint32_t log_size, int32_t replicated, const uint32_t point_h[8], uint32_t out_h[4]);
 /* MerkleOps<Blake2sMerkleHasher>::commit_on_layer (tree_builder.commit, mod.rs:500,583,723): 2^log_size nodes,
- * node i = Blake2s(prev[2i] || prev[2i+1] || LE u32 of cols[k][i >> col_shift[k]] for k < n_cols); prev_layer_d may be NULL (deepest
- * layer). col_shifts_h may be NULL (all 0). Hashes are 32-byte records. */
+ * node i = hash_node(prev[2i], prev[2i+1], [cols[k][i >> col_shift[k]] for k < n_cols]) under the context's merkle_node_hash convention;
+ * prev_layer_d may be NULL (deepest layer). col_shifts_h may be NULL (all 0). Hashes are 32-byte records. */
 int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void* prev_layer_d, const uint32_t* const* cols_h, const uint32_t* col_shifts_h,
                                   uint32_t n_cols, void* out_hashes_d);
 /* MerkleOps<Poseidon252MerkleHasher>::commit_on_layer (upstream stwo capability named by BASELINE.json config 5; the reference itself
@@ -162,10 +189,20 @@ int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on);
  * bfhip_prove_trace  = everything from the preprocessed commitment (mod.rs:493) to the finished proof (mod.rs:734). */
 int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, bfhip_trace** out,
                            uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells);
+/* The same with the VM's RAM size given (MachineBuilder::with_ram_size, machine.rs:56-60; `--ram-size` of bin/brainfuck_prover.rs);
+ * ram_size = 0 selects Machine::DEFAULT_RAM_SIZE = 30000 (machine.rs:114). */
+int32_t bfhip_trace_create_ram(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, size_t ram_size, bfhip_trace** out,
+                               uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells);
+/* What prove_brainfuck(&Machine) actually receives (mod.rs:471-473): an EXECUTED machine — its register trace (`inputs.trace()`, mod.rs:508;
+ * n_rows rows of 7 u32: clk, ip, ci, ni, mp, mv, mvi, the final ci = ni = 0 row included) and its compiled program (`inputs.program()`,
+ * n_code words incl. the jump-target words). No re-execution: the rows are uploaded as they are and the 13 tables are built from them.
+ * Values must be canonical M31 (< 2^31 - 1); the trace must be non-empty. */
+int32_t bfhip_trace_create_from_registers(bfhip_ctx* ctx, const uint32_t* trace7_h, size_t n_rows, const uint32_t* code_words_h, size_t n_code,
+                                          bfhip_trace** out, uint32_t log_sizes[13], uint64_t* main_cells, uint64_t* interaction_cells);
 int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* trace);
-/* Where the 13 `XTable::from(&vm_trace)` builders (mod.rs:511-547) run: 1 = on the GPU (default; sorts, clk-gap fill, padding, pairing and
- * per-opcode selection as gfx950 kernels), 0 = host builders + upload. Results are identical. Process-wide switch. */
-int32_t bfhip_set_table_builder(int32_t on_gpu);
+/* Where the 13 `XTable::from(&vm_trace)` builders (mod.rs:511-547) of this context run: 1 = on the GPU (default; sorts, clk-gap fill, padding,
+ * pairing and per-opcode selection as gfx950 kernels), 0 = host builders + upload. Results are identical. */
+int32_t bfhip_ctx_set_table_builder(bfhip_ctx* ctx, int32_t on_gpu);
 /* Row-granular main-trace column `column` of component `component` (claim order) of a resident trace -> host. out_h may be NULL (size query). */
 int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows);
 int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
@@ -175,6 +212,8 @@ int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log
  * every Merkle decommitment and FRI. Host only (the reference verifies on the CPU as well). Returns 0 = accepted, 1 = rejected with the
  * reason written to err (VerificationError name), -1 = internal error. */
 int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_t log_max_rows, char* err, size_t err_cap);
+/* The same under explicit conventions (NULL = defaults): a proof verifies only under the conventions it was produced with. */
+int32_t bfhip_verify_brainfuck_conv(const char* proof_json, size_t proof_len, uint32_t log_max_rows, const bfhip_conventions* conv, char* err, size_t err_cap);
 
 /* Host-only pieces of the drop-in (usable without a GPU): the Brainfuck compiler (crates/brainfuck_vm/src/compiler.rs:17-37), the VM
  * (crates/brainfuck_vm/src/machine.rs:141-238; trace rows are 7 u32: clk, ip, ci, ni, mp, mv, mvi) and the 13 table builders
@@ -182,6 +221,9 @@ int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_
 int32_t bfhip_host_compile(const char* code, uint32_t* out, size_t cap, size_t* n);
 int32_t bfhip_host_run(const char* code, const uint8_t* input_h, size_t n_input, uint8_t* out, size_t out_cap, size_t* n_out,
                        uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows);
+/* bfhip_host_run with the RAM size given (Machine::new_with_config, machine.rs:116-131); ram_size = 0: the default 30000 cells. */
+int32_t bfhip_host_run_ram(const char* code, const uint8_t* input_h, size_t n_input, size_t ram_size, uint8_t* out, size_t out_cap, size_t* n_out,
+                           uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows);
 int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t* code, size_t n_code, int32_t component,
                          uint32_t* out_row_major, size_t cap, size_t* n_rows, size_t* n_cols);
 

@@ -265,8 +265,9 @@ struct PointEvaluator : EvalBase<PointEvaluator, QM31> {
     static QM31 combine_ef(QM31 a, QM31 b, QM31 c, QM31 d) { QM31 e[4] = {a, b, c, d}; return from_partial_evals(e); }
     QM31 next_ext_mask0() { QM31 v = combine_ef(inter_vals[ii][0], inter_vals[ii + 1][0], inter_vals[ii + 2][0], inter_vals[ii + 3][0]); ii += 4; return v; }
     void next_ext_mask0m1(QM31& c, QM31& p) {
-        c = combine_ef(inter_vals[ii][0], inter_vals[ii + 1][0], inter_vals[ii + 2][0], inter_vals[ii + 3][0]);
-        p = combine_ef(inter_vals[ii][1], inter_vals[ii + 1][1], inter_vals[ii + 2][1], inter_vals[ii + 3][1]);
+        const int ic = conventions().logup_mask_order == 1 ? 1 : 0, ip = 1 - ic;   // position of offset 0 / offset -1 in the sampled list
+        c = combine_ef(inter_vals[ii][ic], inter_vals[ii + 1][ic], inter_vals[ii + 2][ic], inter_vals[ii + 3][ic]);
+        p = combine_ef(inter_vals[ii][ip], inter_vals[ii + 1][ip], inter_vals[ii + 2][ip], inter_vals[ii + 3][ip]);
         ii += 4;
     }
     template <class G> void add_constraint(G c) { *accumulation = *accumulation * random_coeff + denom_inverse * c; }

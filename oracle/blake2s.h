@@ -98,6 +98,11 @@ struct Channel {
     }
     // mix_u64: raw compression of [n_lo, n_hi, 0...] with h = digest words, t = f = 0.
     void mix_u64(u64 nonce) {
+        if (conventions().mix_u64 == 1) {
+            u8 in[64]; memcpy(in, digest.b, 32); memset(in + 32, 0, 32); memcpy(in + 32, &nonce, 8);
+            update_digest(Blake2s::hash(in, 64));
+            return;
+        }
         u32 h[8]; memcpy(h, digest.b, 32);
         u32 m[16] = {0}; m[0] = (u32)nonce; m[1] = (u32)(nonce >> 32);
         blake2s_compress(h, m, 0, 0, 0, 0);

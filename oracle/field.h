@@ -22,6 +22,16 @@ using u64 = uint64_t;
 
 constexpr u32 P = 0x7fffffffu;  // 2^31 - 1
 
+// The byte-level conventions of stwo@31e8dbc that cannot be checked offline, each behind one named switch.
+// The values mirror include/bfhip.h `bfhip_conventions`; the product and the oracle are always run with the same setting.
+struct Conventions {
+    u32 merkle_node_hash = 0;   // 0: zero state + raw compressions (blake2_merkle.rs as published for this period); 1: RFC 7693 Blake2s-256 of the message
+    u32 mix_u64 = 0;            // 0: raw compression of [lo, hi, 0..] on the digest words; 1: Blake2s-256(digest || LE64(n) zero padded to 32 bytes)
+    u32 logup_mask_order = 0;   // 0: offsets [0, -1] on a component's last logUp column; 1: [-1, 0]
+};
+static inline Conventions& conventions() { static Conventions c; return c; }
+
+
 // stwo core/fields/m31.rs: M31::reduce — valid for x in [0, P^2).
 static inline u32 m31_reduce(u64 x) { return (u32)((((((x >> 31) + x + 1) >> 31) + x)) & P); }
 

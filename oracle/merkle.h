@@ -1,6 +1,10 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see field.h header). PARITY UNPINNED.
-// Restates stwo@31e8dbc `core/vcs/{prover,verifier,blake2_merkle}.rs`: mixed-degree Merkle tree,
-// node(i) = Blake2s(left || right || LE-u32 of each column-of-this-size at row i).
+// Restates stwo@31e8dbc `core/vcs/{prover,verifier,blake2_merkle}.rs`: mixed-degree Merkle tree; node(i) absorbs
+// left || right (when a deeper layer exists) and then the LE-u32 value of each column-of-this-size at row i.
+// How it absorbs them is `Conventions::merkle_node_hash` (blake2s.h): the default is the published `Blake2sMerkleHasher::hash_node` of this
+// period — state = 0; state = compress(state, left||right, 0,0,0,0); then compress(state, chunk, 0,0,0,0) for the column words in
+// zero-padded chunks of 16 (rem = 15 - ((len + 15) % 16)); no parameter block, no byte counter, no finalisation flag — the
+// alternative is the RFC 7693 hash of the same byte string.
 // Reference call sites: tree_builder.commit(channel) crates/brainfuck_prover/src/brainfuck_air/mod.rs:500,583,723.
 #pragma once
 #include "blake2s.h"
@@ -12,6 +16,16 @@ namespace orc {
 
 // Blake2sMerkleHasher::hash_node
 static inline Hash32 hash_node(const Hash32* left, const Hash32* right, const u32* vals, size_t n_vals) {
+    if (conventions().merkle_node_hash == 0) {
+        u32 st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[16];
+        if (left) { memcpy(m, left->b, 32); memcpy(m + 8, right->b, 32); blake2s_compress(st, m, 0, 0, 0, 0); }
+        for (size_t o = 0; o < n_vals; o += 16) {
+            size_t take = std::min<size_t>(16, n_vals - o);
+            memset(m, 0, sizeof m); memcpy(m, vals + o, 4 * take);
+            blake2s_compress(st, m, 0, 0, 0, 0);
+        }
+        Hash32 out; memcpy(out.b, st, 32); return out;
+    }
     Blake2s s;
     if (left) { s.update(left->b, 32); s.update(right->b, 32); }
     if (n_vals) s.update(vals, 4 * n_vals);

@@ -35,6 +35,18 @@ int orc_set_threads(int n) {
 #endif
 }
 
+// Byte-level stwo conventions (field.h `Conventions`; same numbering as include/bfhip.h `bfhip_conventions`). Process-wide: set it before a call.
+int orc_set_conventions(u32 merkle_node_hash, u32 mix_u64, u32 logup_mask_order) {
+    if (merkle_node_hash > 1 || mix_u64 > 1 || logup_mask_order > 1) { g_err = "bad convention value"; return -1; }
+    conventions().merkle_node_hash = merkle_node_hash; conventions().mix_u64 = mix_u64; conventions().logup_mask_order = logup_mask_order;
+    return 0;
+}
+// Blake2sMerkleHasher::hash_node under the current convention (left/right may be NULL)
+int orc_hash_node(const u8* left, const u8* right, const u32* vals, size_t n, u8 out[32]) {
+    Hash32 l, r; if (left) { memcpy(l.b, left, 32); memcpy(r.b, right, 32); }
+    Hash32 h = hash_node(left ? &l : nullptr, left ? &r : nullptr, vals, n); memcpy(out, h.b, 32); return 0;
+}
+
 // ---- fields ------------------------------------------------------------------------------------------------------------
 // op: 0 add, 1 sub, 2 mul, 3 inv(a)
 int orc_m31_op(int op, const u32* a, const u32* b, u32* out, size_t n) {

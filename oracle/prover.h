@@ -149,7 +149,8 @@ static inline std::vector<std::vector<std::vector<PointQ>>> mask_points(const st
         for (u32 c = 0; c < l.n_main; c++) mp[1].push_back({p});
         PointQ prev = p - into_ef(CanonicCoset{l.log_size}.step());    // point + trace_step.mul_signed(-1)
         for (u32 c = 0; c < l.n_inter; c++) {
-            if (c + 4 >= l.n_inter) mp[2].push_back({p, prev}); else mp[2].push_back({p});
+            if (c + 4 >= l.n_inter) { if (conventions().logup_mask_order == 1) mp[2].push_back({prev, p}); else mp[2].push_back({p, prev}); }
+            else mp[2].push_back({p});
         }
     }
     mp[3].assign(4, {p});

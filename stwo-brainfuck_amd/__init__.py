@@ -6,6 +6,7 @@ every entry point raises.  Reference interface mirrored: crates/brainfuck_prover
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -40,6 +41,31 @@ def device_count():
     return lib().bfhip_device_count()
 
 
+class Conventions(ctypes.Structure):
+    """include/bfhip.h `bfhip_conventions`: the byte-level stwo conventions that cannot be confirmed offline, one switch each.
+    All zero = the defaults (zero-state raw-compress Merkle nodes, raw-compress mix_u64, logUp mask order [0, -1])."""
+    _fields_ = [("merkle_node_hash", ctypes.c_uint32), ("mix_u64", ctypes.c_uint32), ("logup_mask_order", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5)]
+
+
+_default_conventions = (0, 0, 0)
+_live_contexts = weakref.WeakSet()
+
+
+def set_default_conventions(merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
+    """Process-wide default of the Python mirror: adopted by every Context created afterwards, applied to the live ones, and used by
+    verify_brainfuck(conventions=None). The C ABI itself has no global state: conventions are per context / per verify call."""
+    global _default_conventions
+    _default_conventions = (int(merkle_node_hash), int(mix_u64), int(logup_mask_order))
+    for c in list(_live_contexts):
+        if c._h:
+            c.set_conventions(*_default_conventions)
+
+
+MERKLE_STWO_COMPRESS, MERKLE_RFC7693 = 0, 1
+MIX_U64_COMPRESS, MIX_U64_HASH = 0, 1
+LOGUP_MASK_CUR_PREV, LOGUP_MASK_PREV_CUR = 0, 1
+
+
 class Context:
     """One GPU + one HIP stream + the twiddle tree (mod.rs:480-487: twiddles, channel and commitment scheme setup)."""
 
@@ -47,6 +73,9 @@ class Context:
         self._h = ctypes.c_void_p()
         _check(lib().bfhip_ctx_create(device_id, max_log_domain, ctypes.byref(self._h)))
         self.max_log_domain = max_log_domain
+        _live_contexts.add(self)
+        if _default_conventions != (0, 0, 0):
+            self.set_conventions(*_default_conventions)
 
     def close(self):
         if self._h:
@@ -61,6 +90,19 @@ class Context:
 
     def sync(self):
         _check(lib().bfhip_ctx_sync(self._h))
+
+    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
+        cv = Conventions(merkle_node_hash, mix_u64, logup_mask_order)
+        _check(lib().bfhip_ctx_set_conventions(self._h, ctypes.byref(cv)))
+
+    def get_conventions(self):
+        cv = Conventions()
+        _check(lib().bfhip_ctx_get_conventions(self._h, ctypes.byref(cv)))
+        return cv.merkle_node_hash, cv.mix_u64, cv.logup_mask_order
+
+    def set_table_builder(self, on_gpu=True):
+        """Where this context builds the 13 component tables: GPU kernels (default) or the host builders. Identical results."""
+        _check(lib().bfhip_ctx_set_table_builder(self._h, int(on_gpu)))
 
     # -- one proof over several GPUs (bfhip_ctx_set_shard) ---------------------------------------------------------------------------
     _ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -244,32 +286,47 @@ def prove_brainfuck(code, input_bytes=b"", ctx=None, log_max_rows=24, with_trans
             ctx.close()
 
 
-def verify_brainfuck(proof_json: bytes, log_max_rows=24):
-    """verify_brainfuck (mod.rs:738): returns (ok, reason). Host only — no GPU needed, like the reference's verifier."""
+def verify_brainfuck(proof_json: bytes, log_max_rows=24, conventions=None):
+    """verify_brainfuck (mod.rs:738): returns (ok, reason). Host only — no GPU needed, like the reference's verifier.
+    conventions: (merkle_node_hash, mix_u64, logup_mask_order) the proof was produced under; None = the defaults."""
     err = ctypes.create_string_buffer(512)
-    rc = lib().bfhip_verify_brainfuck(proof_json, ctypes.c_size_t(len(proof_json)), log_max_rows, err, ctypes.c_size_t(512))
+    cv = ctypes.byref(Conventions(*(_default_conventions if conventions is None else conventions)))
+    rc = lib().bfhip_verify_brainfuck_conv(proof_json, ctypes.c_size_t(len(proof_json)), log_max_rows, cv, err, ctypes.c_size_t(512))
     if rc < 0:
         raise BfhipError(lib().bfhip_last_error().decode())
     return rc == 0, err.value.decode()
 
 
-def set_table_builder(on_gpu=True):
-    """Where the 13 component tables are built: GPU kernels (default) or the host builders. Identical results."""
-    _check(lib().bfhip_set_table_builder(int(on_gpu)))
-
-
 class Trace:
     """Prover input resident in HBM (bfhip_trace_create): VM trace -> 13 component tables -> row-granular device columns."""
 
-    def __init__(self, ctx, code, input_bytes=b""):
+    def __init__(self, ctx, code, input_bytes=b"", ram_size=0):
+        """ram_size: Machine RAM cells (MachineBuilder::with_ram_size, machine.rs:56-60); 0 = the default 30000."""
         self.ctx = ctx
         self._h = ctypes.c_void_p()
         ls = (ctypes.c_uint32 * 13)()
         steps, mc, ic = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
-        _check(lib().bfhip_trace_create(ctx._h, code.encode(), input_bytes, ctypes.c_size_t(len(input_bytes)), ctypes.byref(self._h), ls,
-                                        ctypes.byref(steps), ctypes.byref(mc), ctypes.byref(ic)))
+        _check(lib().bfhip_trace_create_ram(ctx._h, code.encode(), input_bytes, ctypes.c_size_t(len(input_bytes)), ctypes.c_size_t(ram_size),
+                                            ctypes.byref(self._h), ls, ctypes.byref(steps), ctypes.byref(mc), ctypes.byref(ic)))
         self.log_sizes = list(ls)
         self.n_steps, self.main_cells, self.interaction_cells = steps.value, mc.value, ic.value
+
+    @classmethod
+    def from_registers(cls, ctx, trace7, code_words):
+        """What prove_brainfuck(&Machine) receives (mod.rs:471-473,508): the executed machine's register trace (n x 7 u32: clk, ip, ci,
+        ni, mp, mv, mvi) and its compiled program words. No re-execution."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._h = ctypes.c_void_p()
+        tr = np.ascontiguousarray(trace7, dtype=np.uint32).reshape(-1, 7)
+        code = np.ascontiguousarray(code_words, dtype=np.uint32)
+        ls = (ctypes.c_uint32 * 13)()
+        mc, ic = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(lib().bfhip_trace_create_from_registers(ctx._h, tr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(tr.shape[0]), code.ctypes.data_as(ctypes.c_void_p),
+                                                       ctypes.c_size_t(code.size), ctypes.byref(self._h), ls, ctypes.byref(mc), ctypes.byref(ic)))
+        self.log_sizes = list(ls)
+        self.n_steps, self.main_cells, self.interaction_cells = tr.shape[0], mc.value, ic.value
+        return self
 
     @property
     def cells(self):

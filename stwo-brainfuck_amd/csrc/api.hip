@@ -54,6 +54,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
 void Ctx::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (stream2) (void)hipStreamSynchronize(stream2);
+    if (stream) prof_forget(stream);
+    if (stream2) prof_forget(stream2);
     arena.release();
     (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
     if (h_stage) (void)hipHostFree(h_stage);
@@ -91,6 +93,26 @@ int32_t bfhip_ctx_set_shard(bfhip_ctx* ctx, uint32_t rank, uint32_t count, bfhip
     g.allgather = allgather; g.allreduce_max = allreduce_max; g.user = user;
     ctx->c.sync();
     ctx->c.shard = g;
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv) {
+    API_CTX(ctx)
+    Conventions cv;
+    if (conv) {
+        if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1) throw HipError("unknown convention value");
+        cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order;
+    }
+    ctx->c.sync();
+    ctx->c.conv = cv;   // a kept preprocessed tree is keyed on the conventions it was hashed under (prover.hip: PreprocessedCache)
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_get_conventions(bfhip_ctx* ctx, bfhip_conventions* out) {
+    API_CTX(ctx)
+    bfhip_conventions r{};
+    r.merkle_node_hash = ctx->c.conv.merkle_node_hash; r.mix_u64 = ctx->c.conv.mix_u64; r.logup_mask_order = ctx->c.conv.logup_mask_order;
+    *out = r;
     return 0;
     API_CATCH
 }
@@ -193,7 +215,7 @@ int32_t bfhip_merkle_commit_layer(bfhip_ctx* ctx, uint32_t log_size, const void*
     std::vector<ColDesc> d(n_cols);
     for (u32 k = 0; k < n_cols; k++) d[k] = ColDesc{cols_h[k], col_shifts_h ? col_shifts_h[k] : 0u, 0};
     const ColDesc* dd = n_cols ? c.stage(d.data(), n_cols) : nullptr;
-    merkle_layer(c.stream, out_hashes_d, prev_layer_d, dd, n_cols, log_size, 0.0, 0, 0);
+    merkle_layer(c.stream, out_hashes_d, prev_layer_d, dd, n_cols, log_size, 0.0, 0, 0, c.conv.merkle_node_hash);
     BF_HIP(hipGetLastError());
     return 0;
     API_CATCH
@@ -251,7 +273,7 @@ int32_t bfhip_grind(bfhip_ctx* ctx, const uint8_t digest_h[32], uint32_t pow_bit
     unsigned long long* d_best = c.stage(&init, 1);
     const u32 span = 1u << 20;
     for (u64 base = 0; best == ~0ull; base += span) {
-        grind_span(c.stream, d_digest, base, span, pow_bits, d_best);
+        grind_span(c.stream, d_digest, base, span, pow_bits, d_best, c.conv.mix_u64);
         BF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c.stream));
         c.sync();
         if (base > (u64(1) << 40)) throw HipError("grind: no nonce found below 2^40");

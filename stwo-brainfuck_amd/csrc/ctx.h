@@ -41,6 +41,8 @@ struct ShardGroup {
 
 struct Ctx {
     int device = 0;
+    Conventions conv;               // byte-level stwo conventions (bfhip_ctx_set_conventions)
+    bool tables_on_gpu = true;      // where the 13 component tables are built (bfhip_ctx_set_table_builder)
     ShardGroup shard;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase

@@ -54,9 +54,29 @@ inline Hash32 hash(const u8* data, size_t len) {
 }
 }  // namespace b2s
 
+// Blake2sMerkleHasher::hash_node on the host (verifier; the prover hashes on the GPU, merkle.hip). conv = Conventions::merkle_node_hash.
+inline Hash32 host_hash_node(const Hash32* l, const Hash32* r, const u32* vals, size_t n, u32 conv) {
+    if (conv == 0) {   // zero state, one raw compression per 64-byte block: children first, then the column words zero padded to 16
+        u32 st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[16];
+        if (l) { memcpy(m, l->b, 32); memcpy(m + 8, r->b, 32); b2s::compress(st, m, 0, 0, 0, 0); }
+        for (size_t o = 0; o < n; o += 16) {
+            size_t take = std::min<size_t>(16, n - o);
+            memset(m, 0, sizeof m); memcpy(m, vals + o, 4 * take);
+            b2s::compress(st, m, 0, 0, 0, 0);
+        }
+        Hash32 out; memcpy(out.b, st, 32); return out;
+    }
+    std::vector<u8> buf((l ? 64 : 0) + 4 * n);
+    if (l) { memcpy(buf.data(), l->b, 32); memcpy(buf.data() + 32, r->b, 32); }
+    if (n) memcpy(buf.data() + (l ? 64 : 0), vals, 4 * n);
+    return b2s::hash(buf.data(), buf.size());
+}
+
 struct Channel {
     Hash32 digest; u32 n_sent = 0;
+    u32 mix_u64_conv = 0;   // Conventions::mix_u64
     Channel() { memset(digest.b, 0, 32); }
+    explicit Channel(const Conventions& cv) : mix_u64_conv(cv.mix_u64) { memset(digest.b, 0, 32); }
     void update(const Hash32& d) { digest = d; n_sent = 0; }
     void mix_root(const Hash32& root) { u8 buf[64]; memcpy(buf, digest.b, 32); memcpy(buf + 32, root.b, 32); update(b2s::hash(buf, 64)); }
     void mix_felts(const Q31* f, size_t n) {
@@ -66,6 +86,7 @@ struct Channel {
         update(b2s::hash(buf.data(), buf.size()));
     }
     void mix_u64(u64 v) {
+        if (mix_u64_conv == 1) { u8 buf[64] = {0}; memcpy(buf, digest.b, 32); memcpy(buf + 32, &v, 8); update(b2s::hash(buf, 64)); return; }
         u32 h[8]; memcpy(h, digest.b, 32);
         u32 m[16] = {0}; m[0] = (u32)v; m[1] = (u32)(v >> 32);
         b2s::compress(h, m, 0, 0, 0, 0);

@@ -44,8 +44,19 @@ struct JsonReader {
                 v.obj.push_back({k, parse(depth + 1)}); ws();
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }
-        } else if (*p == 'n') { if (end - p < 4) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
-        else if (*p >= '0' && *p <= '9') { v.kind = JVal::NUM; u64 x = 0; int nd = 0; while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (u64)(*p - '0'); p++; if (++nd > 20) throw std::runtime_error("json: number"); } v.num = x; }
+        } else if (*p == 'n') { if (end - p < 4 || memcmp(p, "null", 4) != 0) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
+        else if (*p >= '0' && *p <= '9') {
+            // canonical unsigned integers only, as serde_json emits and accepts for u32/u64 fields: no leading zeros, no wrap-around
+            v.kind = JVal::NUM; u64 x = 0; const char* s0 = p;
+            while (p < end && *p >= '0' && *p <= '9') {
+                u64 d = (u64)(*p - '0');
+                if (x > (~u64(0) - d) / 10) throw std::runtime_error("json: number out of range");
+                x = x * 10 + d; p++;
+            }
+            if (p - s0 > 1 && *s0 == '0') throw std::runtime_error("json: leading zero");
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) throw std::runtime_error("json: not an integer");
+            v.num = x;
+        }
         else throw std::runtime_error("json: unexpected character");
         return v;
     }
@@ -75,6 +86,8 @@ inline FriLayerProof jv_fri_layer(const JVal& v) {
 inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     JsonReader jr{s, s + len};
     JVal root = jr.parse();
+    jr.ws();
+    if (jr.p != jr.end) throw std::runtime_error("json: trailing characters");
     BrainfuckProof bp;
     for (int c = 0; c < N_COMPONENTS; c++) {
         const JVal& ls = root.get("claim").get(COMPONENT_NAMES[c]).get("log_size");
@@ -92,29 +105,22 @@ inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     }
     for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(jv_decommitment(d));
     for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(jv_m31(x)); sp.queried_values.push_back(v); }
+    if (p.get("proof_of_work").kind != JVal::NUM) throw std::runtime_error("bad proof_of_work");
     sp.proof_of_work = p.get("proof_of_work").num;
     const JVal& f = p.get("fri_proof");
     sp.fri_proof.first_layer = jv_fri_layer(f.get("first_layer"));
     for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(jv_fri_layer(l));
     for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(jv_qm31(q));
-    sp.fri_proof.last_layer_log_size = (u32)f.get("last_layer_poly").get("log_size").num;
+    { const JVal& ll = f.get("last_layer_poly").get("log_size"); if (ll.kind != JVal::NUM || ll.num > 31) throw std::runtime_error("bad last layer log_size"); sp.fri_proof.last_layer_log_size = (u32)ll.num; }
     return bp;
 }
 
 // ---- verifier ----------------------------------------------------------------------------------------------------------------------------
 struct VerifierConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_bound = 0, n_queries = 3; };   // PcsConfig::default() (mod.rs:743)
 
-// Blake2sMerkleHasher::hash_node on the host
-inline Hash32 host_hash_node(const Hash32* l, const Hash32* r, const u32* vals, size_t n) {
-    std::vector<u8> buf((l ? 64 : 0) + 4 * n);
-    if (l) { memcpy(buf.data(), l->b, 32); memcpy(buf.data() + 32, r->b, 32); }
-    if (n) memcpy(buf.data() + (l ? 64 : 0), vals, 4 * n);
-    return b2s::hash(buf.data(), buf.size());
-}
-
 // MerkleVerifier::verify — "" on success, else the error name
 inline std::string merkle_verify(const Hash32& root, const std::vector<u32>& column_log_sizes, const std::map<u32, std::vector<size_t>>& queries_per_log,
-                                 const std::vector<u32>& queried_values, const MerkleDecommitment& d) {
+                                 const std::vector<u32>& queried_values, const MerkleDecommitment& d, u32 node_conv) {
     if (column_log_sizes.empty()) return "";
     std::map<u32, size_t> ncols_at;
     u32 max_log = 0;
@@ -151,7 +157,7 @@ inline std::string merkle_verify(const Hash32& root, const std::vector<u32>& col
                 if (cw + ncol > d.column_witness.size()) return "WitnessTooShort";
                 for (size_t c = 0; c < ncol; c++) vals[c] = d.column_witness[cw++];
             }
-            total.push_back({node, host_hash_node(have_last ? &l : nullptr, have_last ? &r : nullptr, vals.data(), ncol)});
+            total.push_back({node, host_hash_node(have_last ? &l : nullptr, have_last ? &r : nullptr, vals.data(), ncol, node_conv)});
         }
         last = total; have_last = true;
     }
@@ -176,6 +182,7 @@ struct HostPointEval : LogupState<HostPointEval, Fq> {
     typedef Fq F;
     Q31 preproc; const std::vector<Q31>* tvals; const std::vector<Q31>* ivals; int ti = 0, ii = 0;
     Q31 denom_inverse, random_coeff; Q31* acc;
+    int cur_pos = 0;   // position of mask offset 0 in a last logUp column's sampled pair (Conventions::logup_mask_order)
     Fq is_first() { return {preproc}; }
     Fq trace() { return {tvals[ti++].at(0)}; }
     Fq cst(u32 k) { return {q_from_m(k)}; }
@@ -187,7 +194,7 @@ struct HostPointEval : LogupState<HostPointEval, Fq> {
         return r;
     }
     Fq inter_cur() { Fq v{combine(ivals + ii, 0)}; ii += 4; return v; }
-    void inter_cur_prev(Fq& cur, Fq& prev) { cur.v = combine(ivals + ii, 0); prev.v = combine(ivals + ii, 1); ii += 4; }
+    void inter_cur_prev(Fq& cur, Fq& prev) { cur.v = combine(ivals + ii, cur_pos); prev.v = combine(ivals + ii, 1 - cur_pos); ii += 4; }
     void constraint(Fq cv) { *acc = q_add(q_mul(*acc, random_coeff), q_mul(denom_inverse, cv.v)); }
 };
 inline void host_point_eval(int comp, HostPointEval& pe, const Lookups& el) {
@@ -209,7 +216,7 @@ inline void host_point_eval(int comp, HostPointEval& pe, const Lookups& el) {
 }
 // Components::eval_composition_polynomial_at_point
 inline Q31 eval_composition_at_point(const u32* log_sizes, const Q31* claimed_sums, u32 log_max_rows, const Lookups& el, PtQ oods,
-                                     const std::vector<std::vector<std::vector<Q31>>>& sv, Q31 random_coeff) {
+                                     const std::vector<std::vector<std::vector<Q31>>>& sv, Q31 random_coeff, const Conventions& cv = Conventions()) {
     Q31 acc = q_zero();
     size_t mo = 0, io = 0;
     for (int k = 0; k < N_COMPONENTS; k++) {
@@ -218,7 +225,7 @@ inline Q31 eval_composition_at_point(const u32* log_sizes, const Q31* claimed_su
         pe.tvals = &sv.at(1).at(mo);
         pe.ivals = &sv.at(2).at(io);
         pe.denom_inverse = q_inv(coset_vanishing_q(log_sizes[k], oods));
-        pe.random_coeff = random_coeff; pe.acc = &acc; pe.total_sum = claimed_sums[k];
+        pe.random_coeff = random_coeff; pe.acc = &acc; pe.total_sum = claimed_sums[k]; pe.cur_pos = cv.logup_mask_order == 1 ? 1 : 0;
         host_point_eval(k, pe, el);
         mo += n_main_cols(k); io += 4 * n_logup_cols(k);
     }
@@ -233,12 +240,12 @@ inline std::vector<size_t> v_fold_queries(const std::vector<size_t>& q, u32 n) {
 }
 
 // Returns "" when the proof verifies, else the reason.
-inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, VerifierConfig cfg = VerifierConfig()) {
+inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, const Conventions& cv = Conventions(), VerifierConfig cfg = VerifierConfig()) {
     try {
         const StarkProof& pf = bp.proof;
         if (pf.commitments.size() != 4 || pf.sampled_values.size() != 4 || pf.decommitments.size() != 4 || pf.queried_values.size() != 4) return "InvalidStructure";
         for (int k = 0; k < N_COMPONENTS; k++) if (bp.log_sizes[k] < LOG_N_LANES || bp.log_sizes[k] > log_max_rows) return "InvalidStructure: log_size";
-        Channel ch;
+        Channel ch(cv);
         // claim.log_sizes() with the preprocessed tree overwritten by IS_FIRST_LOG_SIZES (mod.rs:118-143)
         std::vector<std::vector<u32>> col_logs(4);
         for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) col_logs[0].push_back(log + cfg.log_blowup);
@@ -271,7 +278,10 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
             for (u32 j = 0; j < n_main_cols(k); j++) sp[1].push_back({oods});
             PtQ prev = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
             u32 ni = 4 * n_logup_cols(k);
-            for (u32 j = 0; j < ni; j++) { if (j + 4 >= ni) sp[2].push_back({oods, prev}); else sp[2].push_back({oods}); }
+            for (u32 j = 0; j < ni; j++) {
+                if (j + 4 >= ni) { if (cv.logup_mask_order == 1) sp[2].push_back({prev, oods}); else sp[2].push_back({oods, prev}); }
+                else sp[2].push_back({oods});
+            }
         }
         sp[3].assign(4, {oods});
         for (int t = 0; t < 4; t++) {
@@ -280,7 +290,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
         }
         {
             std::vector<Q31> ce[4] = {pf.sampled_values[3][0], pf.sampled_values[3][1], pf.sampled_values[3][2], pf.sampled_values[3][3]};
-            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, pf.sampled_values, random_coeff);
+            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, pf.sampled_values, random_coeff, cv);
             if (!q_eq(HostPointEval::combine(ce, 0), want)) return "OodsNotMatching";
         }
         { std::vector<Q31> flat; for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); ch.mix_felts(flat.data(), flat.size()); }
@@ -309,7 +319,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
         }
         std::map<u32, std::vector<size_t>> positions_by_log;
         for (u32 l : dom_logs) positions_by_log[l] = v_fold_queries(queries, max_log - l);
-        for (int t = 0; t < 4; t++) { std::string e = merkle_verify(pf.commitments[t], col_logs[t], positions_by_log, pf.queried_values[t], pf.decommitments[t]); if (!e.empty()) return "MerkleVerification tree " + std::to_string(t) + ": " + e; }
+        for (int t = 0; t < 4; t++) { std::string e = merkle_verify(pf.commitments[t], col_logs[t], positions_by_log, pf.queried_values[t], pf.decommitments[t], cv.merkle_node_hash); if (!e.empty()) return "MerkleVerification tree " + std::to_string(t) + ": " + e; }
         // fri_answers: per LDE size (descending), the quotient value at every query position
         struct Flat { int t; size_t c; u32 log; };
         std::vector<Flat> flat;
@@ -384,7 +394,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
                 for (int c = 0; c < 4; c++) mlogs.push_back(dom_logs[k]);
             }
             if (wi != fp.first_layer.fri_witness.size()) return "FirstLayerEvaluationsInvalid";
-            std::string e = merkle_verify(fp.first_layer.commitment, mlogs, dpos, dvals, fp.first_layer.decommitment);
+            std::string e = merkle_verify(fp.first_layer.commitment, mlogs, dpos, dvals, fp.first_layer.decommitment, cv.merkle_node_hash);
             if (!e.empty()) return "FirstLayerCommitmentInvalid: " + e;
         }
         auto lq = v_fold_queries(queries, 1);
@@ -406,7 +416,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
             size_t wi = 0; std::vector<size_t> pos; Sparse sps;
             if (!rebuild(lq, lev, lp.fri_witness, wi, pos, sps) || wi != lp.fri_witness.size()) return "InnerLayerEvaluationsInvalid";
             std::map<u32, std::vector<size_t>> dpos; dpos[line_log] = pos;
-            std::string e = merkle_verify(lp.commitment, std::vector<u32>(4, line_log), dpos, words_of(sps), lp.decommitment);
+            std::string e = merkle_verify(lp.commitment, std::vector<u32>(4, line_log), dpos, words_of(sps), lp.decommitment, cv.merkle_node_hash);
             if (!e.empty()) return "InnerLayerCommitmentInvalid: " + e;
             std::vector<Q31> nev;
             for (size_t s = 0; s < sps.evals.size(); s++) {

@@ -11,22 +11,24 @@ namespace bf {
 // are broadcast into 16 consecutive cells (reference: memory/table.rs:95-104) — cell i reads ptr[i >> 4].
 struct ColDesc { const u32* ptr; u32 shift; u32 pad_; };
 
-// prof.hip — optional per-kernel HIP-event timing (bench.py roofline)
-int prof_mode();
-void prof_enable(int mode);
+// prof.hip — optional per-kernel HIP-event timing (bench.py roofline); state is per stream
+int prof_mode(hipStream_t s);
+void prof_enable(hipStream_t s, int mode);
 void prof_run_begin(hipStream_t s, const char* name);   // mode 2: one event pair for a run of back-to-back launches of one kernel
 void prof_run_end(hipStream_t s);
-void prof_begin(hipStream_t s, const char* name, double bytes);
+void prof_begin(hipStream_t s, const char* name, double bytes, double units);
 void prof_end(hipStream_t s);
-void prof_collect();
-void prof_reset();
-std::string prof_report_json();
+void prof_reset(hipStream_t s);
+std::string prof_report_json(const hipStream_t* streams, int n);
+void prof_forget(hipStream_t s);
+// bytes = algorithmic bytes of the launch, units = work units (Blake2s compressions / Hades permutations for the Merkle kernels, else 0).
+// dominant: the kernel that mode 2 (lowest overhead) instruments — the Merkle layer kernel.
 struct ProfScope {
     hipStream_t s; bool on;
-    ProfScope(hipStream_t s_, const char* name, double bytes) : s(s_) {
-        int m = prof_mode();
-        on = m == 1 || (m == 2 && name[2] == 'm' && name[8] == '_' && name[9] == 'l');   // "k_merkle_layer"
-        if (on) prof_begin(s, name, bytes);
+    ProfScope(hipStream_t s_, const char* name, double bytes, double units = 0.0, bool dominant = false) : s(s_) {
+        int m = prof_mode(s);
+        on = m == 1 || (m == 2 && dominant);
+        if (on) prof_begin(s, name, bytes, units);
     }
     ~ProfScope() { if (on) prof_end(s); }
 };
@@ -64,11 +66,12 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
 // merkle.hip
 // out_shift / prev_shift: replication of this layer / of the child layer (nodes are stored at index node >> shift)
 // first/count: range of stored nodes to compute (count == 0: the whole layer) — a rank of a shard group computes its share only
+// node_conv = Conventions::merkle_node_hash
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
-                  u32 first = 0, u32 count = 0);
+                  u32 node_conv, u32 first = 0, u32 count = 0);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32* d_chan = nullptr, u32* d_alpha8 = nullptr, u32* d_root_copy = nullptr);
-void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best);
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32 node_conv, u32* d_chan = nullptr, u32* d_alpha8 = nullptr, u32* d_root_copy = nullptr);
+void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy);

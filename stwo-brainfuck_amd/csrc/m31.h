@@ -21,6 +21,14 @@ using u64 = uint64_t;
 
 constexpr u32 P31 = 0x7fffffffu;
 
+// Byte-level conventions of stwo@31e8dbc that cannot be confirmed offline, one named switch each; the numbering
+// is that of include/bfhip.h `bfhip_conventions`. Defaults = the published stwo code of the period to the best of our reconstruction.
+struct Conventions {
+    u32 merkle_node_hash = 0;   // 0 BFHIP_MERKLE_STWO_COMPRESS: zero state, raw compress(state, block, 0,0,0,0) per 64-byte block; 1 BFHIP_MERKLE_RFC7693
+    u32 mix_u64 = 0;            // 0 BFHIP_MIX_U64_COMPRESS: raw compression on the digest words; 1 BFHIP_MIX_U64_HASH: Blake2s(digest || pad32(LE64 n))
+    u32 logup_mask_order = 0;   // 0 BFHIP_LOGUP_MASK_CUR_PREV: offsets [0, -1] on a component's last logUp column; 1 BFHIP_LOGUP_MASK_PREV_CUR: [-1, 0]
+};
+
 BF_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; u32 t = s - P31; return t < s ? t : s; }           // min(s, s-P) with wraparound
 BF_HD u32 m_sub(u32 a, u32 b) { u32 s = a - b; u32 t = s + P31; return t < s ? t : s; }           // a-b or a-b+P
 // Lazy reduction for dot products: a product of canonical values is < 2^62, so three products fit on top of a folded accumulator

@@ -1,7 +1,10 @@
 // Blake2s mixed-degree Merkle layers for gfx950 — SURVEY.md §8 row a4.
 // Replaces stwo `MerkleOps<Blake2sMerkleHasher>::commit_on_layer` reached from tree_builder.commit(channel),
 // crates/brainfuck_prover/src/brainfuck_air/mod.rs:500,583,723 (and the composition / FRI layer trees inside prover::prove, :732).
-// node(i) = Blake2s-256( left(32B) || right(32B) || LE-u32 value of every column of this layer's size at row i ).
+// node(i) absorbs left(32B) || right(32B) || LE-u32 value of every column of this layer's size at row i, 64 bytes per compression.
+// Conventions::merkle_node_hash (m31.h) selects how: 0 (default) = stwo's Blake2sMerkleHasher::hash_node of the period — zero initial state,
+// raw compress(state, block, 0,0,0,0) per block, column words zero padded to 16; 1 = RFC 7693 Blake2s-256 of the byte string (parameter
+// block, byte counter, final flag). Both cost the same number of compressions; the kernels take the choice as an all-ones/zero mask `rfc`.
 //
 // One lane hashes one node. The message is streamed 64 bytes at a time through a fully unrolled compression (the sigma
 // schedule is compile-time, so the 16 message words and the 16 state words stay in VGPRs; rotations by 16/8 lower to
@@ -54,13 +57,17 @@ __device__ __forceinline__ void store_hash(uint4* __restrict__ out, u32 st, cons
     __builtin_nontemporal_store(lo4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st));
     __builtin_nontemporal_store(hi4, reinterpret_cast<bf_u32x4*>(out + 2 * (size_t)st + 1));
 }
+// initial chaining value: zeros (stwo convention) or IV ^ parameter block (RFC 7693); rfc = 0 / 0xFFFFFFFF
+__device__ __forceinline__ void node_init(u32 (&h)[8], u32 rfc) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) h[k] = B2S_IV[k] & rfc;
+    h[0] ^= 0x01010020u & rfc;
+}
 __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
-                                            u32 out_shift, u32 prev_shift) {
+                                            u32 out_shift, u32 prev_shift, u32 rfc) {
     const u32 i = st << out_shift;          // representative node of this stored slot
     u32 h[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
-    h[0] ^= 0x01010020u;
+    node_init(h, rfc);
     const u32 total_bytes = (prev ? 64u : 0u) + 4u * ncols;
     u32 m[16];
     u32 done = 0;   // bytes compressed so far
@@ -72,7 +79,7 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
         done = 64;
         bool last = total_bytes == 64;
-        blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
+        blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
         if (last) { store_hash(out, st, h); return; }
     }
     // remaining message: column values, 16 words per block (zero padded)
@@ -94,7 +101,7 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         u32 take = min(64u, total_bytes - done);
         done += take; c0 += 16;
         bool last = done == total_bytes;
-        blake2s_compress(h, m, done, last ? 0xFFFFFFFFu : 0u);
+        blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
         if (last) break;
     }
     store_hash(out, st, h);
@@ -105,7 +112,7 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
 // inputs of a lane's next node are fetched while the current node is compressed: with one compression per node the load latency is
 // otherwise exposed once per node and wave (85 -> 89 % of the compression peak). The same for column-less inner nodes measured worse.
 __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
-                                                      u32 out_shift, u32 prev_shift, u32 first) {
+                                                      u32 out_shift, u32 prev_shift, u32 first, u32 rfc) {
     const u32 stride = gridDim.x * blockDim.x;
     u32 st = blockIdx.x * blockDim.x + threadIdx.x;
     if (st >= n_stored) return;
@@ -124,15 +131,13 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
             const bool more = st < n_stored;
             if (more) { i = (first + st) << out_shift; n0 = ld_col(d0, i); n1 = ld_col(d1, i); n2 = ld_col(d2, i); n3 = ld_col(d3, i); }
             u32 h[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
-            h[0] ^= 0x01010020u;
-            blake2s_compress(h, m, 4u * ncols, 0xFFFFFFFFu);
+            node_init(h, rfc);
+            blake2s_compress(h, m, (4u * ncols) & rfc, rfc);
             store_hash(out, cur, h);
             if (!more) return;
         }
     }
-    for (; st < n_stored; st += stride) merkle_node(first + st, out, prev, cols, ncols, out_shift, prev_shift);
+    for (; st < n_stored; st += stride) merkle_node(first + st, out, prev, cols, ncols, out_shift, prev_shift, rfc);
 }
 
 // Blake2sChannel stepped on the device for the FRI commit phase (FriProver::commit: mix_root(layer root) then draw_felt per layer):
@@ -172,19 +177,17 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
 // Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
 // With chan != nullptr the workgroup's first lane then performs the channel step on the fresh root (FRI commit phase): one launch less
 // per layer on the latency-bound path root -> alpha -> next fold.
-__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log, u32* chan, u32* alpha_out, u32* root_out) {
+__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
     for (int lg = (int)top_log - 1; lg >= 0; lg--) {
         const uint4* prev = layers[lg + 1];
         uint4* out = layers[lg];
         for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
             u32 h[8], m[16];
-#pragma unroll
-            for (int k = 0; k < 8; k++) h[k] = B2S_IV[k];
-            h[0] ^= 0x01010020u;
+            node_init(h, rfc);
             uint4 a = prev[4 * i], b = prev[4 * i + 1], c = prev[4 * i + 2], d = prev[4 * i + 3];
             m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
             m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-            blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+            blake2s_compress(h, m, 64u & rfc, rfc);
             out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
         }
         __threadfence_block();
@@ -198,19 +201,21 @@ __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ l
 #endif
 // col_bytes = bytes of column storage this layer reads (for the roofline accounting only)
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
-                  u32 first, u32 count) {
+                  u32 node_conv, u32 first, u32 count) {
     const u32 total = (1u << log) >> out_shift;
     const u32 n = count ? count : total;                 // count == 0: the whole layer
     u32 threads = n < 256 ? (n < 64 ? 64 : n) : 256;
     const double frac = (double)n / (double)total;
-    ProfScope ps(stream, "k_merkle_layer", ((prev ? 64.0 * total : 0.0) + 32.0 * total + col_bytes) * frac);
+    // compressions per node: one for the two children, one per started group of 16 column words (both conventions)
+    const double comp_per_node = (prev ? 1.0 : 0.0) + (double)((ncols + 15) / 16) + ((!prev && ncols == 0) ? 1.0 : 0.0);
+    ProfScope ps(stream, "k_merkle_layer", ((prev ? 64.0 * total : 0.0) + 32.0 * total + col_bytes) * frac, comp_per_node * n, /*dominant=*/true);
     u32 blocks = (n + threads - 1) / threads;
     if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
-    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u);
+    hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u, node_conv ? 0xFFFFFFFFu : 0u);
 }
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32* d_chan, u32* d_alpha8, u32* d_root_copy) {
-    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log));
-    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log, d_chan, d_alpha8, d_root_copy);
+void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy) {
+    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log), (double)((1u << top_log) - 1));
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
 }
 
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {
@@ -219,20 +224,29 @@ void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u
 
 // Proof-of-work search (GrindOps::grind): smallest nonce whose mix_u64 digest has >= pow_bits trailing zero bits
 // (trailing_zeros of the first 16 digest bytes as LE u128). Each launch scans `span` nonces from `base`; the minimum hit is kept.
-__global__ void k_grind(const u32* __restrict__ digest, u64 base, u32 pow_bits, unsigned long long* __restrict__ best) {
+// hashed = Conventions::mix_u64 == 1: digest' = Blake2s-256(digest || LE64(nonce) zero padded to 32 bytes) instead of the raw compression.
+__global__ void k_grind(const u32* __restrict__ digest, u64 base, u32 pow_bits, unsigned long long* __restrict__ best, u32 hashed) {
     u64 nonce = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 h[8], m[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) h[k] = digest[k];
-#pragma unroll
     for (int k = 0; k < 16; k++) m[k] = 0;
-    m[0] = (u32)nonce; m[1] = (u32)(nonce >> 32);
-    blake2s_compress(h, m, 0, 0);
+    if (hashed) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[k] = digest[k];
+        m[8] = (u32)nonce; m[9] = (u32)(nonce >> 32);
+        node_init(h, 0xFFFFFFFFu);
+        blake2s_compress(h, m, 64, 0xFFFFFFFFu);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) h[k] = digest[k];
+        m[0] = (u32)nonce; m[1] = (u32)(nonce >> 32);
+        blake2s_compress(h, m, 0, 0);
+    }
     u32 tz = h[0] ? __ffs(h[0]) - 1 : h[1] ? 32 + __ffs(h[1]) - 1 : h[2] ? 64 + __ffs(h[2]) - 1 : h[3] ? 96 + __ffs(h[3]) - 1 : 128;
     if (tz >= pow_bits) atomicMin(best, (unsigned long long)nonce);
 }
-void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best) {
-    hipLaunchKernelGGL(k_grind, dim3(span / 256), dim3(256), 0, stream, d_digest, base, pow_bits, d_best);
+void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv) {
+    hipLaunchKernelGGL(k_grind, dim3(span / 256), dim3(256), 0, stream, d_digest, base, pow_bits, d_best, mix_u64_conv);
 }
 
 }  // namespace bf

@@ -71,7 +71,14 @@ struct TraceInput {
 // Optional, off by default: the preprocessed tree (IsFirst columns) depends only on LOG_MAX_ROWS, so a deployment that proves many
 // programs can commit it once per context and reuse polynomials, LDE columns and Merkle layers. The reference recomputes it in every
 // prove_brainfuck call (mod.rs:495-500); bench.py's headline number does the same (reuse only with --reuse-preprocessed).
-struct PreprocessedCache { bool enabled = false, valid = false; u32 lmr = 0; DTree tree; Arena keep; };
+// The kept tree is only valid for the configuration it was built under: LOG_MAX_ROWS, the node-hash convention and the shard group
+// (share-wise layers hold one rank's share only) — any change rebuilds it.
+struct PreprocessedCache {
+    bool enabled = false, valid = false; u32 lmr = 0, node_conv = 0, shard_rank = 0, shard_count = 1; DTree tree; Arena keep;
+    bool matches(const Ctx& c, u32 log_max_rows) const {
+        return enabled && valid && lmr == log_max_rows && node_conv == c.conv.merkle_node_hash && shard_rank == c.shard.rank && shard_count == c.shard.count;
+    }
+};
 static std::mutex g_cache_mutex;   // contexts may be driven from different host threads (bench.py --inflight)
 static std::map<Ctx*, PreprocessedCache>& preprocessed_caches() { static std::map<Ctx*, PreprocessedCache> m; return m; }
 static PreprocessedCache& preprocessed_cache_of(Ctx* c) { std::lock_guard<std::mutex> g(g_cache_mutex); return preprocessed_caches()[c]; }   // map nodes are address-stable
@@ -128,6 +135,7 @@ struct HipProver {
     // step: FRI commit phase — the device channel mixes the root and draws the next alpha right behind the tree (fused into the top kernel).
     struct ChannelStep { u32* chan; u32* alpha8; u32* root_copy; };
     DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
+        if (cols_in.empty()) throw HipError("merkle_commit: no columns");
         std::vector<DCol> cols = cols_in;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
         c.stage_checkpoint();
@@ -170,7 +178,7 @@ struct HipProver {
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? (1u << (log - sg.log_count)) : 0u;
             merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
-                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
+                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, c.conv.merkle_node_hash, sg.rank * per_rank, per_rank);
             if (share && log == mk.band_lo) {
                 prof_run_end(c.stream);
                 const size_t slice = (size_t(32) << log) >> sg.log_count;
@@ -183,7 +191,7 @@ struct HipProver {
             }
         }
         prof_run_end(c.stream);
-        if (fused_top > 0) merkle_top(c.stream, dl, fused_top, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
+        if (fused_top > 0) merkle_top(c.stream, dl, fused_top, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
@@ -313,7 +321,8 @@ struct HipProver {
     BrainfuckProof prove(const std::function<const TraceInput&()>& get_input) {
         double t_start = now();
         c.arena.reset();
-        ch = Channel();
+        ch = Channel(c.conv);
+        if (log_max_rows < LOG_N_LANES) throw HipError("log_max_rows must be at least LOG_N_LANES (4)");
         if (log_max_rows + cfg.log_blowup + 1 > c.tw_root_log + 1) throw HipError("context twiddle tree too small for log_max_rows");
         std::vector<DTree> trees(4);
         BrainfuckProof bp;
@@ -326,7 +335,7 @@ struct HipProver {
         PreprocessedCache& cache = preprocessed_cache_of(&c);
         Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
         Hash32* pinned_root1 = pinned_root0 + 1;
-        const bool reuse = cache.enabled && cache.valid && cache.lmr == log_max_rows;
+        const bool reuse = cache.matches(c, log_max_rows);
         BF_HIP(hipEventRecord(c.ev[0], c.stream));
         if (reuse) trees[0] = cache.tree;
         else {
@@ -379,7 +388,10 @@ struct HipProver {
         join_side();
         if (!reuse) {
             trees[0].mk.root = *pinned_root0;
-            if (cache.enabled) { cache.tree = trees[0]; cache.lmr = log_max_rows; cache.valid = true; }
+            if (cache.enabled) {
+                cache.tree = trees[0]; cache.lmr = log_max_rows; cache.node_conv = c.conv.merkle_node_hash;
+                cache.shard_rank = c.shard.rank; cache.shard_count = c.shard.count; cache.valid = true;
+            }
         }
         trees[1].mk.root = *pinned_root1;
         ch.mix_root(trees[0].mk.root);
@@ -468,7 +480,11 @@ struct HipProver {
         for (int k = 0; k < N_COMPONENTS; k++) {
             for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
             u32 ni = 4 * n_logup_cols(k);
-            for (u32 j = 0; j < ni; j++) { if (j + 4 >= ni) mask[2].push_back({0, (u32)(1 + k)}); else mask[2].push_back({0}); }
+            // last logUp column of a component: offsets {0, -1} (LogupAtRow::finalize); which comes first is Conventions::logup_mask_order
+            for (u32 j = 0; j < ni; j++) {
+                if (j + 4 >= ni) { if (c.conv.logup_mask_order == 1) mask[2].push_back({(u32)(1 + k), 0}); else mask[2].push_back({0, (u32)(1 + k)}); }
+                else mask[2].push_back({0});
+            }
         }
         mask[3].assign(4, {0});
         sample(trees, mask, points, bp.proof);
@@ -494,7 +510,7 @@ struct HipProver {
 
         // Sanity check of prover::prove: composition OODS value == constraints evaluated on the sampled mask values.
         {
-            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff);
+            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff, c.conv);
             const auto& cv = bp.proof.sampled_values[3];
             std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
             if (!q_eq(HostPointEval::combine(ce, 0), want)) throw HipError("ConstraintsNotSatisfied");
@@ -756,7 +772,7 @@ struct HipProver {
             unsigned long long best = ~0ull;
             const u32 span = 1u << 16;
             for (u64 base = 0; best == ~0ull; base += span) {
-                grind_span(c.stream, d_digest, base, span, cfg.pow_bits, d_best);
+                grind_span(c.stream, d_digest, base, span, cfg.pow_bits, d_best, c.conv.mix_u64);
                 c.read_back(&best, d_best, 8);
             }
             pf.proof_of_work = best;
@@ -822,9 +838,8 @@ struct HipProver {
 using namespace bf;
 
 struct bfhip_trace { TraceInput in; };
-static bool g_tables_on_gpu = true;
-// Selects where bfhip_trace_create / bfhip_prove_brainfuck build the 13 component tables: 1 = gfx950 kernels (default), 0 = host builders.
-extern "C" int32_t bfhip_set_table_builder(int32_t on_gpu) { g_tables_on_gpu = on_gpu != 0; return 0; }
+// Selects where bfhip_trace_create / bfhip_prove_brainfuck of THIS context build the 13 component tables: 1 = gfx950 kernels (default), 0 = host builders.
+extern "C" int32_t bfhip_ctx_set_table_builder(bfhip_ctx* ctx, int32_t on_gpu) { if (!ctx) { bfhip_set_error("null context"); return -1; } ctx->c.tables_on_gpu = on_gpu != 0; return 0; }
 // Downloads one row-granular column of a resident trace (tests: GPU tables == host tables).
 extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows) {
     try {
@@ -856,21 +871,50 @@ static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_j
     }
 }
 
-extern "C" int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, bfhip_trace** out,
-                                       uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
+static int32_t trace_create_common(bfhip_ctx* ctx, const std::vector<Registers>& vm_trace, const std::vector<u32>& ins, bfhip_trace** out,
+                                   uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
+    if (vm_trace.empty()) throw HipError("EmptyTrace");   // TraceError::EmptyTrace (memory/table.rs:83-86)
+    auto* t = new bfhip_trace();
+    try { HipProver::upload_trace(ctx->c, vm_trace, ins, t->in, /*use_arena=*/false, /*on_gpu=*/ctx->c.tables_on_gpu); } catch (...) { t->in.release(); delete t; throw; }
+    if (log_sizes) memcpy(log_sizes, t->in.log_sizes, sizeof(u32) * N_COMPONENTS);
+    if (n_steps) *n_steps = t->in.n_steps;
+    if (main_cells) *main_cells = t->in.main_cells;
+    if (interaction_cells) *interaction_cells = t->in.interaction_cells;
+    *out = t;
+    return 0;
+}
+extern "C" int32_t bfhip_trace_create_ram(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, size_t ram_size, bfhip_trace** out,
+                                           uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
     try {
+        if (!ctx) throw HipError("null context");
         ctx->c.bind();
         std::vector<u32> ins = compile(code);
-        Machine m(ins, std::vector<u8>(input, input + n_input));
+        Machine m(ins, std::vector<u8>(input, input + n_input), ram_size ? ram_size : Machine::DEFAULT_RAM_SIZE);
         m.execute();
-        auto* t = new bfhip_trace();
-        try { HipProver::upload_trace(ctx->c, m.trace, ins, t->in, /*use_arena=*/false, /*on_gpu=*/g_tables_on_gpu); } catch (...) { t->in.release(); delete t; throw; }
-        if (log_sizes) memcpy(log_sizes, t->in.log_sizes, sizeof(u32) * N_COMPONENTS);
-        if (n_steps) *n_steps = t->in.n_steps;
-        if (main_cells) *main_cells = t->in.main_cells;
-        if (interaction_cells) *interaction_cells = t->in.interaction_cells;
-        *out = t;
-        return 0;
+        return trace_create_common(ctx, m.trace, ins, out, log_sizes, n_steps, main_cells, interaction_cells);
+    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
+}
+extern "C" int32_t bfhip_trace_create(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, bfhip_trace** out,
+                                       uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
+    return bfhip_trace_create_ram(ctx, code, input, n_input, 0, out, log_sizes, n_steps, main_cells, interaction_cells);
+}
+// prove_brainfuck(&Machine) receives an executed machine (mod.rs:471-473): its register trace (mod.rs:508) and its program.
+extern "C" int32_t bfhip_trace_create_from_registers(bfhip_ctx* ctx, const uint32_t* trace7, size_t n_rows, const uint32_t* code_words, size_t n_code,
+                                                      bfhip_trace** out, uint32_t log_sizes[13], uint64_t* main_cells, uint64_t* interaction_cells) {
+    try {
+        if (!ctx) throw HipError("null context");
+        ctx->c.bind();
+        if (!trace7 || n_rows == 0) throw HipError("EmptyTrace");
+        if (!code_words || n_code == 0) throw HipError("empty program");
+        std::vector<Registers> tr(n_rows);
+        for (size_t i = 0; i < n_rows; i++) {
+            const u32* v = trace7 + 7 * i;
+            for (int k = 0; k < 7; k++) if (v[k] >= P31) throw HipError("register value is not a canonical M31");
+            tr[i] = Registers{v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+        }
+        std::vector<u32> ins(code_words, code_words + n_code);
+        for (u32 w : ins) if (w >= P31) throw HipError("program word is not a canonical M31");
+        return trace_create_common(ctx, tr, ins, out, log_sizes, nullptr, main_cells, interaction_cells);
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
 }
 extern "C" int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* t) { (void)ctx; if (t) { t->in.release(); delete t; } return 0; }
@@ -899,7 +943,7 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
             std::vector<u32> ins = compile(code);
             Machine m(ins, std::vector<u8>(input, input + n_input));
             m.execute();
-            HipProver::upload_trace(ctx->c, m.trace, ins, in, /*use_arena=*/true, /*on_gpu=*/g_tables_on_gpu);
+            HipProver::upload_trace(ctx->c, m.trace, ins, in, /*use_arena=*/true, /*on_gpu=*/ctx->c.tables_on_gpu);
             return in;
         });
         fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
@@ -918,14 +962,23 @@ extern "C" int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on) {
 }
 
 // verify_brainfuck (mod.rs:738-797). Host only. 0 = accepted, 1 = rejected (reason in err), -1 = internal error.
-extern "C" int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_t log_max_rows, char* err, size_t err_cap) {
+extern "C" int32_t bfhip_verify_brainfuck_conv(const char* proof_json, size_t proof_len, uint32_t log_max_rows, const bfhip_conventions* conv, char* err, size_t err_cap) {
     try {
+        Conventions cv;
+        if (conv) {
+            if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1) { bfhip_set_error("unknown convention value"); return -1; }
+            cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order;
+        }
         std::string reason;
-        try { BrainfuckProof bp = proof_from_json(proof_json, proof_len); reason = verify_brainfuck(bp, log_max_rows); }
+        try { BrainfuckProof bp = proof_from_json(proof_json, proof_len); reason = verify_brainfuck(bp, log_max_rows, cv); }
         catch (const std::exception& e) { reason = std::string("InvalidStructure: ") + e.what(); }
         if (err && err_cap) snprintf(err, err_cap, "%s", reason.c_str());
         return reason.empty() ? 0 : 1;
     } catch (...) { bfhip_set_error("unknown error"); return -1; }
+}
+
+extern "C" int32_t bfhip_verify_brainfuck(const char* proof_json, size_t proof_len, uint32_t log_max_rows, char* err, size_t err_cap) {
+    return bfhip_verify_brainfuck_conv(proof_json, proof_len, log_max_rows, nullptr, err, err_cap);
 }
 
 // ---- host-only entry points (no GPU needed): compiler, VM and table builders of the drop-in's host side ---------------------------
@@ -933,10 +986,10 @@ extern "C" int32_t bfhip_host_compile(const char* code, uint32_t* out, size_t ca
     try { auto ins = compile(code); *n = ins.size(); if (ins.size() > cap) { bfhip_set_error("capacity"); return -2; } memcpy(out, ins.data(), 4 * ins.size()); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
-extern "C" int32_t bfhip_host_run(const char* code, const uint8_t* input, size_t n_input, uint8_t* out, size_t out_cap, size_t* n_out,
-                                   uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows) {
+extern "C" int32_t bfhip_host_run_ram(const char* code, const uint8_t* input, size_t n_input, size_t ram_size, uint8_t* out, size_t out_cap, size_t* n_out,
+                                       uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows) {
     try {
-        Machine m(compile(code), std::vector<u8>(input, input + n_input));
+        Machine m(compile(code), std::vector<u8>(input, input + n_input), ram_size ? ram_size : Machine::DEFAULT_RAM_SIZE);
         m.execute();
         if (n_out) *n_out = m.output.size();
         if (out && m.output.size() <= out_cap) memcpy(out, m.output.data(), m.output.size());
@@ -945,6 +998,10 @@ extern "C" int32_t bfhip_host_run(const char* code, const uint8_t* input, size_t
             for (size_t i = 0; i < m.trace.size(); i++) { const Registers& r = m.trace[i]; u32 v[7] = {r.clk, r.ip, r.ci, r.ni, r.mp, r.mv, r.mvi}; memcpy(trace7 + 7 * i, v, 28); }
         return 0;
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
+extern "C" int32_t bfhip_host_run(const char* code, const uint8_t* input, size_t n_input, uint8_t* out, size_t out_cap, size_t* n_out,
+                                   uint32_t* trace7, size_t trace_cap_rows, size_t* n_rows) {
+    return bfhip_host_run_ram(code, input, n_input, 0, out, out_cap, n_out, trace7, trace_cap_rows, n_rows);
 }
 // Table of `component` (0..12, claim order of mod.rs:85-99) built from an explicit register trace (7 u32 per row) and compiled program.
 extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t* code, size_t n_code, int32_t component,
@@ -978,9 +1035,17 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
         return 0;
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
-extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) { (void)ctx; prof_enable(mode); return 0; }
-extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) { try { ctx->c.sync(); prof_reset(); return 0; } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } }
+// Profiler state is per stream, i.e. per context: contexts on other threads are not affected (prof.hip).
+static void sync_both(Ctx& c) { c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); }
+extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) {
+    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); return 0; }
+    catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
+extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) {
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); return 0; }
+    catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
+}
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {
-    try { ctx->c.sync(); std::string s = prof_report_json(); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); hipStream_t ss[2] = {ctx->c.stream, ctx->c.stream2}; std::string s = prof_report_json(ss, 2); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }

@@ -290,7 +290,12 @@ void build_tables_device(Ctx& c, const std::vector<u32> trace7_soa[7], u32 n, co
             else { h[0][r] = L - 1; h[3][r] = 1; }
         }
         make_cols(C_PROGRAM, 4, rows);
-        for (int j = 0; j < 4; j++) { const u32* st = c.stage(h[j].data(), rows); BF_HIP(hipMemcpyAsync(cols_out[C_PROGRAM][j], st, rows * sizeof(u32), hipMemcpyDeviceToDevice, s)); }
+        // small programs go through the pinned staging ring (no pageable copy on the timeline); a program too large for it is copied directly
+        const bool direct = size_t(rows) * sizeof(u32) * 4 > c.stage_bytes / 8;
+        for (int j = 0; j < 4; j++) {
+            if (direct) { BF_HIP(hipMemcpyAsync(cols_out[C_PROGRAM][j], h[j].data(), rows * sizeof(u32), hipMemcpyHostToDevice, s)); BF_HIP(hipStreamSynchronize(s)); }
+            else { const u32* st = c.stage(h[j].data(), rows); BF_HIP(hipMemcpyAsync(cols_out[C_PROGRAM][j], st, rows * sizeof(u32), hipMemcpyDeviceToDevice, s)); }
+        }
     }
     // ---- processor (component 3) --------------------------------------------------------------------------------------------------------
     {

@@ -13,6 +13,21 @@ P = (1 << 31) - 1
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "single_conv: run under the default stwo conventions only (not parametrised over CONVENTIONS)")
+
+
+# Byte-level stwo conventions (include/bfhip.h `bfhip_conventions`: merkle_node_hash, mix_u64, logup_mask_order). Every test that uses the
+# `oracle` and/or `ctx` fixture runs once per entry, with the oracle (process-wide switch) and the context set to the same values:
+#   stwo    = defaults (zero-state raw-compress Merkle nodes, raw-compress mix_u64, mask order [0, -1])
+#   rfc7693 = only the Merkle node hash flipped to the RFC 7693 form (round 1's behaviour; tests/golden has the fib19 digest of both)
+#   flipped = every switch on its alternative value
+CONVENTIONS = {"stwo": (0, 0, 0), "rfc7693": (1, 0, 0), "flipped": (1, 1, 1)}
+
+
+def pytest_generate_tests(metafunc):
+    if "conv" in metafunc.fixturenames:
+        single = metafunc.definition.get_closest_marker("single_conv") is not None
+        metafunc.parametrize("conv", ["stwo"] if single else list(CONVENTIONS), indirect=True, scope="function")
 
 
 def load_package():
@@ -45,6 +60,16 @@ class Oracle:
         if rc < 0:
             raise RuntimeError(self.L.orc_last_error().decode())
         return rc
+
+    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
+        self._chk(self.L.orc_set_conventions(merkle_node_hash, mix_u64, logup_mask_order))
+
+    def hash_node(self, left, right, values):
+        """Blake2sMerkleHasher::hash_node under the current convention. left/right: 32-byte strings or None; values: u32 list."""
+        vals = np.ascontiguousarray(values, dtype=np.uint32)
+        out = (ctypes.c_ubyte * 32)()
+        self._chk(self.L.orc_hash_node(left, right, vals.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(vals.size), out))
+        return bytes(out)
 
     def blake2s(self, data: bytes) -> bytes:
         out = (ctypes.c_ubyte * 32)()
@@ -143,8 +168,26 @@ class Oracle:
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def _oracle():
     return Oracle()
+
+
+@pytest.fixture
+def conv(request, _oracle, pkg):
+    """The convention set of this test run: (merkle_node_hash, mix_u64, logup_mask_order). The oracle (process-wide switch), every live
+    product context, contexts created during the test and the product verifier's default are switched to it."""
+    name = getattr(request, "param", "stwo")
+    values = CONVENTIONS[name]
+    _oracle.set_conventions(*values)
+    pkg.set_default_conventions(*values)
+    yield values
+    _oracle.set_conventions(0, 0, 0)
+    pkg.set_default_conventions(0, 0, 0)
+
+
+@pytest.fixture
+def oracle(_oracle, conv):
+    return _oracle
 
 
 @pytest.fixture(scope="session")
@@ -156,10 +199,60 @@ def pkg():
 
 
 @pytest.fixture(scope="session")
-def ctx(pkg):
+def _ctx(pkg):
     c = pkg.Context(0, max_log_domain=24)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx(_ctx, conv):
+    return _ctx
+
+
+# ---- independent restatement of the two Merkle node-hash conventions (pure Python; checks the oracle and, through it, the kernels) ----
+_B2S_IV = [0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19]
+_B2S_SIGMA = [
+    [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], [14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3],
+    [11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4], [7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8],
+    [9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13], [2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9],
+    [12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11], [13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10],
+    [6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5], [10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0]]
+
+
+def py_blake2s_compress(h, m, t0=0, t1=0, f0=0, f1=0):
+    """RFC 7693 section 3.2 compression function F for Blake2s (what stwo's blake2s_ref::compress(h, m, t0, t1, f0, f1) computes).
+    h: 8 words, m: 16 words. Pinned against hashlib in tests/test_oracle_math.py::test_python_compress_reproduces_hashlib."""
+    M = 0xFFFFFFFF
+    rot = lambda x, r: ((x >> r) | (x << (32 - r))) & M
+    v = list(h) + list(_B2S_IV)
+    v[12] ^= t0; v[13] ^= t1; v[14] ^= f0; v[15] ^= f1
+
+    def g(a, b, c, d, x, y):
+        v[a] = (v[a] + v[b] + x) & M; v[d] = rot(v[d] ^ v[a], 16); v[c] = (v[c] + v[d]) & M; v[b] = rot(v[b] ^ v[c], 12)
+        v[a] = (v[a] + v[b] + y) & M; v[d] = rot(v[d] ^ v[a], 8); v[c] = (v[c] + v[d]) & M; v[b] = rot(v[b] ^ v[c], 7)
+
+    for s in _B2S_SIGMA:
+        g(0, 4, 8, 12, m[s[0]], m[s[1]]); g(1, 5, 9, 13, m[s[2]], m[s[3]]); g(2, 6, 10, 14, m[s[4]], m[s[5]]); g(3, 7, 11, 15, m[s[6]], m[s[7]])
+        g(0, 5, 10, 15, m[s[8]], m[s[9]]); g(1, 6, 11, 12, m[s[10]], m[s[11]]); g(2, 7, 8, 13, m[s[12]], m[s[13]]); g(3, 4, 9, 14, m[s[14]], m[s[15]])
+    return [h[i] ^ v[i] ^ v[i + 8] for i in range(8)]
+
+
+def py_hash_node(node_conv, left, right, values):
+    """Blake2sMerkleHasher::hash_node restated for both conventions. left/right: bytes(32) or None; values: iterable of u32."""
+    import hashlib
+    import struct
+    values = [int(v) for v in values]
+    if node_conv == 1:      # RFC 7693 hash of left || right || LE values
+        return hashlib.blake2s((left + right if left is not None else b"") + b"".join(struct.pack("<I", v) for v in values)).digest()
+    state = [0] * 8         # stwo: zero state, raw compressions, column words zero padded to a multiple of 16
+    if left is not None:
+        state = py_blake2s_compress(state, list(struct.unpack("<16I", left + right)))
+    rem = 15 - ((len(values) + 15) % 16)
+    padded = values + [0] * rem
+    for o in range(0, len(padded), 16):
+        state = py_blake2s_compress(state, padded[o:o + 16])
+    return struct.pack("<8I", *state)
 
 
 def splitmix_column(seed: int, n: int) -> np.ndarray:

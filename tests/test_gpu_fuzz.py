@@ -20,8 +20,8 @@ def test_random_program_proof_matches_oracle(ctx, pkg, oracle, seed, max_steps):
     assert got == want, code
     assert pkg.verify_brainfuck(got, log_max_rows) == (True, "")
     if seed % 4 == 0:                                              # host table builders instead of the GPU ones
-        pkg.set_table_builder(False)
+        ctx.set_table_builder(False)
         try:
             assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows) == want
         finally:
-            pkg.set_table_builder(True)
+            ctx.set_table_builder(True)

@@ -115,7 +115,9 @@ def test_merkle_layers_match_oracle(ctx, oracle):
     assert bytes(ctx.download(prev, 8).view(np.uint8)) == bytes(root)
 
 
-def test_merkle_leaf_matches_hashlib_with_replicated_column(ctx):
+def test_merkle_leaf_matches_python_restatement_with_replicated_column(ctx, conv):
+    """Leaf layer of the GPU kernel against the independent Python restatement of the node hash (conftest.py_hash_node), both conventions."""
+    from conftest import py_hash_node
     log = 6
     full = splitmix_column(31, 1 << log); rows = splitmix_column(32, 1 << (log - 4))
     pf, pr = ctx.upload(full), ctx.upload(rows)
@@ -123,8 +125,26 @@ def test_merkle_leaf_matches_hashlib_with_replicated_column(ctx):
     ctx.merkle_commit_layer(log, 0, [pf, pr], out, col_shifts=[0, 4])
     got = ctx.download(out, 8 << log).view(np.uint8).reshape(-1, 32)
     for i in range(1 << log):
-        msg = int(full[i]).to_bytes(4, "little") + int(rows[i >> 4]).to_bytes(4, "little")
-        assert bytes(got[i]) == hashlib.blake2s(msg).digest()
+        assert bytes(got[i]) == py_hash_node(conv[0], None, None, [full[i], rows[i >> 4]])
+
+
+@pytest.mark.parametrize("ncols", [0, 1, 5, 16, 17, 40])
+def test_merkle_inner_nodes_match_python_restatement(ctx, conv, ncols):
+    """Nodes with children and 0..40 columns (1..4 compressions, the zero-padding boundaries at 16 and 17 columns) against the Python
+    restatement, both conventions."""
+    from conftest import py_hash_node
+    log = 3
+    prev_bytes = np.frombuffer(b"".join(hashlib.sha256(bytes([k])).digest() for k in range(2 << log)), dtype=np.uint8)
+    cols = [splitmix_column(700 + k, 1 << log) for k in range(ncols)]
+    dprev = ctx.upload(prev_bytes)
+    dcols = [ctx.upload(c) for c in cols]
+    out = ctx.malloc(32 << log)
+    ctx.merkle_commit_layer(log, dprev, dcols, out)
+    got = ctx.download(out, 8 << log).view(np.uint8).reshape(-1, 32)
+    pb = prev_bytes.tobytes()
+    for i in range(1 << log):
+        l, r = pb[64 * i: 64 * i + 32], pb[64 * i + 32: 64 * i + 64]
+        assert bytes(got[i]) == py_hash_node(conv[0], l, r, [c[i] for c in cols])
 
 
 @pytest.mark.parametrize("log", [1, 2, 5, 11, 16])

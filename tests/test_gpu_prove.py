@@ -81,9 +81,10 @@ def test_integration_programs_match_oracle(pkg, oracle, name, inp, expected):
     assert pkg.verify_brainfuck(got, lmr) == (True, "")
 
 
-def test_fib19_full_size_proof_verifies(pkg, oracle):
+def test_fib19_full_size_proof_verifies(pkg, oracle, conv):
     """BASELINE config 2 at full size (LOG_MAX_ROWS = 24, 2^24-row memory component): the oracle's verifier accepts the HIP proof and
-    rejects it after a one-word change, and the proof bytes hash to the committed digest of the oracle's own proof of this workload."""
+    rejects it after a one-word change, and the proof bytes hash to the committed digest of the oracle's own proof of this workload
+    under the same conventions (digests exist for the default `stwo` set and for `rfc7693`)."""
     c = pkg.Context(0, max_log_domain=26)
     try:
         tr = pkg.Trace(c, _prog("fib19.bf"))
@@ -99,13 +100,17 @@ def test_fib19_full_size_proof_verifies(pkg, oracle):
         # byte parity at full size: the oracle's own proof of this workload, as a committed digest (it needs minutes of CPU time;
         # tests/golden/make_fib19_proof_digest.py)
         import hashlib, json
-        want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))
-        assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["sha256"]
+        digests = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))
+        want = next((d for d in digests.values() if tuple(d["conventions"]) == tuple(conv)), None)
+        assert want is not None or tuple(conv) == (1, 1, 1), "no committed digest for the default conventions"
+        if want is not None:
+            assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["sha256"]
         tr.close()
     finally:
         c.close()
 
 
+@pytest.mark.single_conv
 def test_synthetic_2_to_26_row_trace_verifies(pkg, oracle):
     """BASELINE configs 3-5 family: a nested-counter program whose Memory component has 2^22 table rows = 2^26 domain rows, proved with
     the raised LOG_MAX_ROWS = 26 (2.3 * 10^9 trace cells, transforms up to 2^28 cells). No CPU proof at this size: the oracle's
@@ -191,3 +196,77 @@ def test_reusing_the_preprocessed_tree_does_not_change_the_proof(pkg, oracle):
         assert b3 == oracle.prove("++[-]+.", b"", log_max_rows=20)[0]
     finally:
         c.close()
+
+
+def test_trace_from_registers_equals_trace_from_source(pkg, oracle, ctx):
+    """bfhip_trace_create_from_registers: what prove_brainfuck(&Machine) receives (mod.rs:471-473, inputs.trace() :508) — the executed
+    machine's register rows and program words; no re-execution. Same proof as the source-text entry and as the oracle."""
+    code, inp = "+++>,<[>+.<-]", b"\x01"
+    _, rows = oracle.run(code, inp)
+    t = pkg.Trace.from_registers(ctx, rows, oracle.compile(code))
+    try:
+        assert t.log_sizes == oracle.log_sizes(code, inp)[0]
+        proof, _ = t.prove(20)
+    finally:
+        t.close()
+    assert proof == oracle.prove(code, inp, log_max_rows=20)[0]
+    with pytest.raises(pkg.BfhipError, match="EmptyTrace"):
+        pkg.Trace.from_registers(ctx, rows[:0], oracle.compile(code))
+    bad = rows.copy(); bad[1, 4] = (1 << 31) - 1          # not a canonical M31
+    with pytest.raises(pkg.BfhipError, match="canonical"):
+        pkg.Trace.from_registers(ctx, bad, oracle.compile(code))
+
+
+def test_ram_size_option(pkg, ctx):
+    """MachineBuilder::with_ram_size (machine.rs:56-60, `--ram-size` of bin/brainfuck_prover.rs): cell 30000 is out of range for the
+    default 30000-cell RAM and fine with 30001 cells; the proof equals the one built from the same machine's register rows."""
+    import ctypes
+    import numpy as np
+    code = ">" * 30000 + "+."
+    with pytest.raises(pkg.BfhipError):
+        pkg.Trace(ctx, code, b"")
+    t = pkg.Trace(ctx, code, b"", ram_size=30001)
+    try:
+        proof, _ = t.prove(20)
+    finally:
+        t.close()
+    L = pkg.lib()
+    n_out, n_rows = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.bfhip_host_run_ram(code.encode(), b"", ctypes.c_size_t(0), ctypes.c_size_t(30001), None, ctypes.c_size_t(0), ctypes.byref(n_out), None, ctypes.c_size_t(0), ctypes.byref(n_rows)) == 0
+    rows = np.zeros((n_rows.value, 7), dtype=np.uint32)
+    out = (ctypes.c_ubyte * 1)()
+    assert L.bfhip_host_run_ram(code.encode(), b"", ctypes.c_size_t(0), ctypes.c_size_t(30001), out, ctypes.c_size_t(1), ctypes.byref(n_out), rows.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.c_size_t(n_rows.value), ctypes.byref(n_rows)) == 0
+    assert bytes(out) == b"\x01" and rows[-1, 4] == 30000
+    words = np.zeros(len(code) + 4, dtype=np.uint32); n = ctypes.c_size_t()
+    assert L.bfhip_host_compile(code.encode(), words.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(words.size), ctypes.byref(n)) == 0
+    t2 = pkg.Trace.from_registers(ctx, rows, words[: n.value])
+    try:
+        assert t2.prove(20)[0] == proof
+    finally:
+        t2.close()
+    assert pkg.verify_brainfuck(proof, 20) == (True, "")
+
+
+def test_reuse_preprocessed_survives_a_convention_change(pkg, oracle):
+    """The kept preprocessed tree is keyed on what it was built under (it used to be keyed on LOG_MAX_ROWS only)."""
+    c = pkg.Context(0, max_log_domain=22)
+    try:
+        pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 1)
+        code, inp = "++[-]+.", b""
+        a = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20)
+        cur = c.get_conventions()
+        other = (1 - cur[0], cur[1], cur[2])
+        c.set_conventions(*other)
+        b = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20)          # must rebuild, not reuse the tree hashed the other way
+        assert pkg.verify_brainfuck(b, 20, conventions=other) == (True, "")
+        c.set_conventions(*cur)
+        assert pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20) == a == oracle.prove(code, inp, log_max_rows=20)[0]
+        pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 0)
+    finally:
+        c.close()
+
+
+def test_log_max_rows_below_lanes_is_an_error(pkg, ctx):
+    with pytest.raises(pkg.BfhipError, match="LOG_N_LANES"):
+        pkg.prove_brainfuck("+", b"", ctx=ctx, log_max_rows=3)

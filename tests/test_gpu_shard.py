@@ -83,7 +83,7 @@ def test_fib19_full_size_in_a_shard_group_of_two(pkg):
     import hashlib, json
     code = open(os.path.join(PROGS, "fib19.bf")).read()
     proofs, _ = _prove_sharded(pkg, code, b"", 24, 2)
-    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))["stwo"]
     for p in proofs:
         assert hashlib.sha256(p).hexdigest() == want["sha256"]
 

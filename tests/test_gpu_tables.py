@@ -28,11 +28,11 @@ def big_ctx(pkg):
 @pytest.mark.parametrize("code,inp", CASES, ids=[c[0] for c in CASES])
 def test_gpu_tables_equal_host_tables(pkg, oracle, big_ctx, code, inp):
     code = _code(code)
-    pkg.set_table_builder(True)
+    big_ctx.set_table_builder(True)
     tg = pkg.Trace(big_ctx, code, inp)
-    pkg.set_table_builder(False)
+    big_ctx.set_table_builder(False)
     th = pkg.Trace(big_ctx, code, inp)
-    pkg.set_table_builder(True)
+    big_ctx.set_table_builder(True)
     try:
         assert tg.log_sizes == th.log_sizes == oracle.log_sizes(code, inp)[0]
         ncols = [8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7]
@@ -46,9 +46,9 @@ def test_gpu_tables_equal_host_tables(pkg, oracle, big_ctx, code, inp):
 
 def test_proof_identical_with_either_table_builder(pkg, oracle, big_ctx):
     code, inp = _code("file:hello_kakarot.bf"), b""
-    pkg.set_table_builder(False)
+    big_ctx.set_table_builder(False)
     a = pkg.prove_brainfuck(code, inp, ctx=big_ctx, log_max_rows=17)
-    pkg.set_table_builder(True)
+    big_ctx.set_table_builder(True)
     b = pkg.prove_brainfuck(code, inp, ctx=big_ctx, log_max_rows=17)
     assert a == b
     want, _, _ = oracle.prove(code, inp, log_max_rows=17)
@@ -65,7 +65,7 @@ def _golden_tables():
 def test_gpu_tables_match_the_reference_vectors(pkg, big_ctx, v):
     """The device table builders against the rows the reference's own unit tests pin (tests/golden/reference_vectors.json: processor,
     left, jump-if-not-zero, instruction x2, program, end-of-execution) — the same vectors that pin the oracle and the host builders."""
-    pkg.set_table_builder(True)
+    big_ctx.set_table_builder(True)
     t = pkg.Trace(big_ctx, v["code"], bytes(v["input"]))
     try:
         want = np.array(v["expected"], dtype=np.uint32)

@@ -40,6 +40,7 @@ def test_vm_and_table_builders_are_clean(harness, tmp_path, name, inp):
     assert r.returncode == 0 and r.stdout.startswith("steps "), r.stdout + r.stderr
 
 
+@pytest.mark.single_conv      # the harness verifies under the default conventions
 def test_verifier_is_clean_on_valid_and_mutated_proofs(harness, oracle, tmp_path):
     code, inp, lmr = "+++>,<[>+.<-]", b"\x01", 10
     proof, _, _ = oracle.prove(code, inp, log_max_rows=lmr)

@@ -5,10 +5,35 @@ import re
 import pytest
 
 
-@pytest.fixture(scope="module")
-def proof(oracle):
-    js, _, _ = oracle.prove("+++>,<[>+.<-]", b"\x01", log_max_rows=12)
-    return js
+_PROOF = {}
+
+
+@pytest.fixture
+def proof(oracle, conv):
+    if conv not in _PROOF:
+        _PROOF[conv] = oracle.prove("+++>,<[>+.<-]", b"\x01", log_max_rows=12)[0]
+    return _PROOF[conv]
+
+
+def test_proof_verifies_only_under_its_own_conventions(pkg, oracle, proof, conv):
+    """A proof is bound to the byte-level conventions it was produced under (include/bfhip.h bfhip_conventions)."""
+    from conftest import CONVENTIONS
+    for other in CONVENTIONS.values():
+        ok, _ = pkg.verify_brainfuck(proof, 12, conventions=other)
+        assert ok == (tuple(other) == tuple(conv))
+
+
+def test_verifier_rejects_non_canonical_json(pkg, proof):
+    """serde_json (the reference's reader, bin/brainfuck_prover.rs:146-151) rejects these; so must the product's reader."""
+    import re as _re
+    assert pkg.verify_brainfuck(proof + b" ", 12)[0]                        # trailing whitespace is fine
+    assert not pkg.verify_brainfuck(proof + b"x", 12)[0]                    # trailing bytes
+    assert not pkg.verify_brainfuck(proof + proof, 12)[0]
+    m = _re.search(rb'"log_size":(\d+)', proof)
+    wrapped = str(int(m.group(1)) + (1 << 64)).encode()                      # wraps to the same value modulo 2^64
+    assert not pkg.verify_brainfuck(proof[: m.start(1)] + wrapped + proof[m.end(1):], 12)[0]
+    assert not pkg.verify_brainfuck(proof[: m.start(1)] + b"0" + m.group(1) + proof[m.end(1):], 12)[0]   # leading zero
+    assert not pkg.verify_brainfuck(proof.replace(b"null", b"nuII", 1), 12)[0]
 
 
 def test_accepts_valid_proof(pkg, oracle, proof):

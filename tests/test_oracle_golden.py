@@ -152,3 +152,15 @@ def test_blake2s_matches_hashlib_on_random_lengths(oracle):
     for n in [1, 31, 32, 63, 64, 65, 127, 128, 129, 1000]:
         m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert oracle.blake2s(m) == hashlib.blake2s(m).digest()
+
+
+def test_host_run_ram_size(pkg):
+    """Machine::new_with_config (machine.rs:116-131): RAM size is a parameter; the default is 30000 cells (machine.rs:114)."""
+    L = pkg.lib()
+    code = (">" * 30000 + "+").encode()
+    n_out, n_rows = ctypes.c_size_t(), ctypes.c_size_t()
+    args = (None, ctypes.c_size_t(0), ctypes.byref(n_out), None, ctypes.c_size_t(0), ctypes.byref(n_rows))
+    assert L.bfhip_host_run(code, b"", ctypes.c_size_t(0), *args) != 0                                   # cell 30000 is out of range
+    assert L.bfhip_host_run_ram(code, b"", ctypes.c_size_t(0), ctypes.c_size_t(0), *args) != 0          # 0 = the default size
+    assert L.bfhip_host_run_ram(code, b"", ctypes.c_size_t(0), ctypes.c_size_t(30001), *args) == 0
+    assert n_rows.value == 30002

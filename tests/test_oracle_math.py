@@ -104,15 +104,47 @@ def test_replicated_column_has_sparse_coefficients(oracle):
     assert np.all(lde == lde[:, :1])
 
 
-def test_merkle_root_matches_hashlib(oracle):
-    """Mixed-degree tree: node = blake2s(left || right || LE u32 of the columns of that layer's size)."""
+def test_python_compress_reproduces_hashlib():
+    """Pins conftest.py_blake2s_compress (the F function both node-hash conventions are built from) to hashlib's Blake2s-256 on one-
+    and two-block messages: h0 = IV ^ 0x01010020, byte counter t, final flag."""
+    import struct
+    from conftest import _B2S_IV, py_blake2s_compress
+    for msg in [b"", b"abc", bytes(range(64)), bytes(range(100)), bytes(200)]:
+        h = list(_B2S_IV); h[0] ^= 0x01010020
+        blocks = [msg[i:i + 64] for i in range(0, max(len(msg), 1), 64)] or [b""]
+        t = 0
+        for k, b in enumerate(blocks):
+            last = k == len(blocks) - 1
+            t += len(b)
+            h = py_blake2s_compress(h, list(struct.unpack("<16I", b.ljust(64, b"\0"))), t0=t, f0=0xFFFFFFFF if last else 0)
+        assert struct.pack("<8I", *h) == hashlib.blake2s(msg).digest()
+
+
+@pytest.mark.parametrize("n_vals", [0, 1, 4, 15, 16, 17, 33])
+def test_hash_node_matches_python_restatement(oracle, conv, n_vals):
+    """Blake2sMerkleHasher::hash_node of the oracle under the current convention == the independent Python restatement, with and without
+    children, over the chunk boundaries of the zero-padding rule (rem = 15 - ((len + 15) % 16))."""
+    from conftest import py_hash_node
+    vals = splitmix_column(900 + n_vals, max(n_vals, 1))[:n_vals]
+    l, r = hashlib.sha256(b"l").digest(), hashlib.sha256(b"r").digest()
+    assert oracle.hash_node(l, r, vals) == py_hash_node(conv[0], l, r, vals)
+    if n_vals:
+        assert oracle.hash_node(None, None, vals) == py_hash_node(conv[0], None, None, vals)
+    if conv[0] == 0 and n_vals == 0:
+        assert oracle.hash_node(None, None, vals) == bytes(32)      # nothing absorbed: the zero state
+
+
+def test_merkle_root_matches_python_restatement(oracle, conv):
+    """Mixed-degree tree: node = hash_node(left, right, values of the columns of that layer's size), commit order kept inside a size."""
+    from conftest import py_hash_node
     big = [splitmix_column(40 + k, 8) for k in range(3)]     # log 3
     small = [splitmix_column(50, 2)]                           # log 1
     cols = [big[0], small[0], big[1], big[2]]                  # commit order is preserved inside a size class
-    layer = [hashlib.blake2s(b"".join(int(c[i]).to_bytes(4, "little") for c in big)).digest() for i in range(8)]
-    layer = [hashlib.blake2s(layer[2 * i] + layer[2 * i + 1]).digest() for i in range(4)]
-    layer = [hashlib.blake2s(layer[2 * i] + layer[2 * i + 1] + int(small[0][i]).to_bytes(4, "little")).digest() for i in range(2)]
-    root = hashlib.blake2s(layer[0] + layer[1]).digest()
+    H = lambda l, r, v: py_hash_node(conv[0], l, r, v)
+    layer = [H(None, None, [c[i] for c in big]) for i in range(8)]
+    layer = [H(layer[2 * i], layer[2 * i + 1], []) for i in range(4)]
+    layer = [H(layer[2 * i], layer[2 * i + 1], [small[0][i]]) for i in range(2)]
+    root = H(layer[0], layer[1], [])
     ptrs = (ctypes.c_void_p * 4)(*[c.ctypes.data for c in cols])
     logs = (ctypes.c_uint32 * 4)(3, 1, 3, 3)
     out = (ctypes.c_ubyte * 32)()
@@ -120,7 +152,7 @@ def test_merkle_root_matches_hashlib(oracle):
     assert bytes(out) == root
 
 
-def test_channel_primitives(oracle):
+def test_channel_primitives(oracle, conv):
     ch = ctypes.c_void_p(oracle.L.orc_channel_new())
     d = (ctypes.c_ubyte * 32)()
     oracle.L.orc_channel_digest(ch, d)
@@ -141,6 +173,16 @@ def test_channel_primitives(oracle):
     if np.all(words < 2 * P):
         assert list(out) == [int(w % P) for w in words[:4]]
     nonce = oracle.L.orc_channel_grind(ch, 5)
+    oracle.L.orc_channel_digest(ch, d)
+    before = bytes(d)
     oracle.L.orc_channel_mix_u64(ch, ctypes.c_uint64(nonce))
     assert oracle.L.orc_channel_trailing_zeros(ch) >= 5
+    oracle.L.orc_channel_digest(ch, d)
+    import struct
+    from conftest import py_blake2s_compress
+    if conv[1] == 0:    # mix_u64 = raw compression of [lo, hi, 0 x 14] on the digest words
+        want = struct.pack("<8I", *py_blake2s_compress(list(struct.unpack("<8I", before)), [nonce & 0xFFFFFFFF, nonce >> 32] + [0] * 14))
+    else:               # Blake2s-256(digest || LE64(n) zero padded to 32 bytes)
+        want = hashlib.blake2s(before + struct.pack("<Q", nonce) + bytes(24)).digest()
+    assert bytes(d) == want
     oracle.L.orc_channel_free(ch)

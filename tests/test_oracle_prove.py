@@ -20,15 +20,20 @@ E2E = [
 ]
 
 
-@pytest.fixture(scope="module")
-def proofs(oracle):
-    out = []
-    for code, inp in E2E:
-        ls, _ = oracle.log_sizes(code, inp)
-        lmr = max(LMR, max(ls))
-        js, tr, _ = oracle.prove(code, inp, log_max_rows=lmr)
-        out.append((js, lmr))
-    return out
+_PROOFS = {}   # convention set -> proofs (the oracle fixture is per test: it follows the convention parametrisation)
+
+
+@pytest.fixture
+def proofs(oracle, conv):
+    if conv not in _PROOFS:
+        out = []
+        for code, inp in E2E:
+            ls, _ = oracle.log_sizes(code, inp)
+            lmr = max(LMR, max(ls))
+            js, tr, _ = oracle.prove(code, inp, log_max_rows=lmr)
+            out.append((js, lmr))
+        _PROOFS[conv] = out
+    return _PROOFS[conv]
 
 
 def test_prove_verify_roundtrip(oracle, proofs):
