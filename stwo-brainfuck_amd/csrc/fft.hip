@@ -452,6 +452,9 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
         u32 ns = nl > 12 ? (nl - 12 + 6) / 7 : 0;
         u32 k0 = nl - 7 * ns;
         int np = 1 + (int)ns;
+        // profiler accounting: `bytes` = what this pass moves (4 B in + 4 B out per cell), `units` = this pass's share of the transform's
+        // ALGORITHMIC bytes (iFFT 8N, LDE 12N per column = read the input once, write the output once)
+        const double alg = 4.0 * ncols * ((double)(1u << src_log) + (double)(1u << log)) / np;
         for (int pi = 0; pi < np; pi++) {
             int p = inverse ? pi : np - 1 - pi;
             bool first = pi == 0, last = pi == np - 1;
@@ -467,12 +470,12 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
             dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
             if (p == 0) {
                 a.lo = 0; a.k = k0; a.tile_log = 12;
-                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", 8.0 * ncols * (double)(1u << log));
+                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", 8.0 * ncols * (double)(1u << log), alg);
                 if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, a);
                 else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, a);
             } else {
                 a.lo = k0 + 7 * (p - 1); a.k = 7;
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", 8.0 * ncols * (double)(1u << log));
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", 8.0 * ncols * (double)(1u << log), alg);
                 if (inverse) hipLaunchKernelGGL(k_fft_strided7<true>, grid, dim3(128), 0, stream, a);
                 else hipLaunchKernelGGL(k_fft_strided7<false>, grid, dim3(128), 0, stream, a);
             }
@@ -491,6 +494,7 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
         u32 kk = (rem + passes_left - 1) / passes_left;  // balance the strided passes
         bounds[np + 1] = bounds[np] + kk; np++;
     }
+    const double alg = 4.0 * ncols * ((double)(1u << src_log) + (double)(1u << log)) / np;
     for (int pi = 0; pi < np; pi++) {
         int p = inverse ? pi : np - 1 - pi;
         bool first = pi == 0, last = pi == np - 1;
@@ -506,7 +510,7 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
         while ((u64)ntiles * ((ncols + cpb - 1) / cpb) > 8192 && cpb < ncols) cpb *= 2;
         a.cols_per_block = cpb;
         dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
-        ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", 8.0 * ncols * (double)(1u << log));
+        ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", 8.0 * ncols * (double)(1u << log), alg);
         if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, a);
         else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, a);
     }
