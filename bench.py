@@ -236,8 +236,10 @@ def main():
     if sharded:
         if args.inflight > 1:
             raise SystemExit("--shard and --inflight are exclusive")
+        # control plane only: rank 0's RCCL unique id reaches the others through torch.distributed; every data-path exchange of the proof
+        # is issued by libbfhip itself on the context's stream (RCCL over xGMI, device buffers on both ends)
         dev = torch.device("cuda", device) if args.dist_backend == "nccl" else None
-        ctx.set_shard(rank, world, *replicas.shard_exchanges(dist, dev))
+        ctx.join_rccl_group(replicas.share_unique_id(dist, pkg.rccl_unique_id, dev), rank, world)
 
     def sync():
         ctx.sync()
@@ -340,7 +342,7 @@ def main():
                        "conventions": list(conv), "own_verifier_accepts": bool(verified)},
             "config": {"workload": "fib19.bf, largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle, 1 proof per step",
                        "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
-                       "component_log_sizes": trace.log_sizes, "parallelism": ("shard group: one proof over all ranks" if sharded else "replicas") if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
+                       "component_log_sizes": trace.log_sizes, "parallelism": ("shard group: one proof over all ranks (column-sharded transforms, row-sharded Merkle/constraints/quotients/folds, RCCL)" if sharded else "replicas") if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
                        "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()},
                        "headline_2^22": ({"cells_per_s": headline22["cells_per_s"], "ms_per_proof": headline22["ms_per_proof"], "cells": headline22["cells"],
                                           "workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')"}
@@ -355,7 +357,7 @@ def main():
     if args.reuse_preprocessed:
         lib.bfhip_ctx_reuse_preprocessed(ctx._h, 0)
     if sharded:
-        ctx.set_shard(0, 1)
+        ctx.leave_group()
     for c2, t2 in extra:
         t2.close(); c2.close()
     trace.close()

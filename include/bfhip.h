@@ -165,19 +165,35 @@ int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint
 int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
                               char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
 void bfhip_free_host(void* p);
-/* ---- one proof over several GPUs: row-sharded commitments --------------------------------------------------------------------------
- * north_star: "columns shard across the GPUs of one node, Merkle root reduced via RCCL". Every rank of a shard group runs the same
- * proof on the same trace (identical transcript), but of every large Merkle layer it hashes only its contiguous 1/count share of the
- * nodes — hashing is >50 % of a proof. Two exchanges per proof path, both tiny and supplied by the host program as callbacks
- * (torch.distributed / RCCL in bench.py; any MPI-like layer works):
- *   allgather      — once per committed tree: every rank contributes its slice of the smallest sharded layer (256 nodes = 8 KiB);
- *                    all ranks then finish the top of the tree redundantly and obtain the same root.
- *   allreduce_max  — once per proof: the decommitment words (each hash witness is held by exactly one rank, zero elsewhere).
- * count must be a power of two; rank < count. count = 1 (default) switches the mode off. Callbacks return 0 on success; buffers are
- * host memory. The proof is byte-identical to the single-GPU proof. */
-typedef int32_t (*bfhip_allgather_fn)(void* user, const void* send_h, size_t bytes_per_rank, void* recv_h);
-typedef int32_t (*bfhip_allreduce_max_u32_fn)(void* user, uint32_t* buf_h, size_t n);
-int32_t bfhip_ctx_set_shard(bfhip_ctx* ctx, uint32_t rank, uint32_t count, bfhip_allgather_fn allgather, bfhip_allreduce_max_u32_fn allreduce_max, void* user);
+/* ---- one proof over several GPUs (shard group) ------------------------------------------------------------------------------------------
+ * north_star: "trace columns shard naturally across the 8 GPUs of one node, with the Merkle root and FRI fold reduced via RCCL over xGMI"
+ * (SURVEY.md section 8(e)). The ranks of a group prove ONE trace together and all return the byte-identical proof of the single-GPU path:
+ *   - the full-size columns of the interaction and composition trees are COLUMN-sharded for interpolation / LDE (greedy by size), then one
+ *     grouped send-receive cuts every LDE column into contiguous bit-reversed ROW ranges (contiguous ranges of a bit-reversed circle domain
+ *     are sub-cosets), together with a previous-row copy of each component's last logUp column (its mask offset -1 is not a halo);
+ *   - Merkle subtrees, constraint evaluation, FRI quotients and the FRI folds down to 2^12 rows per rank are row-local; one all-gather per
+ *     tree completes the layer of 256 nodes per rank, the top is hashed redundantly so that every rank feeds the same root to its channel;
+ *   - out-of-domain samples and decommitment words are each produced by one rank and completed by a max-reduce (exact: zero elsewhere).
+ * Every exchange is issued by the library on the context's own stream with device buffers on both ends; the host program supplies no
+ * callbacks. Two transports:
+ *   RCCL  — one process per GPU: rank 0 calls bfhip_rccl_unique_id, the host program hands the 128 bytes to the other ranks (any control
+ *           channel: torch.distributed, MPI, a file), every rank calls bfhip_ctx_join_rccl_group. librccl is loaded on first use.
+ *   local — the N contexts belong to one process and are driven by N host threads (used by the tests to run N ranks on one GPU).
+ * count must be a power of two in [2, 64]. Every rank must issue the same sequence of prove calls on the same trace. */
+typedef struct bfhip_local_group bfhip_local_group;
+int32_t bfhip_local_group_create(uint32_t count, bfhip_local_group** out);
+int32_t bfhip_local_group_destroy(bfhip_local_group* group);
+int32_t bfhip_ctx_join_local_group(bfhip_ctx* ctx, bfhip_local_group* group, uint32_t rank);
+int32_t bfhip_rccl_unique_id(uint8_t id[128]);
+int32_t bfhip_ctx_join_rccl_group(bfhip_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t count);
+int32_t bfhip_ctx_leave_group(bfhip_ctx* ctx);
+/* Since the group was joined: out = {all-gathers, max-reduces, grouped send-receives, payload bytes this rank sent to other ranks}. */
+int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]);
+/* Exercises the RCCL transport with a one-rank communicator on this context's GPU (library load, communicator, all-gather, max-reduce,
+ * grouped exchange): what a single-GPU box can check of the multi-process path. */
+int32_t bfhip_rccl_selftest(bfhip_ctx* ctx);
+/* rank / count (0 / 1 outside a group) and a static description of the transport. Any pointer may be NULL. */
+int32_t bfhip_ctx_group_info(bfhip_ctx* ctx, uint32_t* rank, uint32_t* count, const char** transport);
 
 /* Optional (off by default): keep the preprocessed tree (IsFirst(LOG_MAX_ROWS..=4): polynomials, LDE columns, Merkle layers, root) of
  * the first proof in the context and reuse it for later proofs with the same LOG_MAX_ROWS. The reference recommits it in every

@@ -41,6 +41,27 @@ def device_count():
     return lib().bfhip_device_count()
 
 
+def rccl_unique_id() -> bytes:
+    """bfhip_rccl_unique_id: the 128-byte id rank 0 creates for a multi-process shard group (loads librccl on first use)."""
+    buf = (ctypes.c_uint8 * 128)()
+    _check(lib().bfhip_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+class LocalGroup:
+    """Rendezvous object of an in-process shard group (bfhip_local_group_create): `count` contexts of this process, one thread each."""
+
+    def __init__(self, count):
+        self._h = ctypes.c_void_p()
+        _check(lib().bfhip_local_group_create(count, ctypes.byref(self._h)))
+        self.count = count
+
+    def close(self):
+        if self._h:
+            lib().bfhip_local_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+
 class Conventions(ctypes.Structure):
     """include/bfhip.h `bfhip_conventions`: the byte-level stwo conventions that cannot be confirmed offline, one switch each.
     All zero = the defaults (zero-state raw-compress Merkle nodes, raw-compress mix_u64, logUp mask order [0, -1])."""
@@ -104,40 +125,32 @@ class Context:
         """Where this context builds the 13 component tables: GPU kernels (default) or the host builders. Identical results."""
         _check(lib().bfhip_ctx_set_table_builder(self._h, int(on_gpu)))
 
-    # -- one proof over several GPUs (bfhip_ctx_set_shard) ---------------------------------------------------------------------------
-    _ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
-    _ALLREDUCE = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+    # -- one proof over several GPUs (shard group: bfhip_ctx_join_*_group) -----------------------------------------------------------------
+    def join_local_group(self, group, rank):
+        """Makes this context rank `rank` of a LocalGroup: N contexts of this process, one host thread each, prove ONE trace together."""
+        _check(lib().bfhip_ctx_join_local_group(self._h, group._h, rank))
+        self._group = group          # keep the rendezvous object alive as long as the context uses it
 
-    def set_shard(self, rank, count, allgather=None, allreduce_max=None):
-        """Makes this context rank `rank` of a group of `count` contexts (one per GPU) that prove ONE trace together.
-        allgather(send: bytes) -> bytes of all ranks in rank order; allreduce_max(values: np.ndarray[uint32]) -> element-wise maximum
-        over the ranks. count = 1 switches the mode off."""
-        if count == 1:
-            _check(lib().bfhip_ctx_set_shard(self._h, 0, 1, None, None, None))
-            self._shard_cbs = None
-            return
+    def join_rccl_group(self, unique_id: bytes, rank, count):
+        """One process per GPU: `unique_id` is rccl_unique_id() of rank 0, handed over by the host program (replicas.share_unique_id)."""
+        if len(unique_id) != 128:
+            raise BfhipError("an RCCL unique id has 128 bytes")
+        _check(lib().bfhip_ctx_join_rccl_group(self._h, unique_id, rank, count))
 
-        def _ag(_user, send_p, nbytes, recv_p):
-            try:
-                out = allgather(ctypes.string_at(send_p, nbytes))
-                if len(out) != nbytes * count:
-                    return -2
-                ctypes.memmove(recv_p, out, len(out))
-                return 0
-            except Exception:      # an exception must not unwind through the C frames
-                return -1
+    def leave_group(self):
+        _check(lib().bfhip_ctx_leave_group(self._h))
+        self._group = None
 
-        def _ar(_user, buf_p, n):
-            try:
-                arr = np.ctypeslib.as_array(ctypes.cast(buf_p, ctypes.POINTER(ctypes.c_uint32)), shape=(n,))
-                arr[:] = allreduce_max(arr.copy())
-                return 0
-            except Exception:
-                return -1
+    def group_stats(self):
+        """{all_gathers, max_reduces, exchanges, bytes_sent} of this rank since it joined its shard group."""
+        out = (ctypes.c_uint64 * 4)()
+        _check(lib().bfhip_ctx_group_stats(self._h, out))
+        return dict(zip(("all_gathers", "max_reduces", "exchanges", "bytes_sent"), [int(v) for v in out]))
 
-        cbs = (self._ALLGATHER(_ag), self._ALLREDUCE(_ar))
-        _check(lib().bfhip_ctx_set_shard(self._h, rank, count, cbs[0], cbs[1], None))
-        self._shard_cbs = cbs       # keep the thunks alive as long as the context uses them
+    def group_info(self):
+        r, n, t = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_char_p()
+        _check(lib().bfhip_ctx_group_info(self._h, ctypes.byref(r), ctypes.byref(n), ctypes.byref(t)))
+        return r.value, n.value, (t.value or b"").decode()
 
     # -- buffers ---------------------------------------------------------------------------------------------------
     def malloc(self, nbytes):

@@ -20,6 +20,22 @@ namespace bf {
 // ------------------------------------------------------------------------------------------------------------------------------
 typedef ConstraintLaunch ConstraintArgs;   // lives in HBM (staged by the host); read through scalar loads
 
+// LDE row (bit-reversed storage, blowup 2) of the point at trace-coset offset -1 from LDE row `row` of a component of 2^log_size rows
+__device__ __forceinline__ u32 prev_lde_row(u32 row, u32 log_size) {
+    u32 el = log_size + 1, half = 1u << log_size;
+    u32 d = bit_rev(row, el);
+    u32 pd = d < half ? ((d + half - 1) & (half - 1)) : (((d - half + 1) & (half - 1)) + half);
+    return bit_rev(pd, el);
+}
+__global__ void __launch_bounds__(256) k_prev_row_copy(u32* __restrict__ dst, const u32* __restrict__ src, u32 log_size) {
+    u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row < (2u << log_size)) dst[row] = src[prev_lde_row(row, log_size)];
+}
+void prev_row_copy(hipStream_t stream, u32* dst, const u32* src, u32 log_size) {
+    u32 n = 2u << log_size;
+    hipLaunchKernelGGL(k_prev_row_copy, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, log_size);
+}
+
 struct DomainEval : LogupState<DomainEval, Fm> {
     typedef Fm F;
     const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0;
@@ -45,11 +61,11 @@ struct DomainEval : LogupState<DomainEval, Fm> {
     __device__ __forceinline__ void inter_cur_prev(Fq& cur, Fq& prev) {
         // previous trace row = point - trace_step: on the 2x LDE domain (bit-reversed storage) this is d-1 cyclic in the first
         // half-coset and d+1 cyclic in the conjugate half (stwo offset_bit_reversed_circle_domain_index with offset -1).
-        u32 el = a.log_size + 1, half = 1u << a.log_size;
-        u32 d = bit_rev(row, el);
-        u32 pd = d < half ? ((d + half - 1) & (half - 1)) : (((d - half + 1) & (half - 1)) + half);
-        u32 pr = bit_rev(pd, el);
-        cur.v = rd(ii, row); prev.v = rd(ii, pr); ii += 4;
+        cur.v = rd(ii, row);
+        if (a.inter_prev[0]) {   // materialised previous-row copy (row-sharded columns)
+            prev.v = q_make(as_global(a.inter_prev[0])[row], as_global(a.inter_prev[1])[row], as_global(a.inter_prev[2])[row], as_global(a.inter_prev[3])[row]);
+        } else prev.v = rd(ii, prev_lde_row(row, a.log_size));
+        ii += 4;
     }
     __device__ __forceinline__ void constraint(Fm c) {
         const Q31 k = a.coeff[ci++];
@@ -64,7 +80,8 @@ template <int COMP>
 __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __restrict__ ap) {
     const ConstraintArgs& a = *ap;
     u32 row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= (2u << a.log_size)) return;
+    if (a.n_rows) { if (row >= a.n_rows) return; row += a.row0; }
+    else if (row >= (2u << a.log_size)) return;
     DomainEval e(a, row);
     air_eval<COMP>(e, a.el);
     Q31 r = q_mulm(e.result(), a.denom_inv[row >> a.log_size]);
@@ -77,27 +94,27 @@ __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __res
 }
 
 template <int COMP>
-static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size) {
-    u32 n = 2u << log_size;
+static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size, u32 n_rows) {
+    u32 n = n_rows ? n_rows : 2u << log_size;
     ProfScope ps(s, "k_constraints", 0);
     hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
-void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size) {
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size, u32 n_rows) {
     switch (comp) {
-        case C_MEMORY: launch_c<C_MEMORY>(stream, a, log_size); break;
-        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a, log_size); break;
-        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a, log_size); break;
-        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a, log_size); break;
-        case C_JNZ: launch_c<C_JNZ>(stream, a, log_size); break;
-        case C_JZ: launch_c<C_JZ>(stream, a, log_size); break;
-        case C_INPUT: launch_c<C_INPUT>(stream, a, log_size); break;
-        case C_LEFT: launch_c<C_LEFT>(stream, a, log_size); break;
-        case C_MINUS: launch_c<C_MINUS>(stream, a, log_size); break;
-        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a, log_size); break;
-        case C_PLUS: launch_c<C_PLUS>(stream, a, log_size); break;
-        case C_RIGHT: launch_c<C_RIGHT>(stream, a, log_size); break;
-        default: launch_c<C_EOE>(stream, a, log_size); break;
+        case C_MEMORY: launch_c<C_MEMORY>(stream, a, log_size, n_rows); break;
+        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a, log_size, n_rows); break;
+        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a, log_size, n_rows); break;
+        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a, log_size, n_rows); break;
+        case C_JNZ: launch_c<C_JNZ>(stream, a, log_size, n_rows); break;
+        case C_JZ: launch_c<C_JZ>(stream, a, log_size, n_rows); break;
+        case C_INPUT: launch_c<C_INPUT>(stream, a, log_size, n_rows); break;
+        case C_LEFT: launch_c<C_LEFT>(stream, a, log_size, n_rows); break;
+        case C_MINUS: launch_c<C_MINUS>(stream, a, log_size, n_rows); break;
+        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a, log_size, n_rows); break;
+        case C_PLUS: launch_c<C_PLUS>(stream, a, log_size, n_rows); break;
+        case C_RIGHT: launch_c<C_RIGHT>(stream, a, log_size, n_rows); break;
+        default: launch_c<C_EOE>(stream, a, log_size, n_rows); break;
     }
 }
 

@@ -54,6 +54,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
 void Ctx::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (stream2) (void)hipStreamSynchronize(stream2);
+    shard = ShardGroup();
     if (stream) prof_forget(stream);
     if (stream2) prof_forget(stream2);
     arena.release();
@@ -82,17 +83,90 @@ int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx**
     API_CATCH
 }
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
-int32_t bfhip_ctx_set_shard(bfhip_ctx* ctx, uint32_t rank, uint32_t count, bfhip_allgather_fn allgather, bfhip_allreduce_max_u32_fn allreduce_max, void* user) {
-    API_CTX(ctx)
-    if (count == 0 || (count & (count - 1)) != 0 || count > 256) throw HipError("shard count must be a power of two <= 256");
-    if (rank >= count) throw HipError("shard rank out of range");
-    if (count > 1 && (!allgather || !allreduce_max)) throw HipError("a shard group needs both exchange callbacks");
-    ShardGroup g;
-    g.rank = rank; g.count = count; g.log_count = 0;
-    while ((1u << g.log_count) < count) g.log_count++;
-    g.allgather = allgather; g.allreduce_max = allreduce_max; g.user = user;
+// ---- shard groups: one proof over several GPUs (comm.h) ------------------------------------------------------------------------------
+struct bfhip_local_group { LocalGroup* g; uint32_t count; };
+static void join_group(bfhip_ctx* ctx, std::unique_ptr<Comm> comm) {
+    u32 count = comm->count, lc = 0;
+    while ((1u << lc) < count) lc++;
     ctx->c.sync();
+    ShardGroup g; g.rank = comm->rank; g.count = count; g.log_count = lc; g.comm = std::shared_ptr<Comm>(std::move(comm));
     ctx->c.shard = g;
+}
+static void check_group_size(uint32_t rank, uint32_t count) {
+    if (count < 2 || (count & (count - 1)) != 0 || count > 64) throw HipError("shard count must be a power of two in [2, 64]");
+    if (rank >= count) throw HipError("shard rank out of range");
+}
+int32_t bfhip_local_group_create(uint32_t count, bfhip_local_group** out) {
+    API_TRY
+    check_group_size(0, count);
+    *out = new bfhip_local_group{local_group_create(count), count};
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_local_group_destroy(bfhip_local_group* g) { if (g) { local_group_destroy(g->g); delete g; } return 0; }
+int32_t bfhip_ctx_join_local_group(bfhip_ctx* ctx, bfhip_local_group* group, uint32_t rank) {
+    API_CTX(ctx)
+    if (!group) throw HipError("null group");
+    check_group_size(rank, group->count);
+    join_group(ctx, local_comm_join(group->g, rank));
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_rccl_unique_id(uint8_t id[128]) { API_TRY rccl_unique_id(id); return 0; API_CATCH }
+int32_t bfhip_ctx_join_rccl_group(bfhip_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t count) {
+    API_CTX(ctx)
+    check_group_size(rank, count);
+    join_group(ctx, rccl_comm_join(id, rank, count));
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]) {
+    API_CTX(ctx)
+    const Comm* m = ctx->c.shard.comm.get();
+    out[0] = m ? m->n_all_gather : 0; out[1] = m ? m->n_all_reduce : 0; out[2] = m ? m->n_exchange : 0; out[3] = m ? m->bytes_sent : 0;
+    return 0;
+    API_CATCH
+}
+// Exercises the RCCL transport with a communicator of ONE rank on this context's GPU: library load, communicator creation, an in-place
+// all-gather, a max-reduce and a grouped exchange (a block to oneself). What a single-GPU box can check of the multi-process path.
+int32_t bfhip_rccl_selftest(bfhip_ctx* ctx) {
+    API_CTX(ctx)
+    Ctx& c = ctx->c;
+    unsigned char id[128];
+    rccl_unique_id(id);
+    std::unique_ptr<Comm> comm = rccl_comm_join(id, 0, 1);
+    const u32 n = 1024;
+    u32 *a = nullptr, *b = nullptr;
+    BF_HIP(hipMalloc((void**)&a, n * sizeof(u32)));
+    hipError_t e = hipMalloc((void**)&b, n * sizeof(u32));
+    if (e != hipSuccess) { (void)hipFree(a); BF_HIP(e); }
+    std::vector<u32> h(n), out(n);
+    for (u32 i = 0; i < n; i++) h[i] = i * 2654435761u;
+    try {
+        BF_HIP(hipMemcpyAsync(a, h.data(), n * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+        comm->all_gather(c.stream, a, n * sizeof(u32));
+        comm->all_reduce_max_u32(c.stream, a, n);
+        comm->exchange(c.stream, {Xfer{0, a, n * sizeof(u32)}}, {Xfer{0, b, n * sizeof(u32)}});
+        BF_HIP(hipMemcpyAsync(out.data(), b, n * sizeof(u32), hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+    } catch (...) { (void)hipFree(a); (void)hipFree(b); throw; }
+    (void)hipFree(a); (void)hipFree(b);
+    if (out != h) throw HipError("RCCL self-test: data mismatch");
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_leave_group(bfhip_ctx* ctx) {
+    API_CTX(ctx)
+    ctx->c.sync();
+    ctx->c.shard = ShardGroup();
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_group_info(bfhip_ctx* ctx, uint32_t* rank, uint32_t* count, const char** transport) {
+    API_CTX(ctx)
+    if (rank) *rank = ctx->c.shard.rank;
+    if (count) *count = ctx->c.shard.count;
+    if (transport) *transport = ctx->c.shard.comm ? ctx->c.shard.comm->transport() : "none";
     return 0;
     API_CATCH
 }

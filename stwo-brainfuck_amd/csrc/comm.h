@@ -1,0 +1,44 @@
+// Shard-group communication: the exchanges of ONE proof over several GPUs, issued by the C++ prover on the
+// context's own HIP stream with device buffers on both ends — no host callbacks and no host bounce in the data path.
+//
+// Two transports behind one interface:
+//   RcclComm   one process per GPU (bench.py --gpus N --shard): RCCL collectives / grouped send-recv over xGMI. librccl is loaded with
+//              dlopen at group-join time, so the library itself has no link-time dependency on it.
+//   LocalComm  N contexts of ONE process driven by N host threads (tests: N ranks on one GPU): device-to-device copies ordered by HIP
+//              events between the ranks' streams plus a host rendezvous. Same call sequence, same bytes.
+// Every rank of a group calls the same sequence of operations with matching sizes (SPMD), like any collective library expects.
+#pragma once
+#include "kernels.h"
+#include <vector>
+#include <memory>
+#include <cstring>
+
+namespace bf {
+
+struct Xfer { u32 peer; void* ptr; size_t bytes; };   // one point-to-point block: send (ptr is the source) or receive (ptr is the destination)
+
+struct Comm {
+    u32 rank = 0, count = 1;
+    // operation counts and payload bytes this rank sent to OTHER ranks since the group was joined (tests, DESIGN.md numbers)
+    u64 n_all_gather = 0, n_all_reduce = 0, n_exchange = 0, bytes_sent = 0;
+    virtual ~Comm() {}
+    // In place: rank r's block is buf + r * bytes_per_rank; afterwards every block is filled on every rank.
+    virtual void all_gather(hipStream_t s, void* buf, size_t bytes_per_rank) = 0;
+    // Element-wise maximum over the ranks (decommitment words / sampled values: each is held by one rank, zero elsewhere).
+    virtual void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) = 0;
+    // Point-to-point blocks. Sends to / receives from one peer are matched in list order. A block to oneself is a plain copy.
+    virtual void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) = 0;
+    virtual const char* transport() const = 0;
+};
+
+// LocalComm rendezvous object shared by the N contexts of one process.
+struct LocalGroup;
+LocalGroup* local_group_create(u32 count);
+void local_group_destroy(LocalGroup* g);
+std::unique_ptr<Comm> local_comm_join(LocalGroup* g, u32 rank);
+
+// RCCL: rank 0 creates the 128-byte unique id, the host program distributes it (control plane), every rank joins.
+void rccl_unique_id(unsigned char id[128]);
+std::unique_ptr<Comm> rccl_comm_join(const unsigned char id[128], u32 rank, u32 count);
+
+}  // namespace bf

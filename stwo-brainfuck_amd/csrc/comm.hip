@@ -1,0 +1,192 @@
+// Shard-group transports (comm.h): RCCL over xGMI for one process per GPU, and an in-process transport for N contexts on one GPU.
+#include "ctx.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
+namespace bf {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// LocalComm: the ranks are host threads of one process, their buffers live on one device. A transfer is a device-to-device copy
+// enqueued on the RECEIVER's stream after the sender's "ready" event; the sender's stream then waits for the receivers' "done" events
+// before it may touch the source again. A host rendezvous (barrier) separates publishing the pointers from reading them.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct LocalGroup {
+    u32 count;
+    std::mutex mu; std::condition_variable cv; u32 arrived = 0; u64 generation = 0; u32 joined = 0;
+    struct Slot { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; std::vector<Xfer> sends; };
+    std::vector<Slot> slots;
+    explicit LocalGroup(u32 n) : count(n), slots(n) {}
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const u64 gen = generation;
+        if (++arrived == count) { arrived = 0; generation++; cv.notify_all(); return; }
+        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen; }))
+            throw HipError("shard group: a rank did not reach the rendezvous (another rank failed or diverged)");
+    }
+};
+LocalGroup* local_group_create(u32 count) { return new LocalGroup(count); }
+void local_group_destroy(LocalGroup* g) { delete g; }
+
+__global__ void k_max_u32_n(u32* __restrict__ out, const u32* const* __restrict__ bufs, u32 nbufs, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 m = 0;
+    for (u32 b = 0; b < nbufs; b++) { u32 v = bufs[b][i]; m = v > m ? v : m; }
+    out[i] = m;
+}
+
+struct LocalComm : Comm {
+    LocalGroup* g;
+    u32* scratch = nullptr; size_t scratch_words = 0;
+    const u32** d_ptrs = nullptr;
+    LocalComm(LocalGroup* g_, u32 r) : g(g_) {
+        rank = r; count = g_->count;
+        BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
+        BF_HIP(hipEventCreateWithFlags(&g->slots[r].done, hipEventDisableTiming));
+        BF_HIP(hipMalloc((void**)&d_ptrs, sizeof(u32*) * count));
+    }
+    ~LocalComm() override {
+        (void)hipEventDestroy(g->slots[rank].ready); (void)hipEventDestroy(g->slots[rank].done);
+        g->slots[rank].ready = g->slots[rank].done = nullptr;
+        (void)hipFree(scratch); (void)hipFree((void*)d_ptrs);
+    }
+    const char* transport() const override { return "local (N contexts of one process, device-to-device copies ordered by HIP events)"; }
+    void publish(hipStream_t s, void* buf) { g->slots[rank].buf = buf; BF_HIP(hipEventRecord(g->slots[rank].ready, s)); g->barrier(); }
+    void finish(hipStream_t s) {
+        BF_HIP(hipEventRecord(g->slots[rank].done, s));
+        g->barrier();
+        for (u32 p = 0; p < count; p++) if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].done, 0));   // peers have read my buffer
+    }
+    void all_gather(hipStream_t s, void* buf, size_t bpr) override {
+        n_all_gather++; bytes_sent += bpr * (count - 1);
+        publish(s, buf);
+        for (u32 p = 0; p < count; p++) {
+            if (p == rank) continue;
+            BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0));
+            BF_HIP(hipMemcpyAsync((char*)buf + p * bpr, (const char*)g->slots[p].buf + p * bpr, bpr, hipMemcpyDeviceToDevice, s));
+        }
+        finish(s);
+    }
+    void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
+        n_all_reduce++; bytes_sent += n * sizeof(u32);
+        if (n == 0) { g->barrier(); g->barrier(); return; }
+        if (scratch_words < n) { (void)hipFree(scratch); scratch = nullptr; BF_HIP(hipMalloc((void**)&scratch, n * sizeof(u32))); scratch_words = n; }
+        publish(s, buf);
+        std::vector<const u32*> ptrs(count);
+        for (u32 p = 0; p < count; p++) { ptrs[p] = (const u32*)g->slots[p].buf; if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0)); }
+        BF_HIP(hipMemcpyAsync((void*)d_ptrs, ptrs.data(), sizeof(u32*) * count, hipMemcpyHostToDevice, s));
+        BF_HIP(hipStreamSynchronize(s));   // `ptrs` is a stack object; tiny operation on a latency-insensitive path (tests)
+        hipLaunchKernelGGL(k_max_u32_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, d_ptrs, count, n);
+        finish(s);                         // every rank has computed its result from the unmodified inputs
+        BF_HIP(hipMemcpyAsync(buf, scratch, n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    }
+    void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
+        n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
+        g->slots[rank].sends = sends;
+        publish(s, nullptr);
+        std::vector<size_t> next(count, 0);   // per peer: position in that peer's send list of the next block addressed to me
+        for (const Xfer& r : recvs) {
+            const std::vector<Xfer>& ps = g->slots[r.peer].sends;
+            size_t& k = next[r.peer];
+            while (k < ps.size() && ps[k].peer != rank) k++;
+            if (k >= ps.size() || ps[k].bytes != r.bytes) throw HipError("shard group: unmatched send/receive");
+            if (r.peer != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[r.peer].ready, 0));
+            if (r.bytes) BF_HIP(hipMemcpyAsync(r.ptr, ps[k].ptr, r.bytes, hipMemcpyDeviceToDevice, s));
+            k++;
+        }
+        finish(s);
+    }
+};
+std::unique_ptr<Comm> local_comm_join(LocalGroup* g, u32 rank) {
+    if (!g || rank >= g->count) throw HipError("shard group: bad rank");
+    return std::unique_ptr<Comm>(new LocalComm(g, rank));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// RcclComm: RCCL (backend "nccl" of torch.distributed is the same library) on the context's stream. Loaded lazily.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi& rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+        if (!api.lib) return;
+        auto sym = [&](const char* n) { return dlsym(api.lib, n); };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.AllReduce = (decltype(api.AllReduce))sym("ncclAllReduce");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
+    if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
+        throw HipError("RCCL is not available (librccl.so.1 could not be loaded): a multi-process shard group needs it");
+    return api;
+}
+#define BF_NCCL(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) throw HipError(std::string(#expr) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r__) : "RCCL error")); } while (0)
+
+void rccl_unique_id(unsigned char id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    BF_NCCL(rccl().GetUniqueId(&u));
+    memcpy(id, &u, 128);
+}
+
+struct RcclComm : Comm {
+    ncclComm_t comm = nullptr;
+    RcclComm(const unsigned char id[128], u32 r, u32 n) {
+        rank = r; count = n;
+        ncclUniqueId u; memcpy(&u, id, 128);
+        BF_NCCL(rccl().CommInitRank(&comm, (int)n, u, (int)r));
+    }
+    ~RcclComm() override { if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm); }
+    const char* transport() const override { return "RCCL (one process per GPU, collectives on the context's stream over xGMI)"; }
+    void all_gather(hipStream_t s, void* buf, size_t bpr) override {
+        n_all_gather++; bytes_sent += bpr * (count - 1);
+        BF_NCCL(rccl().AllGather((const char*)buf + rank * bpr, buf, bpr, ncclUint8, comm, s));   // in place: send block = my block of the receive buffer
+    }
+    void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
+        n_all_reduce++; bytes_sent += n * sizeof(u32);
+        if (n) BF_NCCL(rccl().AllReduce(buf, buf, n, ncclUint32, ncclMax, comm, s));
+    }
+    void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
+        n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
+        // blocks to oneself are plain copies, matched in order
+        std::vector<const Xfer*> self_s, self_r;
+        for (auto& x : sends) if (x.peer == rank) self_s.push_back(&x);
+        for (auto& x : recvs) if (x.peer == rank) self_r.push_back(&x);
+        if (self_s.size() != self_r.size()) throw HipError("shard group: unmatched self transfer");
+        for (size_t i = 0; i < self_s.size(); i++) {
+            if (self_s[i]->bytes != self_r[i]->bytes) throw HipError("shard group: unmatched self transfer");
+            if (self_s[i]->bytes) BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
+        }
+        BF_NCCL(rccl().GroupStart());
+        for (auto& x : sends) if (x.peer != rank && x.bytes) BF_NCCL(rccl().Send(x.ptr, x.bytes, ncclUint8, (int)x.peer, comm, s));
+        for (auto& x : recvs) if (x.peer != rank && x.bytes) BF_NCCL(rccl().Recv(x.ptr, x.bytes, ncclUint8, (int)x.peer, comm, s));
+        BF_NCCL(rccl().GroupEnd());
+    }
+};
+std::unique_ptr<Comm> rccl_comm_join(const unsigned char id[128], u32 rank, u32 count) { return std::unique_ptr<Comm>(new RcclComm(id, rank, count)); }
+
+}  // namespace bf

@@ -1,6 +1,8 @@
 // Device context: stream, twiddle tree, arena allocator, small staging helpers. Internal to the library.
 #pragma once
 #include "kernels.h"
+#include "comm.h"
+#include <memory>
 #include <vector>
 #include <string>
 #include <stdexcept>
@@ -31,12 +33,10 @@ struct Arena {
     void release() { for (auto& c : chunks) (void)hipFree(c.base); chunks.clear(); total_used = 0; }
 };
 
-// One proof over several GPUs (include/bfhip.h: bfhip_ctx_set_shard): this rank's place in the group and the two host-side exchanges.
+// One proof over several GPUs (include/bfhip.h: bfhip_ctx_join_*_group): this rank's place in the group and its transport (comm.h).
 struct ShardGroup {
     u32 rank = 0, count = 1, log_count = 0;
-    int (*allgather)(void* user, const void* send_h, size_t bytes_per_rank, void* recv_h) = nullptr;
-    int (*allreduce_max)(void* user, u32* buf_h, size_t n) = nullptr;
-    void* user = nullptr;
+    std::shared_ptr<Comm> comm;
 };
 
 struct Ctx {

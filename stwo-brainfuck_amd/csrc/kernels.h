@@ -84,9 +84,16 @@ void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24);
 struct ConstraintLaunch {
     const u32* is_first; ColDesc trace[13]; ColDesc inter[12]; u32* acc[4]; Q31 coeff[12]; Lookups el; Q31 total_sum; u32 denom_inv[2]; u32 log_size;
     u32 overwrite;   // 1: acc = value (first component of an accumulator: no zero fill, no read); 0: acc += value
+    // Row range of the 2^(log_size+1)-row evaluation domain this launch covers (n_rows == 0: all rows) — a rank of a shard group evaluates
+    // its contiguous share only. Column / accumulator pointers are then "virtual bases": valid for the rows of the range.
+    u32 row0, n_rows;
+    // Previous-row copy of the component's LAST logUp column (4 coordinates): prev[k][row] = inter[last + k][row at offset -1]. nullptr:
+    // the kernel reads the neighbour itself (it generally lives in another rank's row range — SURVEY.md section 7 vii).
+    const u32* inter_prev[4];
 };
 // `d_args` points to a ConstraintLaunch staged in device memory.
-void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size);
+// n_rows: the launch's row count when d_args->n_rows != 0 (host copy of the same value), else 0
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size, u32 n_rows = 0);
 struct LogupLaunch {
     const u32* cols[13];   // row-granular main columns
     u32* out_rep[8];       // row-granular coordinate columns of the non-last logUp columns
@@ -98,16 +105,22 @@ void logup_generate(hipStream_t stream, const LogupLaunch& L);
 void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells);
 
 // quotient.hip
-struct EvalJob { const u32* coeffs; u32 log_n; u32 point; u32 factor_shift; u32 partial_off; };
+struct EvalJob { const u32* coeffs; u32 log_n; u32 point; u32 factor_shift; u32 partial_off; u32 out_idx; u32 pad_; };   // result -> out[out_idx]
 void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 total_partials, const void* d_factors, void* d_partials, void* d_out);
 struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; C31 kden; u32 pad_; };   // kden = prx * piy - pry * pix
 struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
-struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; };
+// row0 / n_rows: range of rows to compute (n_rows == 0: all 2^log rows; both multiples of 4); out pointers may be virtual bases
+struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; u32 row0, n_rows; };
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
 // d_alpha8: device pointer to alpha[4] || alpha^2[4]
 // fresh: dst holds nothing yet (treated as zero, not read)
-void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh = false);
-void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log);
+// first / count: range of DESTINATION cells to compute (count == 0: all 2^(log-1)); pointers may be virtual bases
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh = false,
+                           u32 first = 0, u32 count = 0);
+void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, u32 first = 0, u32 count = 0);
+// dst[i] = src[index of the row at trace-coset offset -1 of LDE row i] over a whole column of 2^(log_size+1) cells (blowup 2) — the
+// "previous-row copy" a column owner materialises before the column is cut into row ranges
+void prev_row_copy(hipStream_t stream, u32* dst, const u32* src, u32 log_size);
 // out[out_off + w] = base[index + w] for w < n_words (n_words = 1: a column cell, 8: a hash); base == nullptr reads as zeros
 struct GatherReq { const u32* base; u64 index; u32 out_off; u32 n_words; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);

@@ -24,24 +24,38 @@ void build_tables_device(Ctx& c, const std::vector<u32> trace7_soa[7], u32 n, co
 
 struct PcsConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_bound = 0, n_queries = 3; };  // PcsConfig::default() (mod.rs:479)
 
+static constexpr u32 OWNER_ALL = 0xFFFFFFFFu;   // a polynomial every rank of a shard group holds and transforms itself
+
 struct DCol {
     u32* ptr = nullptr; u32 log_size = 0; u32 shift = 0;   // 2^log_size domain cells, stored as 2^(log_size - shift) u32
-    size_t stored() const { return size_t(1) << (log_size - shift); }
+    // Row-sharded column of a shard group (lc = log2(ranks) > 0): this rank stores only its contiguous range of 2^(log_size - lc) rows and
+    // `ptr` is a VIRTUAL BASE — the slice's address minus the range's first row — so that kernels keep addressing rows by their global
+    // index; only rows of the rank's own range may be dereferenced.
+    u32 lc = 0;
+    bool sliced() const { return lc != 0; }
+    size_t stored() const { return size_t(1) << (log_size - shift - lc); }
     ColDesc desc() const { return ColDesc{ptr, shift, 0}; }
+    bool mine(u64 cell, u32 rank) const { return lc == 0 || (cell >> (log_size - lc)) == rank; }
 };
 // layer k: node i stored at i >> shifts[k]. In a shard group (Ctx::shard.count > 1) the layers k with band_lo < k <= band_hi hold only this
 // rank's contiguous share of the nodes (node i belongs to rank i >> (k - log2 count)); layer band_lo and everything below is complete.
 struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; int band_lo = 0, band_hi = -1; };
-struct DTree { std::vector<DCol> polys, evals; DevMerkle mk; };
-struct DSecure { u32* c[4]; u32 log_size; };
+// owner[i]: the rank that holds polynomial i (coefficients) and computes its LDE, or OWNER_ALL. prev[i]: previous-row copy of evals[i]
+// (row-sharded last logUp columns only; ptr == nullptr otherwise).
+struct DTree { std::vector<DCol> polys, evals, prev; std::vector<u32> owner; DevMerkle mk; };
+struct DSecure {
+    u32* c[4]; u32 log_size; u32 lc = 0;     // lc > 0: row-sharded, c[] are virtual bases (see DCol)
+    bool mine(u64 cell, u32 rank) const { return lc == 0 || (cell >> (log_size - lc)) == rank; }
+};
 
 struct Gather {
     std::vector<GatherReq> reqs;
     u32 n_words = 0;
-    // each returns the position of the first gathered word in the output of run()
-    size_t add(const u32* base, u64 idx) { reqs.push_back({base, idx, n_words, 1u}); n_words += 1; return n_words - 1; }
+    // each returns the position of the first gathered word in the output of run(); mine == false: another rank of the shard group holds
+    // the word (this rank contributes a zero, the max-reduce completes it)
+    size_t add(const u32* base, u64 idx, bool mine = true) { reqs.push_back({mine ? base : nullptr, idx, n_words, 1u}); n_words += 1; return n_words - 1; }
     size_t add_hash(const u32* layer, u64 node_slot, bool mine) { reqs.push_back({mine ? layer : nullptr, node_slot * 8, n_words, 8u}); n_words += 8; return n_words - 8; }
-    size_t add_col(const DCol& col, u64 cell) { return add(col.ptr, cell >> col.shift); }
+    size_t add_col(const DCol& col, u64 cell, u32 rank) { return add(col.ptr, cell >> col.shift, col.mine(cell, rank)); }
     std::vector<u32> run(Ctx& c) {
         std::vector<u32> out(n_words);
         if (reqs.empty()) return out;
@@ -50,10 +64,10 @@ struct Gather {
         GatherReq* d = c.stage(reqs.data(), reqs.size());
         u32* dout = c.alloc_u32(n_words);
         gather_u32(c.stream, d, (u32)reqs.size(), dout);
+        // shard group: every word is either identical on all ranks (replicated columns, complete layers) or held by one rank and zero
+        // elsewhere (rows of sharded columns, hashes of share-wise layers) — an element-wise maximum completes it everywhere
+        if (c.shard.count > 1) c.shard.comm->all_reduce_max_u32(c.stream, dout, n_words);
         c.read_back(out.data(), dout, n_words * sizeof(u32));
-        // shard group: every word is either identical on all ranks (column values, complete layers) or held by one rank and zero
-        // elsewhere (hashes of share-wise layers) — an element-wise maximum completes it everywhere
-        if (c.shard.count > 1 && c.shard.allreduce_max(c.shard.user, out.data(), out.size()) != 0) throw HipError("shard group: all-reduce failed");
         return out;
     }
 };
@@ -171,6 +185,8 @@ struct HipProver {
             for (int log = (int)mk.max_log; log >= 0; log--) if (mk.shifts[log] == 0) { hi = log; break; }
             int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
             if (hi >= lo) { mk.band_hi = hi; mk.band_lo = lo; }
+            // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
+            for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
         prof_run_begin(c.stream, "k_merkle_layer");
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
@@ -180,14 +196,11 @@ struct HipProver {
             merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
                          mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, c.conv.merkle_node_hash, sg.rank * per_rank, per_rank);
             if (share && log == mk.band_lo) {
+                // the smallest share-wise layer is completed on every rank by one all-gather on the device buffer (rank r's block = its
+                // contiguous node range); the levels below are hashed redundantly, so every rank obtains the same root
                 prof_run_end(c.stream);
-                const size_t slice = (size_t(32) << log) >> sg.log_count;
-                std::vector<u8> mine(slice), everyone(slice * sg.count);
-                c.read_back(mine.data(), reinterpret_cast<const u8*>(mk.layers[log]) + sg.rank * slice, slice);
-                if (sg.allgather(sg.user, mine.data(), slice, everyone.data()) != 0) throw HipError("shard group: all-gather failed");
-                c.stage_checkpoint();
-                const u8* staged = c.stage(everyone.data(), everyone.size());
-                BF_HIP(hipMemcpyAsync(mk.layers[log], staged, everyone.size(), hipMemcpyDeviceToDevice, c.stream));
+                sg.comm->all_gather(c.stream, mk.layers[log], (size_t(32) << log) >> sg.log_count);
+                prof_run_begin(c.stream, "k_merkle_layer");
             }
         }
         prof_run_end(c.stream);
@@ -245,7 +258,7 @@ struct HipProver {
                 }
                 bool queried = qi < colq.size() && colq[qi] == node;
                 if (queried) qi++;
-                for (auto& col : lc) { size_t f = g.add_col(col, node); slots.push_back({queried ? 2 : 1, f}); }
+                for (auto& col : lc) { size_t f = g.add_col(col, node, c.shard.rank); slots.push_back({queried ? 2 : 1, f}); }
                 total.push_back(node);
             }
             std::swap(last, total);
@@ -259,15 +272,77 @@ struct HipProver {
         };
     }
 
+    // ---- shard group (one proof over several GPUs): which columns are cut into row ranges ---------------------------------------------
+    // A full-size column of the interaction / composition trees, a quotient column or an FRI layer with at least 2^12 rows per rank is
+    // ROW-sharded: rank r holds rows [r * 2^(log - lc), (r + 1) * 2^(log - lc)) — a contiguous range of a bit-reversed circle domain, i.e.
+    // a sub-coset, so Merkle subtrees, offset-0 masks, quotient rows and FRI sibling pairs are all local. Smaller columns, the 16x-replicated
+    // (row-granular) columns and the preprocessed / main trees stay complete on every rank.
+    static constexpr u32 SLICE_MIN_LOG_PER_RANK = 12;
+    bool sharded() const { return c.shard.count > 1; }
+    u32 lc() const { return c.shard.log_count; }
+    bool slice_log(u32 log) const { return sharded() && log >= lc() + SLICE_MIN_LOG_PER_RANK; }
+    size_t slice_cells(u32 log) const { return size_t(1) << (log - lc()); }
+    size_t slice_first(u32 log) const { return (size_t)c.shard.rank << (log - lc()); }
+    // storage for this rank's row range of a 2^log column, returned as a virtual base (see DCol)
+    u32* alloc_slice(u32 log) { return reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(c.alloc_u32(slice_cells(log))) - sizeof(u32) * slice_first(log)); }
+    // Column-sharding of the transforms: the biggest column goes to the least loaded rank (greedy by 2^log, deterministic on every rank).
+    std::vector<u32> assign_owners(const std::vector<DCol>& polys, u32 log_blowup) const {
+        std::vector<u32> owner(polys.size(), OWNER_ALL);
+        if (!sharded()) return owner;
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < polys.size(); i++) if (polys[i].shift == 0 && slice_log(polys[i].log_size + log_blowup)) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return polys[a].log_size > polys[b].log_size; });
+        std::vector<u64> load(c.shard.count, 0);
+        for (size_t i : idx) {
+            u32 best = 0;
+            for (u32 r = 1; r < c.shard.count; r++) if (load[r] < load[best]) best = r;
+            owner[i] = best; load[best] += u64(1) << polys[i].log_size;
+        }
+        return owner;
+    }
+
     // CommitmentTreeProver::new: LDE by the blowup factor, Merkle, mix_root.
-    void commit_tree(DTree& t, Hash32* pinned_root = nullptr) {
-        t.evals.resize(t.polys.size());
-        for (size_t i = 0; i < t.polys.size(); i++) {
+    // Shard group: a polynomial with t.owner[i] != OWNER_ALL is extended by its owner only; one grouped send-receive then hands every rank
+    // its row range of the LDE column (with_prev: and of the column's previous-row copy, which the constraint kernel needs for the mask
+    // offset -1 of the last logUp column — that neighbour is a reflection in bit-reversed storage, not a halo).
+    void commit_tree(DTree& t, Hash32* pinned_root = nullptr, bool with_prev = false) {
+        const size_t n = t.polys.size();
+        if (t.owner.size() != n) t.owner.assign(n, OWNER_ALL);
+        t.evals.resize(n); t.prev.assign(n, DCol());
+        std::vector<DCol> fsrc, fdst, full(n), fullprev(n);
+        for (size_t i = 0; i < n; i++) {
             DCol e; e.log_size = t.polys[i].log_size + cfg.log_blowup; e.shift = t.polys[i].shift;
-            e.ptr = c.alloc_u32(e.stored());
+            if (t.owner[i] == OWNER_ALL) { e.ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(e); }
+            else {
+                if (t.owner[i] == c.shard.rank) {
+                    full[i] = e; full[i].ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(full[i]);
+                    if (with_prev) { fullprev[i] = e; fullprev[i].ptr = c.alloc_u32(e.stored()); }
+                }
+                e.lc = lc(); e.ptr = alloc_slice(e.log_size);
+                if (with_prev) { t.prev[i] = e; t.prev[i].ptr = alloc_slice(e.log_size); }
+            }
             t.evals[i] = e;
         }
-        fft_cols(false, t.polys, t.evals);
+        fft_cols(false, fsrc, fdst);
+        if (sharded()) {
+            std::vector<Xfer> sends, recvs;
+            for (size_t i = 0; i < n; i++) {
+                if (t.owner[i] == OWNER_ALL) continue;
+                const u32 el = t.evals[i].log_size;
+                const size_t cells = slice_cells(el), bytes = cells * sizeof(u32), first = slice_first(el);
+                if (t.owner[i] == c.shard.rank) {
+                    if (with_prev) prev_row_copy(c.stream, fullprev[i].ptr, full[i].ptr, t.polys[i].log_size);
+                    for (u32 r = 0; r < c.shard.count; r++) {
+                        sends.push_back({r, full[i].ptr + r * cells, bytes});
+                        if (with_prev) sends.push_back({r, fullprev[i].ptr + r * cells, bytes});
+                    }
+                }
+                recvs.push_back({t.owner[i], t.evals[i].ptr + first, bytes});
+                if (with_prev) recvs.push_back({t.owner[i], t.prev[i].ptr + first, bytes});
+            }
+            if (!recvs.empty()) c.shard.comm->exchange(c.stream, sends, recvs);
+        }
+        BF_HIP(hipGetLastError());
         t.mk = merkle_commit(t.evals, pinned_root);
         if (!pinned_root) ch.mix_root(t.mk.root);
     }
@@ -337,10 +412,14 @@ struct HipProver {
         Hash32* pinned_root1 = pinned_root0 + 1;
         const bool reuse = cache.matches(c, log_max_rows);
         BF_HIP(hipEventRecord(c.ev[0], c.stream));
+        // In a shard group everything stays on the main stream: the group's exchanges are issued in one order on one stream per rank.
+        const bool use_side = !sharded();
         if (reuse) trees[0] = cache.tree;
         else {
-            BF_HIP(hipStreamWaitEvent(c.stream2, c.ev[0], 0));       // stream2 starts after whatever preceded this proof on the main stream
-            std::swap(c.stream, c.stream2); c.side_busy = true;
+            if (use_side) {
+                BF_HIP(hipStreamWaitEvent(c.stream2, c.ev[0], 0));   // stream2 starts after whatever preceded this proof on the main stream
+                std::swap(c.stream, c.stream2); c.side_busy = true;
+            }
             try {
                 if (cache.enabled) { cache.keep.reset(); std::swap(c.arena, cache.keep); }   // build the tree in memory that survives arena.reset()
                 for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
@@ -352,8 +431,8 @@ struct HipProver {
                 commit_tree(trees[0], pinned_root0);
                 if (cache.enabled) std::swap(c.arena, cache.keep);
                 BF_HIP(hipEventRecord(c.ev[1], c.stream));
-            } catch (...) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; throw; }
-            std::swap(c.stream, c.stream2);
+            } catch (...) { if (use_side) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } throw; }
+            if (use_side) std::swap(c.stream, c.stream2);
         }
         auto join_side = [&]() { if (c.side_busy) { (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } };
         const TraceInput* in_p = nullptr;
@@ -445,9 +524,16 @@ struct HipProver {
             for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
         }
         trees[2].polys = inter_vals;          // interpolate in place
-        fft_cols(true, inter_vals, trees[2].polys);
+        // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner
+        // interpolates and extends a column; the row-granular ones and the small ones are transformed by every rank.
+        trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
+        {
+            std::vector<DCol> mine_cols;
+            for (size_t i = 0; i < inter_vals.size(); i++) if (trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank) mine_cols.push_back(inter_vals[i]);
+            fft_cols(true, mine_cols, mine_cols);
+        }
         for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
-        commit_tree(trees[2]);
+        commit_tree(trees[2], nullptr, /*with_prev=*/true);
         tap("root2");
         tm.interaction = now() - t0;
 
@@ -531,9 +617,12 @@ struct HipProver {
         std::vector<ConstraintLaunch> launches(N_COMPONENTS);
         for (int k = 0; k < N_COMPONENTS; k++) {
             u32 log = bp.log_sizes[k], eval_log = log + 1, nc = n_constraints(k);
+            // shard group: an accumulator of a row-sharded size holds this rank's row range only (its components' interaction LDE columns
+            // have the same size and are row-sharded too)
+            const bool sl = slice_log(eval_log);
             if (!have[eval_log]) {
-                acc[eval_log].log_size = eval_log;
-                for (int w = 0; w < 4; w++) acc[eval_log].c[w] = c.alloc_u32(size_t(1) << eval_log);
+                acc[eval_log].log_size = eval_log; acc[eval_log].lc = sl ? lc() : 0;
+                for (int w = 0; w < 4; w++) acc[eval_log].c[w] = sl ? alloc_slice(eval_log) : c.alloc_u32(size_t(1) << eval_log);
             }
             ConstraintLaunch L{};
             L.overwrite = have[eval_log] ? 0u : 1u;      // the first component of a size writes the accumulator (no zero fill)
@@ -543,7 +632,10 @@ struct HipProver {
             remaining -= nc;
             L.is_first = trees[0].evals[log_max_rows - log].ptr;
             for (u32 j = 0; j < n_main_cols(k); j++) L.trace[j] = trees[1].evals[main_off[k] + j].desc();
-            for (u32 j = 0; j < 4 * n_logup_cols(k); j++) L.inter[j] = trees[2].evals[inter_off[k] + j].desc();
+            const u32 ni = 4 * n_logup_cols(k);
+            for (u32 j = 0; j < ni; j++) L.inter[j] = trees[2].evals[inter_off[k] + j].desc();
+            for (int w = 0; w < 4; w++) { const DCol& pv = trees[2].prev[inter_off[k] + ni - 4 + w]; L.inter_prev[w] = pv.ptr; }   // nullptr unless row-sharded
+            if (sl) { L.row0 = (u32)slice_first(eval_log); L.n_rows = (u32)slice_cells(eval_log); }
             for (int w = 0; w < 4; w++) L.acc[w] = acc[eval_log].c[w];
             L.el = el; L.total_sum = bp.claimed_sums[k]; L.log_size = log;
             // denom_inv[i] = 1 / coset_vanishing(CanonicCoset(log).coset, eval_domain.at(i)), i in {0, 1} (bit-reversal of 2 entries = identity)
@@ -552,24 +644,49 @@ struct HipProver {
         }
         c.stage_checkpoint();
         const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());   // one copy for the 13 parameter blocks
-        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k]);
+        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k], launches[k].n_rows);
         BF_HIP(hipGetLastError());
         // finalize (DomainEvaluationAccumulator::finalize): ascending sizes; the reference evaluates the running polynomial on the next
         // populated size, adds the evaluations and interpolates the sum. Interpolation is linear and evaluating a polynomial on a larger
         // domain is zero-extension of its coefficients (CirclePoly::extend), so interpolate(values + evaluate(prev)) =
         // interpolate(values) + extend(prev): one inverse transform per size and an addition over the *smaller* size — no forward
         // transform, no full-size accumulate. Exact field arithmetic: the coefficients are the same.
+        // Shard group: the 4 coordinate columns of a row-sharded accumulator are gathered whole on their owners (coordinate w on rank
+        // w mod count: rows -> columns, one grouped send-receive per size), which interpolate and merge them; ranks without a coordinate idle.
         bool cur_have = false; std::vector<DCol> cur(4);
+        bool cur_owned = false;               // `cur` is complete only on the coordinate's owner
+        auto owner_of = [&](int w) { return (u32)w % c.shard.count; };
         for (u32 log = 1; log <= max_log; log++) {
             if (!have[log]) continue;
-            std::vector<DCol> vals(4);
-            for (int w = 0; w < 4; w++) { vals[w].ptr = acc[log].c[w]; vals[w].log_size = log; vals[w].shift = 0; }
-            fft_cols(true, vals, vals);
+            std::vector<DCol> vals(4), mine_vals;
+            const bool sl = acc[log].lc != 0;
+            if (sl) {
+                const size_t cells = slice_cells(log), bytes = cells * sizeof(u32), first = slice_first(log);
+                std::vector<Xfer> sends, recvs;
+                for (int w = 0; w < 4; w++) {
+                    vals[w].log_size = log; vals[w].shift = 0;
+                    sends.push_back({owner_of(w), acc[log].c[w] + first, bytes});
+                    if (owner_of(w) == c.shard.rank) {
+                        vals[w].ptr = c.alloc_u32(size_t(1) << log);
+                        for (u32 r = 0; r < c.shard.count; r++) recvs.push_back({r, vals[w].ptr + r * cells, bytes});
+                        mine_vals.push_back(vals[w]);
+                    }
+                }
+                // receive order per peer must follow that peer's send order (coordinate ascending): regroup by coordinate within a peer
+                std::stable_sort(recvs.begin(), recvs.end(), [](const Xfer& a, const Xfer& b) { return a.peer < b.peer; });
+                c.shard.comm->exchange(c.stream, sends, recvs);
+            } else {
+                if (cur_owned) throw HipError("composition: a replicated accumulator above a row-sharded one");
+                for (int w = 0; w < 4; w++) { vals[w].ptr = acc[log].c[w]; vals[w].log_size = log; vals[w].shift = 0; mine_vals.push_back(vals[w]); }
+            }
+            fft_cols(true, mine_vals, mine_vals);
             if (cur_have)
-                for (int w = 0; w < 4; w++) accumulate(c.stream, vals[w].ptr, cur[w].ptr, 1u << cur[w].log_size);
-            cur = vals; cur_have = true;
+                for (int w = 0; w < 4; w++) if (!sl || owner_of(w) == c.shard.rank) accumulate(c.stream, vals[w].ptr, cur[w].ptr, 1u << cur[w].log_size);
+            cur = vals; cur_have = true; cur_owned = sl;
         }
         trees[3].polys = cur;
+        trees[3].owner.assign(4, OWNER_ALL);
+        if (cur_owned) for (int w = 0; w < 4; w++) trees[3].owner[w] = owner_of(w);
     }
 
     // PolyOps::eval_at_point for every (column, mask point)
@@ -582,26 +699,33 @@ struct HipProver {
             factors[p * 32 + 0] = pk(points[p].y);
             for (u32 b = 1; b < 32; b++) { factors[p * 32 + b] = pk(x); x = q_double_x(x); }
         }
+        // Shard group: a sample is evaluated by ONE rank — the owner of the polynomial's coefficients, or for polynomials every rank holds the
+        // rank (job index mod count), which splits that work — the others leave a zero and one max-reduce completes the array everywhere.
         std::vector<EvalJob> jobs;
-        u32 partial_off = 0;
+        u32 partial_off = 0, n_all = 0;
         for (size_t t = 0; t < trees.size(); t++)
             for (size_t col = 0; col < trees[t].polys.size(); col++)
                 for (u32 pt : mask[t][col]) {
+                    const u32 ji = n_all++;
+                    const u32 owner = trees[t].owner.empty() ? OWNER_ALL : trees[t].owner[col];
+                    if (sharded() && (owner == OWNER_ALL ? ji % c.shard.count : owner) != c.shard.rank) continue;
                     const DCol& p = trees[t].polys[col];
-                    EvalJob j; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = partial_off;
+                    EvalJob j{}; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = partial_off; j.out_idx = ji;
                     partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
                     jobs.push_back(j);
                 }
         c.stage_checkpoint();
         StageBatch sb(c);
         const uint4* d_factors = c.stage(factors.data(), factors.size());     // through the pinned staging ring (no pageable copies)
-        const EvalJob* d_jobs = c.stage(jobs.data(), jobs.size());
+        const EvalJob* d_jobs = jobs.empty() ? nullptr : c.stage(jobs.data(), jobs.size());
         sb.end();
-        void* d_partials = c.arena.alloc(size_t(partial_off) * sizeof(uint4));
-        uint4* d_out = (uint4*)c.arena.alloc(jobs.size() * sizeof(uint4));
+        void* d_partials = c.arena.alloc(size_t(partial_off ? partial_off : 1) * sizeof(uint4));
+        uint4* d_out = (uint4*)c.arena.alloc(n_all * sizeof(uint4));
+        if (sharded()) BF_HIP(hipMemsetAsync(d_out, 0, n_all * sizeof(uint4), c.stream));
         eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
         BF_HIP(hipGetLastError());
-        std::vector<uint4> out(jobs.size());
+        if (sharded()) c.shard.comm->all_reduce_max_u32(c.stream, reinterpret_cast<u32*>(d_out), size_t(n_all) * 4);
+        std::vector<uint4> out(n_all);
         c.read_back(out.data(), d_out, out.size() * sizeof(uint4));
         pf.sampled_values.resize(trees.size());
         size_t ji = 0;
@@ -636,9 +760,14 @@ struct HipProver {
             }
             std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
             build_quotient_batches(samples, random_coeff, batches, entries);
-            DSecure q; q.log_size = log;
-            for (int w = 0; w < 4; w++) q.c[w] = c.alloc_u32(size_t(1) << log);
+            // shard group: the quotient of a row-sharded size is computed for this rank's row range only (every column of the group is
+            // either complete or row-sharded over the same range)
+            const bool sl = slice_log(log);
+            DSecure q; q.log_size = log; q.lc = sl ? lc() : 0;
+            for (int w = 0; w < 4; w++) q.c[w] = sl ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
             QuotientArgs a{};
+            if (sl) { a.row0 = (u32)slice_first(log); a.n_rows = (u32)slice_cells(log); }
+            for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && flat[k].col.shift == 0 && flat[k].tree >= 2) throw HipError("quotients: inconsistent row-sharding in a size group");
             a.cols = c.stage(descs.data(), descs.size());
             a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
             a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
@@ -676,13 +805,13 @@ struct HipProver {
     }
     Finisher gather_secure_deferred(Gather& g, const DSecure& s, const std::vector<size_t>& pos, std::vector<Q31>* out) {
         size_t first = g.n_words;
-        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
+        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p, s.mine(p, c.shard.rank));
         size_t n = pos.size();
         return [first, n, out](const std::vector<u32>& d) { for (size_t k = 0; k < n; k++) out->push_back(q_make(d[first + 4 * k], d[first + 4 * k + 1], d[first + 4 * k + 2], d[first + 4 * k + 3])); };
     }
     std::vector<Q31> gather_secure(const DSecure& s, const std::vector<size_t>& pos) {
         Gather g;
-        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p);
+        for (size_t p : pos) for (int w = 0; w < 4; w++) g.add(s.c[w], p, s.mine(p, c.shard.rank));
         auto d = g.run(c);
         std::vector<Q31> out;
         for (size_t k = 0; k < pos.size(); k++) out.push_back(q_make(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]));
@@ -690,7 +819,7 @@ struct HipProver {
     }
     static std::vector<DCol> secure_cols(const DSecure& s) {
         std::vector<DCol> v(4);
-        for (int w = 0; w < 4; w++) { v[w].ptr = s.c[w]; v[w].log_size = s.log_size; v[w].shift = 0; }
+        for (int w = 0; w < 4; w++) { v[w].ptr = s.c[w]; v[w].log_size = s.log_size; v[w].shift = 0; v[w].lc = s.lc; }
         return v;
     }
 
@@ -716,30 +845,50 @@ struct HipProver {
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
-        DSecure layer; layer.log_size = line_log;
-        for (int w = 0; w < 4; w++) layer.c[w] = c.alloc_u32(size_t(1) << line_log);
+        // Shard group: a layer with >= 2^12 rows per rank is row-sharded like the quotients (a fold maps the sibling pair (2i, 2i+1) to cell
+        // i, so a rank's row range of the source folds into its row range of the destination). The first layer below that size is produced
+        // range-wise into a complete buffer and finished by one all-gather; everything smaller is folded redundantly on every rank.
+        auto new_layer = [&](u32 log) {
+            DSecure l; l.log_size = log; l.lc = slice_log(log) ? lc() : 0;
+            for (int w = 0; w < 4; w++) l.c[w] = l.lc ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
+            return l;
+        };
+        // destination range of a fold whose SOURCE has 2^src_log rows: the image of this rank's source range when the source is sharded
+        auto fold_range = [&](u32 src_log, bool src_sliced, u32& first, u32& count) {
+            if (src_sliced) { first = (u32)(slice_first(src_log) >> 1); count = (u32)(slice_cells(src_log) >> 1); } else { first = 0; count = 0; }
+        };
+        DSecure layer = new_layer(line_log);
         bool layer_fresh = true;                     // nothing folded into `layer` yet: the first circle fold writes it (no zero fill)
+        bool layer_partial = false;                  // a complete (unsharded) buffer of which every rank has filled only its range so far
         size_t qi = 0;
         u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
         if (line_log > last_log + max_layers) throw HipError("FRI: too many layers");
         while (line_log > last_log) {
             while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
                 const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
-                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size, layer_fresh);
+                u32 first, count; fold_range(quotients[qi].log_size, quotients[qi].lc != 0, first, count);
+                if (quotients[qi].lc != 0 && layer.lc == 0) layer_partial = true;
+                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size, layer_fresh, first, count);
                 layer_fresh = false;
                 qi++;
+            }
+            if (layer_partial) {
+                for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, layer.c[w], sizeof(u32) << (line_log - lc()));
+                layer_partial = false;
             }
             Inner in; in.ev = layer;
             cur_alpha++;
             ChannelStep step{d_chan, d_alpha + 8 * cur_alpha, d_roots + 8 * (1 + inner.size())};
             in.tree = merkle_commit(secure_cols(layer), nullptr, /*no_readback=*/true, &step);
-            DSecure next; next.log_size = line_log - 1;
-            for (int w = 0; w < 4; w++) next.c[w] = c.alloc_u32(size_t(1) << (line_log - 1));
+            DSecure next = new_layer(line_log - 1);
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
-            fold_line(c.stream, next.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, line_log);
+            u32 first, count; fold_range(line_log, layer.lc != 0, first, count);
+            if (layer.lc != 0 && next.lc == 0) layer_partial = true;
+            fold_line(c.stream, next.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, line_log, first, count);
             inner.push_back(in);
             layer = next; line_log--;
         }
+        if (layer_partial) for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, layer.c[w], sizeof(u32) << (line_log - lc()));
         if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
         BF_HIP(hipGetLastError());
         BF_HIP(hipMemcpyAsync(pinned_chan, d_chan, 36, hipMemcpyDeviceToHost, c.stream));

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage2(const EvalJob* __r
         if (act) s[t] = pk_q(r);
         __syncthreads();
     }
-    if (t == 0) out[blockIdx.x] = s[0];
+    if (t == 0) out[job.out_idx] = s[0];
 }
 
 // total_partials = sum over jobs of their chunk counts (= partial_off of the last job + its chunk count); jobs sorted by partial_off.
@@ -143,7 +143,8 @@ __device__ __forceinline__ void domain_point(const u32* __restrict__ tw, u32 tw_
 // denominators of a batch share one M31 inversion (Montgomery trick on the CM31 norms) — values identical to 4 separate inverses.
 __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
     u32 row0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (row0 >= (1u << a.log)) return;
+    if (a.n_rows) { if (row0 >= a.n_rows) return; row0 += a.row0; }
+    else if (row0 >= (1u << a.log)) return;
     u32 x[4], y[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) domain_point(a.tw, a.tw_total, a.log, row0 + r, x[r], y[r]);
@@ -211,7 +212,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
     *reinterpret_cast<uint4*>(a.out[3] + row0) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
 }
 void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
-    u32 n = (1u << a.log) / 4;   // 4 rows per lane (all quotient domains have >= 2^5 rows)
+    u32 n = (a.n_rows ? a.n_rows : (1u << a.log)) / 4;   // 4 rows per lane (all quotient domains have >= 2^5 rows)
     ProfScope ps(stream, "k_quotients", 0);
     hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
@@ -224,9 +225,10 @@ void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u32* const d1, u32* const d2, u32* const d3,
                                                                const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
-                                                               const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log, u32 fresh) {
+                                                               const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log, u32 fresh, u32 first, u32 count) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << (log - 1))) return;
+    if (i >= count) return;
+    i += first;
     const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]), alpha_sq = q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]);
     const u32* t1 = itw + (tw_total - (1u << (log - 1)));
     u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
@@ -241,9 +243,10 @@ __global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u3
 }
 __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3,
                                                    const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
-                                                   const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log) {
+                                                   const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log, u32 first, u32 count) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << (log - 1))) return;
+    if (i >= count) return;
+    i += first;
     const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]);
     u32 xinv = itw[tw_total - (1u << log) + i];
     uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
@@ -253,14 +256,16 @@ __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
 // d_alpha8 = device pointer to alpha[4] || alpha^2[4] (written by k_channel_mix_root_draw or staged from the host)
-void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh) {
-    u32 n = 1u << (log - 1);
-    hipLaunchKernelGGL(k_fold_circle_into_line, dim3((n + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3],
-                       d_alpha8, itw, 1u << tw_root_log, log, fresh ? 1u : 0u);
+void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh,
+                           u32 first, u32 count) {
+    if (!count) { first = 0; count = 1u << (log - 1); }
+    hipLaunchKernelGGL(k_fold_circle_into_line, dim3((count + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3],
+                       d_alpha8, itw, 1u << tw_root_log, log, fresh ? 1u : 0u, first, count);
 }
-void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log) {
-    u32 n = 1u << (log - 1);
-    hipLaunchKernelGGL(k_fold_line, dim3((n + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3], d_alpha8, itw, 1u << tw_root_log, log);
+void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, u32 first, u32 count) {
+    if (!count) { first = 0; count = 1u << (log - 1); }
+    hipLaunchKernelGGL(k_fold_line, dim3((count + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3], d_alpha8, itw, 1u << tw_root_log, log,
+                       first, count);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

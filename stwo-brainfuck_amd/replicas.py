@@ -1,6 +1,7 @@
-"""Multi-GPU host logic for the "replicas only" mode: one process per GPU, each rank proves its own
-independent trace; there is no data-path collective (the reference has no multi-device path at all — SURVEY.md §2.3).
-Only the timing protocol needs torch.distributed: barrier on both sides of the timed region and MAX over ranks of the elapsed time."""
+"""Multi-GPU host logic (DESIGN.md section multi-GPU): one process per GPU. Replicas (default): each rank proves its own independent
+trace, no data-path collective (the reference has no multi-device path at all — SURVEY.md section 2.3). Shard group: the ranks prove
+ONE trace together; the data-path exchanges are issued by libbfhip itself (RCCL on the context's stream) and torch.distributed only
+carries the timing protocol (barrier on both sides of the timed region, MAX over ranks of the elapsed time) and the 128-byte unique id."""
 import time
 
 
@@ -51,27 +52,19 @@ def aggregate_units(units_this_rank: int, dist=None, backend_tensor=None) -> int
     return int(t.item())
 
 
-def shard_exchanges(dist, device=None):
-    """The two exchanges of a shard group (Context.set_shard) over torch.distributed: RCCL when `device` is a CUDA device
-    (backend "nccl"), gloo on CPU tensors otherwise. Returns (allgather, allreduce_max)."""
-    import numpy as np
+def share_unique_id(dist, make_id, device=None) -> bytes:
+    """Control plane of a multi-process shard group (Context.join_rccl_group): rank 0 creates the 128-byte RCCL unique id with make_id()
+    and every rank receives it through one broadcast of the already initialised torch.distributed group (RCCL tensors when `device` is
+    a CUDA device, gloo on CPU tensors otherwise). The proof's data never travels this way: the library issues its own collectives."""
     import torch
-
-    world = dist.get_world_size()
-
-    def allgather(send: bytes) -> bytes:
-        t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
-        if device is not None:
-            t = t.to(device)
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        return b"".join(o.cpu().numpy().tobytes() for o in outs)
-
-    def allreduce_max(values):
-        t = torch.from_numpy(values.astype(np.int64))     # u32 values as int64: MAX is then the unsigned maximum on every backend
-        if device is not None:
-            t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return t.cpu().numpy().astype(np.uint32)
-
-    return allgather, allreduce_max
+    rank = dist.get_rank()
+    t = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        raw = make_id()
+        if len(raw) != 128:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().numpy().tobytes())

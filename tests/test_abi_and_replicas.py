@@ -68,14 +68,11 @@ assert len(calls) == 4 and last[0] == "proof"
 assert dt >= 0.02 * 2 * 3 * 0.9, dt          # MAX over ranks: the slow rank (rank 1) sets the time
 assert cells == 2001
 assert rep.rank_device(rank, 8) == rank
-# the two exchanges of a shard group (one proof over several GPUs) over gloo
-import numpy as np
-allgather, allreduce_max = rep.shard_exchanges(dist)
-got = allgather(bytes([rank]) * 5)
-assert got == b"\x00" * 5 + b"\x01" * 5, got
-vals = np.array([0, 7, 0xFFFFFFFF, 3], dtype=np.uint32) if rank == 0 else np.array([5, 0, 1, 3], dtype=np.uint32)
-red = allreduce_max(vals)
-assert red.dtype == np.uint32 and red.tolist() == [5, 7, 0xFFFFFFFF, 3], red
+# control plane of a shard group (one proof over several GPUs): rank 0's 128-byte unique id reaches every rank over gloo
+made = []
+uid = rep.share_unique_id(dist, lambda: (made.append(1), bytes(range(128)))[1])
+assert uid == bytes(range(128)), uid
+assert len(made) == (1 if rank == 0 else 0)
 print("ok", rank, round(dt, 3))
 dist.destroy_process_group()
 """
@@ -100,6 +97,6 @@ def test_rust_ffi_is_in_step_with_the_header():
     assert r.returncode == 0, r.stderr
     assert open(os.path.join(ROOT, "bindings", "rust", "bfhip_sys.rs")).read() == committed, "bfhip_sys.rs is stale: run tools/gen_rust_ffi.py"
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bfhip.h")).read(), flags=re.S)
-    declared = set(re.findall(r"\b(bfhip_\w+)\s*\(", header)) - {"bfhip_allgather_fn", "bfhip_allreduce_max_u32_fn"}
+    declared = set(re.findall(r"\b(bfhip_\w+)\s*\(", header))
     in_rust = set(re.findall(r"pub fn (bfhip_\w+)\(", committed))
     assert declared == in_rust, declared ^ in_rust

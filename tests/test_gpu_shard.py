@@ -1,6 +1,7 @@
-"""-m gpu: one proof over several contexts ("shard group", include/bfhip.h: bfhip_ctx_set_shard). The group members run on the one
-GPU of the test box — one context, stream and host thread each — and exchange through an in-process all-gather / max-reduce, which is
-what the callbacks see from torch.distributed on a multi-GPU node. Every rank must produce exactly the single-GPU proof."""
+"""-m gpu: one proof over several contexts ("shard group", include/bfhip.h: bfhip_ctx_join_local_group / _rccl_group). The group members
+run on the one GPU of the test box — one context, stream and host thread each — over the library's in-process transport, which issues
+the same sequence of exchanges (all-gather per tree, grouped send-receive column -> row ranges, max-reduce of samples and decommitment
+words) as the RCCL transport does with one process per GPU. Every rank must produce exactly the single-GPU proof, byte for byte."""
 import os
 import threading
 
@@ -12,49 +13,20 @@ pytestmark = pytest.mark.gpu
 PROGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "programs")
 
 
-class InProcessGroup:
-    """Rendezvous of `count` threads: allgather / allreduce_max with torch.distributed semantics."""
-
-    def __init__(self, count):
-        self.count = count
-        self.barrier = threading.Barrier(count)
-        self.slots = [None] * count
-        self.calls = {"allgather": 0, "allreduce": 0}
-
-    def exchanges(self, rank):
-        def allgather(send: bytes) -> bytes:
-            self.slots[rank] = send
-            self.barrier.wait()
-            out = b"".join(self.slots)
-            self.barrier.wait()
-            if rank == 0:
-                self.calls["allgather"] += 1
-            return out
-
-        def allreduce_max(values):
-            self.slots[rank] = values
-            self.barrier.wait()
-            out = np.maximum.reduce(self.slots)
-            self.barrier.wait()
-            if rank == 0:
-                self.calls["allreduce"] += 1
-            return out
-
-        return allgather, allreduce_max
-
-
-def _prove_sharded(pkg, code, inp, lmr, count):
-    group = InProcessGroup(count)
+def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False):
+    """`count` contexts of this process on the one GPU, one host thread each, joined into a local shard group (bfhip_local_group_*)."""
+    group = pkg.LocalGroup(count)
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(count)]
-    proofs, errors = [None] * count, []
+    proofs, errors, stats = [None] * count, [], [None] * count
 
     def run(rank):
         try:
-            ctxs[rank].set_shard(rank, count, *group.exchanges(rank))
-            proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr)
-        except Exception as e:      # a failing rank must not leave the others waiting at the rendezvous
+            ctxs[rank].join_local_group(group, rank)
+            assert ctxs[rank].group_info()[:2] == (rank, count)
+            proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr, with_transcript=with_transcript)
+            stats[rank] = ctxs[rank].group_stats()
+        except Exception as e:      # the other ranks run into the rendezvous timeout of the library
             errors.append(e)
-            group.barrier.abort()
 
     threads = [threading.Thread(target=run, args=(r,)) for r in range(count)]
     for t in threads:
@@ -62,27 +34,34 @@ def _prove_sharded(pkg, code, inp, lmr, count):
     for t in threads:
         t.join()
     for c in ctxs:
+        c.leave_group()
         c.close()
+    group.close()
     assert not errors, errors
-    return proofs, group.calls
+    _prove_sharded.last_stats = stats
+    return proofs
 
 
 @pytest.mark.parametrize("count", [2, 4, 8])
 @pytest.mark.parametrize("name,inp,lmr", [("hello_kakarot.bf", b"", 17), ("collatz.bf", b"7\n", 21)])
 def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, lmr, count):
     code = open(os.path.join(PROGS, name)).read()
-    single = pkg.prove_brainfuck(code, inp, ctx=pkg.Context(0, max_log_domain=lmr + 2), log_max_rows=lmr)
-    proofs, calls = _prove_sharded(pkg, code, inp, lmr, count)
-    assert all(p == single for p in proofs)
-    assert calls["allgather"] > 0 and calls["allreduce"] > 0          # the trees really were hashed share-wise
+    c1 = pkg.Context(0, max_log_domain=lmr + 2)
+    single = pkg.prove_brainfuck(code, inp, ctx=c1, log_max_rows=lmr)
+    c1.close()
+    proofs = _prove_sharded(pkg, code, inp, lmr, count)
+    for r, p in enumerate(proofs):
+        assert p == single, f"rank {r} of {count} differs from the single-GPU proof"
     assert oracle.verify(single, lmr)[0]
+    for st in _prove_sharded.last_stats:     # the work really was divided: trees hashed share-wise, columns cut into row ranges, samples reduced
+        assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
 
 
 def test_fib19_full_size_in_a_shard_group_of_two(pkg):
     """The benchmark workload: both ranks reproduce the committed digest of the oracle's proof."""
     import hashlib, json
     code = open(os.path.join(PROGS, "fib19.bf")).read()
-    proofs, _ = _prove_sharded(pkg, code, b"", 24, 2)
+    proofs = _prove_sharded(pkg, code, b"", 24, 2)
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))["stwo"]
     for p in proofs:
         assert hashlib.sha256(p).hexdigest() == want["sha256"]
@@ -90,10 +69,15 @@ def test_fib19_full_size_in_a_shard_group_of_two(pkg):
 
 def test_shard_arguments_are_checked(pkg, ctx):
     with pytest.raises(pkg.BfhipError, match="power of two"):
-        ctx.set_shard(0, 3, lambda b: b, lambda v: v)
+        pkg.LocalGroup(3)
+    g = pkg.LocalGroup(2)
     with pytest.raises(pkg.BfhipError, match="rank"):
-        ctx.set_shard(2, 2, lambda b: b, lambda v: v)
-    ctx.set_shard(0, 1)
+        ctx.join_local_group(g, 2)
+    assert ctx.group_info()[:2] == (0, 1)
+    ctx.leave_group()
+    g.close()
+    with pytest.raises(pkg.BfhipError, match="128"):
+        ctx.join_rccl_group(b"short", 0, 2)
 
 
 def test_independent_contexts_prove_concurrently(pkg, oracle):
@@ -126,3 +110,9 @@ def test_independent_contexts_prove_concurrently(pkg, oracle):
     assert not errors, errors
     for k in range(2):
         assert all(p == alone[k] for p in out[k])
+
+
+def test_rccl_transport_selftest(pkg, ctx):
+    """RCCL is loaded with dlopen and driven on the context's stream; with one GPU only a one-rank communicator can be exercised."""
+    assert pkg.lib().bfhip_rccl_selftest(ctx._h) == 0, pkg.lib().bfhip_last_error().decode()
+    assert len(pkg.rccl_unique_id()) == 128

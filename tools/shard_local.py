@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""One proof over N contexts of ONE GPU (local shard group, one host thread per rank): ms per proof for N = 1, 2, 4, 8 and what it says
+about the division of work. The N ranks time-share the GPU, so T(N) = N * S + P where S is the work every rank repeats (replicated
+phases) and P the work that is divided; with one GPU per rank the expected time is about S + P / N plus the exchanges.
+Usage: python tools/shard_local.py [steps]"""
+import json, os, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package
+
+FIB19 = open(os.path.join(ROOT, "tests", "golden", "programs", "fib19.bf")).read()
+
+
+def run(pkg, n, steps, lmr=24):
+    group = pkg.LocalGroup(n) if n > 1 else None
+    ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(n)]
+    traces = [pkg.Trace(c, FIB19, b"") for c in ctxs]
+    proofs, stats, times = [None] * n, [None] * n, [0.0] * n
+    barrier = threading.Barrier(n)
+
+    def work(r):
+        if group:
+            ctxs[r].join_local_group(group, r)
+        traces[r].prove(lmr)
+        barrier.wait()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proofs[r], _ = traces[r].prove(lmr)
+        ctxs[r].sync()
+        times[r] = (time.perf_counter() - t0) / steps
+        if group:
+            stats[r] = ctxs[r].group_stats()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for r in range(n):
+        if group:
+            ctxs[r].leave_group()
+        traces[r].close(); ctxs[r].close()
+    if group:
+        group.close()
+    assert all(p == proofs[0] for p in proofs)
+    return max(times) * 1e3, proofs[0], stats
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    pkg = load_package()
+    out, ref = [], None
+    for n in (1, 2, 4, 8):
+        ms, proof, stats = run(pkg, n, steps)
+        ref = ref or proof
+        row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "identical_to_single": proof == ref}
+        if stats[0]:
+            per_proof = {k: v / (steps + 1) for k, v in stats[0].items()}
+            row["rank0_per_proof"] = {"all_gathers": per_proof["all_gathers"], "max_reduces": per_proof["max_reduces"], "exchanges": per_proof["exchanges"],
+                                      "MB_sent": round(per_proof["bytes_sent"] / 1e6, 1)}
+        out.append(row)
+    t1 = out[0]["ms_per_proof"]
+    for row in out[1:]:
+        n = row["ranks_on_one_gpu"]
+        s = (row["ms_per_proof"] - t1) / (n - 1)          # T(N) = N S + P, T(1) = S + P
+        row["replicated_ms_S"] = round(s, 2); row["divided_ms_P"] = round(t1 - s, 2); row["projected_ms_with_one_gpu_per_rank"] = round(s + (t1 - s) / n, 2)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
