@@ -423,11 +423,21 @@ struct HipProver {
             try {
                 if (cache.enabled) { cache.keep.reset(); std::swap(c.arena, cache.keep); }   // build the tree in memory that survives arena.reset()
                 for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
-                    DCol p; p.log_size = log; p.shift = 0; p.ptr = c.alloc_u32(p.stored());
-                    one_hot(c.stream, p.ptr, 1u << log);
+                    DCol p; p.log_size = log; p.shift = 0; p.ptr = nullptr;
                     trees[0].polys.push_back(p);
                 }
-                fft_cols(true, trees[0].polys, trees[0].polys);
+                // shard group: the big IsFirst columns are column-sharded like the interaction tree's (owner interpolates and extends,
+                // every rank receives its row range of the LDE)
+                trees[0].owner = assign_owners(trees[0].polys, cfg.log_blowup);
+                std::vector<DCol> mine_cols;
+                for (size_t i = 0; i < trees[0].polys.size(); i++) {
+                    if (trees[0].owner[i] != OWNER_ALL && trees[0].owner[i] != c.shard.rank) continue;
+                    DCol& p = trees[0].polys[i];
+                    p.ptr = c.alloc_u32(p.stored());
+                    one_hot(c.stream, p.ptr, 1u << p.log_size);
+                    mine_cols.push_back(p);
+                }
+                fft_cols(true, mine_cols, mine_cols);
                 commit_tree(trees[0], pinned_root0);
                 if (cache.enabled) std::swap(c.arena, cache.keep);
                 BF_HIP(hipEventRecord(c.ev[1], c.stream));
@@ -767,7 +777,7 @@ struct HipProver {
             for (int w = 0; w < 4; w++) q.c[w] = sl ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
             QuotientArgs a{};
             if (sl) { a.row0 = (u32)slice_first(log); a.n_rows = (u32)slice_cells(log); }
-            for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && flat[k].col.shift == 0 && flat[k].tree >= 2) throw HipError("quotients: inconsistent row-sharding in a size group");
+            for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && flat[k].col.shift == 0) throw HipError("quotients: inconsistent row-sharding in a size group");
             a.cols = c.stage(descs.data(), descs.size());
             a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
             a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());

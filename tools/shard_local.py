@@ -15,7 +15,7 @@ def run(pkg, n, steps, lmr=24):
     group = pkg.LocalGroup(n) if n > 1 else None
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(n)]
     traces = [pkg.Trace(c, FIB19, b"") for c in ctxs]
-    proofs, stats, times = [None] * n, [None] * n, [0.0] * n
+    proofs, stats, times, phases = [None] * n, [None] * n, [0.0] * n, [None] * n
     barrier = threading.Barrier(n)
 
     def work(r):
@@ -25,7 +25,7 @@ def run(pkg, n, steps, lmr=24):
         barrier.wait()
         t0 = time.perf_counter()
         for _ in range(steps):
-            proofs[r], _ = traces[r].prove(lmr)
+            proofs[r], phases[r] = traces[r].prove(lmr)
         ctxs[r].sync()
         times[r] = (time.perf_counter() - t0) / steps
         if group:
@@ -39,7 +39,7 @@ def run(pkg, n, steps, lmr=24):
     if group:
         group.close()
     assert all(p == proofs[0] for p in proofs)
-    return max(times) * 1e3, proofs[0], stats
+    return max(times) * 1e3, proofs[0], stats, phases[0]
 
 
 def main():
@@ -47,15 +47,21 @@ def main():
     pkg = load_package()
     out, ref = [], None
     for n in (1, 2, 4, 8):
-        ms, proof, stats = run(pkg, n, steps)
+        ms, proof, stats, ph = run(pkg, n, steps)
         ref = ref or proof
-        row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "identical_to_single": proof == ref}
+        row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "identical_to_single": proof == ref,
+               "rank0_phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in ph.items()}}
         if stats[0]:
             per_proof = {k: v / (steps + 1) for k, v in stats[0].items()}
             row["rank0_per_proof"] = {"all_gathers": per_proof["all_gathers"], "max_reduces": per_proof["max_reduces"], "exchanges": per_proof["exchanges"],
                                       "MB_sent": round(per_proof["bytes_sent"] / 1e6, 1)}
         out.append(row)
     t1 = out[0]["ms_per_proof"]
+    p1 = out[0]["rank0_phase_ms_last_proof"]
+    for row in out[1:]:
+        n = row["ranks_on_one_gpu"]
+        # per phase: T(N) = N S + P with T(1) = S + P  ->  S = (T(N) - T(1)) / (N - 1): the part of the phase every rank repeats
+        row["replicated_ms_by_phase"] = {k: round((row["rank0_phase_ms_last_proof"][k] - p1[k]) / (n - 1), 2) for k in p1}
     for row in out[1:]:
         n = row["ranks_on_one_gpu"]
         s = (row["ms_per_proof"] - t1) / (n - 1)          # T(N) = N S + P, T(1) = S + P
