@@ -41,11 +41,18 @@ typedef struct bfhip_trace bfhip_trace;
 enum { BFHIP_MERKLE_STWO_COMPRESS = 0, BFHIP_MERKLE_RFC7693 = 1 };
 enum { BFHIP_MIX_U64_COMPRESS = 0, BFHIP_MIX_U64_HASH = 1 };
 enum { BFHIP_LOGUP_MASK_CUR_PREV = 0, BFHIP_LOGUP_MASK_PREV_CUR = 1 };
+/* merkle_channel is not a convention but the protocol variant, carried in the same struct so that it reaches prover and verifier alike:
+ *      BFHIP_CHANNEL_BLAKE2S      Blake2sMerkleChannel — what the reference instantiates (mod.rs:56,486-487). Default.
+ *      BFHIP_CHANNEL_POSEIDON252  Poseidon252MerkleChannel (BASELINE.json config 5; an upstream stwo capability over starknet-crypto 0.6.2,
+ *                                 Cargo.lock:821-864, which the reference never instantiates): Poseidon252MerkleHasher nodes, Poseidon252Channel
+ *                                 transcript, felt252 hashes serialised as "0x.." hex strings. merkle_node_hash and mix_u64 do not apply. */
+enum { BFHIP_CHANNEL_BLAKE2S = 0, BFHIP_CHANNEL_POSEIDON252 = 1 };
 typedef struct bfhip_conventions {
     uint32_t merkle_node_hash;
     uint32_t mix_u64;
     uint32_t logup_mask_order;
-    uint32_t reserved[5];   /* must be zero */
+    uint32_t merkle_channel;
+    uint32_t reserved[4];   /* must be zero */
 } bfhip_conventions;
 
 const char* bfhip_last_error(void);

@@ -6,6 +6,7 @@
 // LookupElements::draw (brainfuck_air/mod.rs:158-164).
 #pragma once
 #include "field.h"
+#include "poseidon252.h"
 #include <cstring>
 #include <vector>
 
@@ -83,21 +84,39 @@ struct Blake2s {
     static Hash32 hash(const void* data, size_t len) { Blake2s s; s.update(data, len); return s.finalize(); }
 };
 
-// stwo core/channel/blake2s.rs Blake2sChannel.
+// stwo core/channel/blake2s.rs Blake2sChannel, or — conventions().merkle_channel == 1 at construction — core/channel/poseidon252.rs
+// Poseidon252Channel, whose felt252 digest is kept as its canonical 32 little-endian bytes.
 struct Channel {
     Hash32 digest;
     u32 n_challenges = 0, n_sent = 0;
-    Channel() { memset(digest.b, 0, 32); }
+    bool poseidon = false;
+    Channel() : poseidon(conventions().merkle_channel == 1) { memset(digest.b, 0, 32); }
     void update_digest(const Hash32& d) { digest = d; n_challenges++; n_sent = 0; }
-    // Blake2sMerkleChannel::mix_root: digest = H(digest || root)
-    void mix_root(const Hash32& root) { Blake2s s; s.update(digest.b, 32); s.update(root.b, 32); update_digest(s.finalize()); }
+    void update_felt(const Felt& f) { Hash32 d; f.to_le_bytes(d.b); update_digest(d); }
+    Felt digest_felt() const { return Felt::from_le_bytes(digest.b); }
+    // Blake2sMerkleChannel::mix_root: digest = H(digest || root); Poseidon252MerkleChannel::mix_root: digest = poseidon_hash(digest, root)
+    void mix_root(const Hash32& root) {
+        if (poseidon) { update_felt(poseidon_hash(digest_felt(), Felt::from_le_bytes(root.b))); return; }
+        Blake2s s; s.update(digest.b, 32); s.update(root.b, 32); update_digest(s.finalize());
+    }
     void mix_felts(const QM31* f, size_t n) {
+        if (poseidon) {   // poseidon_hash_many([digest] ++ one felt per chunk of 2 secure felts, folded cur = cur * 2^31 + coordinate)
+            std::vector<Felt> res; res.push_back(digest_felt());
+            for (size_t i = 0; i < n; i += 2) {
+                Felt cur = Felt::raw(0, 0, 0, 0);
+                for (size_t k = i; k < std::min(n, i + 2); k++) { auto a = f[k].to_u32(); for (int q = 0; q < 4; q++) cur = fold_m31(cur, a[q]); }
+                res.push_back(cur);
+            }
+            update_felt(poseidon_hash_many(res));
+            return;
+        }
         Blake2s s; s.update(digest.b, 32);
         for (size_t i = 0; i < n; i++) { auto a = f[i].to_u32(); s.update(a.data(), 16); }
         update_digest(s.finalize());
     }
     // mix_u64: raw compression of [n_lo, n_hi, 0...] with h = digest words, t = f = 0.
     void mix_u64(u64 nonce) {
+        if (poseidon) { update_felt(poseidon_hash(digest_felt(), Felt::from_u64(nonce))); return; }
         if (conventions().mix_u64 == 1) {
             u8 in[64]; memcpy(in, digest.b, 32); memset(in + 32, 0, 32); memcpy(in + 32, &nonce, 8);
             update_digest(Blake2s::hash(in, 64));
@@ -109,16 +128,34 @@ struct Channel {
         Hash32 d; memcpy(d.b, h, 32);
         update_digest(d);
     }
-    Hash32 draw_random_bytes() {
+    // Poseidon252Channel::draw_felt252 as canonical integer limbs
+    void draw_felt252(u64 out[4]) { Felt r = poseidon_hash(digest_felt(), Felt::from_u64(n_sent)); n_sent++; r.to_canonical(out); }
+    std::vector<u8> draw_random_bytes() {
+        if (poseidon) {   // 31 times: byte = cur mod 2^8, cur = cur div 2^8
+            u64 c[4]; draw_felt252(c);
+            std::vector<u8> out(31);
+            for (int i = 0; i < 31; i++) out[i] = (u8)(c[i / 8] >> (8 * (i % 8)));
+            return out;
+        }
         u8 in[64]; memcpy(in, digest.b, 32); memset(in + 32, 0, 32);
         memcpy(in + 32, &n_sent, 4);  // counter as LE bytes, zero padded to 32
         n_sent++;
-        return Blake2s::hash(in, 64);
+        Hash32 r = Blake2s::hash(in, 64);
+        return std::vector<u8>(r.b, r.b + 32);
     }
     void draw_base_felts(M31 out[8]) {
+        if (poseidon) {   // 8 times: limb = cur mod 2^31, cur = cur div 2^31; BaseField::reduce(limb)
+            u64 c[4]; draw_felt252(c);
+            for (int i = 0; i < 8; i++) {
+                u32 limb = (u32)(c[0] & 0x7fffffffull);
+                out[i] = M31(m31_reduce(limb));
+                for (int k = 0; k < 4; k++) c[k] = (c[k] >> 31) | (k + 1 < 4 ? c[k + 1] << 33 : 0);
+            }
+            return;
+        }
         for (;;) {
-            Hash32 r = draw_random_bytes();
-            u32 w[8]; memcpy(w, r.b, 32);
+            std::vector<u8> r = draw_random_bytes();
+            u32 w[8]; memcpy(w, r.data(), 32);
             bool ok = true;
             for (int i = 0; i < 8; i++) if (w[i] >= 2 * P) ok = false;
             if (!ok) continue;
@@ -140,8 +177,15 @@ struct Channel {
         }
         return out;
     }
-    // trailing zeros of the first 16 digest bytes read as a LE u128
+    // trailing zeros of the first 16 digest bytes read as a LE u128 (Poseidon: of digest.to_bytes_be())
     u32 trailing_zeros() const {
+        if (poseidon) {
+            u8 be[32]; for (int i = 0; i < 32; i++) be[i] = digest.b[31 - i];
+            unsigned __int128 v = 0; for (int i = 15; i >= 0; i--) v = (v << 8) | be[i];
+            if (!v) return 128;
+            u32 tz = 0; while (!(v & 1)) { v >>= 1; tz++; }
+            return tz;
+        }
         u64 lo, hi; memcpy(&lo, digest.b, 8); memcpy(&hi, digest.b + 8, 8);
         if (lo) return (u32)__builtin_ctzll(lo);
         if (hi) return 64 + (u32)__builtin_ctzll(hi);

@@ -28,6 +28,7 @@ struct Conventions {
     u32 merkle_node_hash = 0;   // 0: zero state + raw compressions (blake2_merkle.rs as published for this period); 1: RFC 7693 Blake2s-256 of the message
     u32 mix_u64 = 0;            // 0: raw compression of [lo, hi, 0..] on the digest words; 1: Blake2s-256(digest || LE64(n) zero padded to 32 bytes)
     u32 logup_mask_order = 0;   // 0: offsets [0, -1] on a component's last logUp column; 1: [-1, 0]
+    u32 merkle_channel = 0;     // protocol variant, not a convention: 0 Blake2sMerkleChannel (the reference), 1 Poseidon252MerkleChannel (BASELINE config 5)
 };
 static inline Conventions& conventions() { static Conventions c; return c; }
 

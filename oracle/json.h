@@ -16,7 +16,17 @@ struct JsonWriter {
     std::string s;
     void num(u64 v) { s += std::to_string(v); }
     void qm31(const QM31& q) { auto a = q.to_u32(); s += "[["; num(a[0]); s += ","; num(a[1]); s += "],["; num(a[2]); s += ","; num(a[3]); s += "]]"; }
-    void hash(const Hash32& h) { s += "["; for (int i = 0; i < 32; i++) { if (i) s += ","; num(h.b[i]); } s += "]"; }
+    // Blake2sHash: 32 byte values; FieldElement252 (Poseidon252 variant): "0x" + minimal lowercase hex of the canonical value
+    void hash(const Hash32& h) {
+        if (conventions().merkle_channel == 1) {
+            char buf[3]; std::string hex;
+            for (int i = 31; i >= 0; i--) { snprintf(buf, sizeof buf, "%02x", h.b[i]); hex += buf; }
+            size_t nz = hex.find_first_not_of('0');
+            s += "\"0x" + (nz == std::string::npos ? std::string("0") : hex.substr(nz)) + "\"";
+            return;
+        }
+        s += "["; for (int i = 0; i < 32; i++) { if (i) s += ","; num(h.b[i]); } s += "]";
+    }
     template <class T, class Fn> void arr(const std::vector<T>& v, Fn f) { s += "["; for (size_t i = 0; i < v.size(); i++) { if (i) s += ","; f(v[i]); } s += "]"; }
     void decommitment(const MerkleDecommitment& d) {
         s += "{\"hash_witness\":"; arr(d.hash_witness, [&](const Hash32& h) { hash(h); });
@@ -51,8 +61,9 @@ static inline std::string proof_to_json(const BrainfuckProof& bp) {
 
 // Minimal JSON value tree (numbers are unsigned integers; null supported).
 struct JVal {
-    enum Kind { NUM, ARR, OBJ, NUL } kind = NUL;
+    enum Kind { NUM, ARR, OBJ, NUL, STR } kind = NUL;
     u64 num = 0;
+    std::string str;
     std::vector<JVal> arr;
     std::vector<std::pair<std::string, JVal>> obj;
     const JVal& get(const char* k) const { for (auto& kv : obj) if (kv.first == k) return kv.second; throw std::runtime_error(std::string("missing key ") + k); }
@@ -78,7 +89,8 @@ struct JsonParser {
                 v.obj.push_back({k, parse()}); ws();
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }
-        } else if (*p == 'n') { if (end - p < 4) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
+        } else if (*p == '"') { p++; const char* s0 = p; while (p < end && *p != '"') p++; if (p >= end) throw std::runtime_error("json: string"); v.kind = JVal::STR; v.str.assign(s0, p); p++; }
+        else if (*p == 'n') { if (end - p < 4) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
         else if (*p >= '0' && *p <= '9') { v.kind = JVal::NUM; u64 x = 0; while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (u64)(*p - '0'); p++; } v.num = x; }
         else throw std::runtime_error("json: unexpected char");
         return v;
@@ -91,6 +103,18 @@ static inline QM31 j_qm31(const JVal& v) {
     return QM31::from_u32(j_m31(v.arr[0].arr[0]), j_m31(v.arr[0].arr[1]), j_m31(v.arr[1].arr[0]), j_m31(v.arr[1].arr[1]));
 }
 static inline Hash32 j_hash(const JVal& v) {
+    if (conventions().merkle_channel == 1) {
+        if (v.kind != JVal::STR || v.str.size() < 3 || v.str.size() > 66 || v.str.compare(0, 2, "0x") != 0) throw std::runtime_error("bad felt hash");
+        Hash32 h; memset(h.b, 0, 32);
+        for (size_t i = 0; i + 2 < v.str.size(); i++) {
+            char ch = v.str[v.str.size() - 1 - i]; int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1;
+            if (d < 0) throw std::runtime_error("bad felt hash digit");
+            h.b[i / 2] |= (u8)(d << (4 * (i & 1)));
+        }
+        u64 c[4]; memcpy(c, h.b, 32);
+        if (Felt::ge_p(c)) throw std::runtime_error("felt hash out of range");
+        return h;
+    }
     if (v.kind != JVal::ARR || v.arr.size() != 32) throw std::runtime_error("bad hash");
     Hash32 h; for (int i = 0; i < 32; i++) { if (v.arr[i].num > 255) throw std::runtime_error("bad hash byte"); h.b[i] = (u8)v.arr[i].num; } return h;
 }

@@ -16,6 +16,18 @@ namespace orc {
 
 // Blake2sMerkleHasher::hash_node
 static inline Hash32 hash_node(const Hash32* left, const Hash32* right, const u32* vals, size_t n_vals) {
+    if (conventions().merkle_channel == 1) {
+        // Poseidon252MerkleHasher::hash_node: values = [left, right]? ++ one felt per block of 8 column values (zero padded),
+        // word = word * 2^31 + x; poseidon_hash_many(values)
+        std::vector<Felt> values;
+        if (left) { values.push_back(Felt::from_le_bytes(left->b)); values.push_back(Felt::from_le_bytes(right->b)); }
+        for (size_t o = 0; o < n_vals; o += 8) {
+            Felt word = Felt::raw(0, 0, 0, 0);
+            for (size_t k = 0; k < 8; k++) word = fold_m31(word, o + k < n_vals ? vals[o + k] : 0u);
+            values.push_back(word);
+        }
+        Hash32 out; poseidon_hash_many(values).to_le_bytes(out.b); return out;
+    }
     if (conventions().merkle_node_hash == 0) {
         u32 st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[16];
         if (left) { memcpy(m, left->b, 32); memcpy(m + 8, right->b, 32); blake2s_compress(st, m, 0, 0, 0, 0); }

@@ -36,9 +36,23 @@ int orc_set_threads(int n) {
 }
 
 // Byte-level stwo conventions (field.h `Conventions`; same numbering as include/bfhip.h `bfhip_conventions`). Process-wide: set it before a call.
-int orc_set_conventions(u32 merkle_node_hash, u32 mix_u64, u32 logup_mask_order) {
-    if (merkle_node_hash > 1 || mix_u64 > 1 || logup_mask_order > 1) { g_err = "bad convention value"; return -1; }
+int orc_set_conventions(u32 merkle_node_hash, u32 mix_u64, u32 logup_mask_order, u32 merkle_channel) {
+    if (merkle_node_hash > 1 || mix_u64 > 1 || logup_mask_order > 1 || merkle_channel > 1) { g_err = "bad convention value"; return -1; }
     conventions().merkle_node_hash = merkle_node_hash; conventions().mix_u64 = mix_u64; conventions().logup_mask_order = logup_mask_order;
+    conventions().merkle_channel = merkle_channel;
+    return 0;
+}
+// Hades permutation of three canonical felt252 values (4 LE u64 limbs each) and poseidon_hash_many of n of them — pinned against
+// oracle/poseidon252.py (big-integer restatement with the public Hades known-answer vector) in tests/test_oracle_poseidon.py
+int orc_hades(const u64 in[12], u64 out[12]) {
+    Felt s[3]; for (int k = 0; k < 3; k++) s[k] = Felt::from_canonical(in + 4 * k);
+    hades_permutation(s);
+    for (int k = 0; k < 3; k++) s[k].to_canonical(out + 4 * k);
+    return 0;
+}
+int orc_poseidon_hash_many(const u64* in, size_t n, u64 out[4]) {
+    std::vector<Felt> v; for (size_t i = 0; i < n; i++) v.push_back(Felt::from_canonical(in + 4 * i));
+    poseidon_hash_many(v).to_canonical(out);
     return 0;
 }
 // Blake2sMerkleHasher::hash_node under the current convention (left/right may be NULL)

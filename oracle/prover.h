@@ -291,9 +291,9 @@ static inline std::vector<size_t> generate_queries(Channel& ch, u32 log_domain_s
     std::set<size_t> q;
     u32 cnt = 0; u32 mask = (u32)((u64(1) << log_domain_size) - 1);
     for (;;) {
-        Hash32 r = ch.draw_random_bytes();
-        for (int k = 0; k < 8; k++) {
-            u32 w; memcpy(&w, r.b + 4 * k, 4);
+        std::vector<u8> r = ch.draw_random_bytes();          // chunks_exact(4): 8 words per draw (Blake2s, 32 bytes), 7 (Poseidon252, 31 bytes)
+        for (size_t k = 0; 4 * k + 4 <= r.size(); k++) {
+            u32 w; memcpy(&w, r.data() + 4 * k, 4);
             q.insert(w & mask);
             if (++cnt == n_queries) return std::vector<size_t>(q.begin(), q.end());
         }

@@ -65,23 +65,25 @@ class LocalGroup:
 class Conventions(ctypes.Structure):
     """include/bfhip.h `bfhip_conventions`: the byte-level stwo conventions that cannot be confirmed offline, one switch each.
     All zero = the defaults (zero-state raw-compress Merkle nodes, raw-compress mix_u64, logUp mask order [0, -1])."""
-    _fields_ = [("merkle_node_hash", ctypes.c_uint32), ("mix_u64", ctypes.c_uint32), ("logup_mask_order", ctypes.c_uint32), ("reserved", ctypes.c_uint32 * 5)]
+    _fields_ = [("merkle_node_hash", ctypes.c_uint32), ("mix_u64", ctypes.c_uint32), ("logup_mask_order", ctypes.c_uint32), ("merkle_channel", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32 * 4)]
 
 
-_default_conventions = (0, 0, 0)
+_default_conventions = (0, 0, 0, 0)
 _live_contexts = weakref.WeakSet()
 
 
-def set_default_conventions(merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
+def set_default_conventions(merkle_node_hash=0, mix_u64=0, logup_mask_order=0, merkle_channel=0):
     """Process-wide default of the Python mirror: adopted by every Context created afterwards, applied to the live ones, and used by
     verify_brainfuck(conventions=None). The C ABI itself has no global state: conventions are per context / per verify call."""
     global _default_conventions
-    _default_conventions = (int(merkle_node_hash), int(mix_u64), int(logup_mask_order))
+    _default_conventions = (int(merkle_node_hash), int(mix_u64), int(logup_mask_order), int(merkle_channel))
     for c in list(_live_contexts):
         if c._h:
             c.set_conventions(*_default_conventions)
 
 
+CHANNEL_BLAKE2S, CHANNEL_POSEIDON252 = 0, 1
 MERKLE_STWO_COMPRESS, MERKLE_RFC7693 = 0, 1
 MIX_U64_COMPRESS, MIX_U64_HASH = 0, 1
 LOGUP_MASK_CUR_PREV, LOGUP_MASK_PREV_CUR = 0, 1
@@ -95,7 +97,7 @@ class Context:
         _check(lib().bfhip_ctx_create(device_id, max_log_domain, ctypes.byref(self._h)))
         self.max_log_domain = max_log_domain
         _live_contexts.add(self)
-        if _default_conventions != (0, 0, 0):
+        if _default_conventions != (0, 0, 0, 0):
             self.set_conventions(*_default_conventions)
 
     def close(self):
@@ -112,14 +114,14 @@ class Context:
     def sync(self):
         _check(lib().bfhip_ctx_sync(self._h))
 
-    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
-        cv = Conventions(merkle_node_hash, mix_u64, logup_mask_order)
+    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0, merkle_channel=0):
+        cv = Conventions(merkle_node_hash, mix_u64, logup_mask_order, merkle_channel)
         _check(lib().bfhip_ctx_set_conventions(self._h, ctypes.byref(cv)))
 
     def get_conventions(self):
         cv = Conventions()
         _check(lib().bfhip_ctx_get_conventions(self._h, ctypes.byref(cv)))
-        return cv.merkle_node_hash, cv.mix_u64, cv.logup_mask_order
+        return cv.merkle_node_hash, cv.mix_u64, cv.logup_mask_order, cv.merkle_channel
 
     def set_table_builder(self, on_gpu=True):
         """Where this context builds the 13 component tables: GPU kernels (default) or the host builders. Identical results."""

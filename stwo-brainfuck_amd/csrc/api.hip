@@ -174,8 +174,8 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
     API_CTX(ctx)
     Conventions cv;
     if (conv) {
-        if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1) throw HipError("unknown convention value");
-        cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order;
+        if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1 || conv->merkle_channel > 1) throw HipError("unknown convention value");
+        cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order; cv.merkle_channel = conv->merkle_channel;
     }
     ctx->c.sync();
     ctx->c.conv = cv;   // a kept preprocessed tree is keyed on the conventions it was hashed under (prover.hip: PreprocessedCache)
@@ -185,7 +185,7 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
 int32_t bfhip_ctx_get_conventions(bfhip_ctx* ctx, bfhip_conventions* out) {
     API_CTX(ctx)
     bfhip_conventions r{};
-    r.merkle_node_hash = ctx->c.conv.merkle_node_hash; r.mix_u64 = ctx->c.conv.mix_u64; r.logup_mask_order = ctx->c.conv.logup_mask_order;
+    r.merkle_node_hash = ctx->c.conv.merkle_node_hash; r.mix_u64 = ctx->c.conv.mix_u64; r.logup_mask_order = ctx->c.conv.logup_mask_order; r.merkle_channel = ctx->c.conv.merkle_channel;
     *out = r;
     return 0;
     API_CATCH

@@ -25,21 +25,35 @@ struct BrainfuckProof { u32 log_sizes[N_COMPONENTS]; Q31 claimed_sums[N_COMPONEN
 namespace json {
 inline void num(std::string& s, u64 v) { char buf[24]; int n = 0; if (!v) buf[n++] = '0'; while (v) { buf[n++] = (char)('0' + v % 10); v /= 10; } while (n) s.push_back(buf[--n]); }
 inline void qm31(std::string& s, const Q31& q) { s += "[["; num(s, q.a.a); s += ','; num(s, q.a.b); s += "],["; num(s, q.b.a); s += ','; num(s, q.b.b); s += "]]"; }
-inline void hash(std::string& s, const Hash32& h) { s += '['; for (int i = 0; i < 32; i++) { if (i) s += ','; num(s, h.b[i]); } s += ']'; }
+// Blake2sHash: array of 32 byte values. FieldElement252 (felt = true, Poseidon252MerkleHasher::Hash): "0x" + minimal lowercase hex, the
+// human-readable serde form of starknet-ff 0.3.7 (Cargo.lock:861); h holds the canonical value as 32 little-endian bytes.
+inline void hash(std::string& s, const Hash32& h, bool felt) {
+    if (felt) {
+        static const char* HEX = "0123456789abcdef";
+        s += "\"0x";
+        int top = 63; while (top > 0 && ((h.b[top / 2] >> (4 * (top & 1))) & 15) == 0) top--;
+        for (int i = top; i >= 0; i--) s.push_back(HEX[(h.b[i / 2] >> (4 * (i & 1))) & 15]);
+        s += '"';
+        return;
+    }
+    s += '['; for (int i = 0; i < 32; i++) { if (i) s += ','; num(s, h.b[i]); } s += ']';
+}
 template <class T, class Fn> void arr(std::string& s, const std::vector<T>& v, Fn f) { s += '['; for (size_t i = 0; i < v.size(); i++) { if (i) s += ','; f(v[i]); } s += ']'; }
-inline void decommitment(std::string& s, const MerkleDecommitment& d) {
-    s += "{\"hash_witness\":"; arr(s, d.hash_witness, [&](const Hash32& h) { hash(s, h); });
+inline void decommitment(std::string& s, const MerkleDecommitment& d, bool felt) {
+    s += "{\"hash_witness\":"; arr(s, d.hash_witness, [&](const Hash32& h) { hash(s, h, felt); });
     s += ",\"column_witness\":"; arr(s, d.column_witness, [&](u32 v) { num(s, v); }); s += '}';
 }
-inline void fri_layer(std::string& s, const FriLayerProof& l) {
+inline void fri_layer(std::string& s, const FriLayerProof& l, bool felt) {
     s += "{\"fri_witness\":"; arr(s, l.fri_witness, [&](const Q31& q) { qm31(s, q); });
-    s += ",\"decommitment\":"; decommitment(s, l.decommitment);
-    s += ",\"commitment\":"; hash(s, l.commitment); s += '}';
+    s += ",\"decommitment\":"; decommitment(s, l.decommitment, felt);
+    s += ",\"commitment\":"; hash(s, l.commitment, felt); s += '}';
 }
 }  // namespace json
 
-inline std::string proof_to_json(const BrainfuckProof& bp) {
+// felt_hashes: the proof was made with Poseidon252MerkleChannel (hashes are felt252 values)
+inline std::string proof_to_json(const BrainfuckProof& bp, bool felt_hashes = false) {
     using namespace json;
+    const bool felt = felt_hashes;
     std::string s;
     s.reserve(1 << 17);
     s += "{\"claim\":{";
@@ -47,14 +61,14 @@ inline std::string proof_to_json(const BrainfuckProof& bp) {
     s += "},\"interaction_claim\":{";
     for (int c = 0; c < N_COMPONENTS; c++) { if (c) s += ','; s += '"'; s += COMPONENT_NAMES[c]; s += "\":{\"claimed_sum\":"; qm31(s, bp.claimed_sums[c]); s += '}'; }
     const StarkProof& p = bp.proof;
-    s += "},\"proof\":{\"commitments\":"; arr(s, p.commitments, [&](const Hash32& h) { hash(s, h); });
+    s += "},\"proof\":{\"commitments\":"; arr(s, p.commitments, [&](const Hash32& h) { hash(s, h, felt); });
     s += ",\"sampled_values\":";
     arr(s, p.sampled_values, [&](const std::vector<std::vector<Q31>>& t) { arr(s, t, [&](const std::vector<Q31>& c) { arr(s, c, [&](const Q31& q) { qm31(s, q); }); }); });
-    s += ",\"decommitments\":"; arr(s, p.decommitments, [&](const MerkleDecommitment& d) { decommitment(s, d); });
+    s += ",\"decommitments\":"; arr(s, p.decommitments, [&](const MerkleDecommitment& d) { decommitment(s, d, felt); });
     s += ",\"queried_values\":"; arr(s, p.queried_values, [&](const std::vector<u32>& v) { arr(s, v, [&](u32 x) { num(s, x); }); });
     s += ",\"proof_of_work\":"; num(s, p.proof_of_work);
-    s += ",\"fri_proof\":{\"first_layer\":"; fri_layer(s, p.fri_proof.first_layer);
-    s += ",\"inner_layers\":"; arr(s, p.fri_proof.inner_layers, [&](const FriLayerProof& l) { fri_layer(s, l); });
+    s += ",\"fri_proof\":{\"first_layer\":"; fri_layer(s, p.fri_proof.first_layer, felt);
+    s += ",\"inner_layers\":"; arr(s, p.fri_proof.inner_layers, [&](const FriLayerProof& l) { fri_layer(s, l, felt); });
     s += ",\"last_layer_poly\":{\"coeffs\":"; arr(s, p.fri_proof.last_layer_coeffs, [&](const Q31& q) { qm31(s, q); });
     s += ",\"log_size\":"; num(s, p.fri_proof.last_layer_log_size); s += "}}}}";
     return s;

@@ -16,8 +16,9 @@ namespace bf {
 
 // ---- minimal JSON reader (unsigned integers, arrays, objects, null) ------------------------------------------------------------------
 struct JVal {
-    enum Kind { NUM, ARR, OBJ, NUL } kind = NUL;
+    enum Kind { NUM, ARR, OBJ, NUL, STR } kind = NUL;
     u64 num = 0;
+    std::string str;
     std::vector<JVal> arr;
     std::vector<std::pair<std::string, JVal>> obj;
     const JVal& get(const char* k) const { for (auto& kv : obj) if (kv.first == k) return kv.second; throw std::runtime_error(std::string("missing key ") + k); }
@@ -44,6 +45,10 @@ struct JsonReader {
                 v.obj.push_back({k, parse(depth + 1)}); ws();
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }
+        } else if (*p == '"') {   // strings occur only as felt252 hashes ("0x..." hex), never with escapes
+            p++; const char* s0 = p; while (p < end && *p != '"' && *p != '\\') p++;
+            if (p >= end || *p != '"') throw std::runtime_error("json: string");
+            v.kind = JVal::STR; v.str.assign(s0, p); p++;
         } else if (*p == 'n') { if (end - p < 4 || memcmp(p, "null", 4) != 0) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
         else if (*p >= '0' && *p <= '9') {
             // canonical unsigned integers only, as serde_json emits and accepts for u32/u64 fields: no leading zeros, no wrap-around
@@ -66,24 +71,38 @@ inline Q31 jv_qm31(const JVal& v) {
     if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
     return q_make(jv_m31(v.arr[0].arr[0]), jv_m31(v.arr[0].arr[1]), jv_m31(v.arr[1].arr[0]), jv_m31(v.arr[1].arr[1]));
 }
-inline Hash32 jv_hash(const JVal& v) {
+inline Hash32 jv_hash(const JVal& v, bool felt) {
+    if (felt != (v.kind == JVal::STR)) throw std::runtime_error("hash form does not match the Merkle channel");
+    if (v.kind == JVal::STR) {   // Poseidon252MerkleHasher::Hash = FieldElement252, serialised by starknet-ff as "0x" + minimal lowercase hex
+        const std::string& t = v.str;
+        if (t.size() < 3 || t.size() > 66 || t[0] != '0' || t[1] != 'x' || (t.size() > 3 && t[2] == '0')) throw std::runtime_error("bad felt252 hash");
+        Hash32 h; memset(h.b, 0, 32);
+        size_t nd = t.size() - 2;
+        for (size_t i = 0; i < nd; i++) {
+            char ch = t[t.size() - 1 - i]; int d = ch >= '0' && ch <= '9' ? ch - '0' : ch >= 'a' && ch <= 'f' ? ch - 'a' + 10 : -1;
+            if (d < 0) throw std::runtime_error("bad felt252 hash digit");
+            h.b[i / 2] |= (u8)(d << (4 * (i & 1)));
+        }
+        if (!fe252::canonical_bytes_in_range(h.b)) throw std::runtime_error("felt252 hash out of range");
+        return h;
+    }
     if (v.kind != JVal::ARR || v.arr.size() != 32) throw std::runtime_error("bad hash");
     Hash32 h; for (int i = 0; i < 32; i++) { if (v.arr[i].kind != JVal::NUM || v.arr[i].num > 255) throw std::runtime_error("bad hash byte"); h.b[i] = (u8)v.arr[i].num; } return h;
 }
-inline MerkleDecommitment jv_decommitment(const JVal& v) {
+inline MerkleDecommitment jv_decommitment(const JVal& v, bool felt) {
     MerkleDecommitment d;
-    for (auto& h : v.get("hash_witness").arr) d.hash_witness.push_back(jv_hash(h));
+    for (auto& h : v.get("hash_witness").arr) d.hash_witness.push_back(jv_hash(h, felt));
     for (auto& x : v.get("column_witness").arr) d.column_witness.push_back(jv_m31(x));
     return d;
 }
-inline FriLayerProof jv_fri_layer(const JVal& v) {
+inline FriLayerProof jv_fri_layer(const JVal& v, bool felt) {
     FriLayerProof l;
     for (auto& q : v.get("fri_witness").arr) l.fri_witness.push_back(jv_qm31(q));
-    l.decommitment = jv_decommitment(v.get("decommitment"));
-    l.commitment = jv_hash(v.get("commitment"));
+    l.decommitment = jv_decommitment(v.get("decommitment"), felt);
+    l.commitment = jv_hash(v.get("commitment"), felt);
     return l;
 }
-inline BrainfuckProof proof_from_json(const char* s, size_t len) {
+inline BrainfuckProof proof_from_json(const char* s, size_t len, bool felt = false) {
     JsonReader jr{s, s + len};
     JVal root = jr.parse();
     jr.ws();
@@ -97,19 +116,19 @@ inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     }
     const JVal& p = root.get("proof");
     StarkProof& sp = bp.proof;
-    for (auto& h : p.get("commitments").arr) sp.commitments.push_back(jv_hash(h));
+    for (auto& h : p.get("commitments").arr) sp.commitments.push_back(jv_hash(h, felt));
     for (auto& t : p.get("sampled_values").arr) {
         std::vector<std::vector<Q31>> tv;
         for (auto& c : t.arr) { std::vector<Q31> cv; for (auto& q : c.arr) cv.push_back(jv_qm31(q)); tv.push_back(cv); }
         sp.sampled_values.push_back(tv);
     }
-    for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(jv_decommitment(d));
+    for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(jv_decommitment(d, felt));
     for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(jv_m31(x)); sp.queried_values.push_back(v); }
     if (p.get("proof_of_work").kind != JVal::NUM) throw std::runtime_error("bad proof_of_work");
     sp.proof_of_work = p.get("proof_of_work").num;
     const JVal& f = p.get("fri_proof");
-    sp.fri_proof.first_layer = jv_fri_layer(f.get("first_layer"));
-    for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(jv_fri_layer(l));
+    sp.fri_proof.first_layer = jv_fri_layer(f.get("first_layer"), felt);
+    for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(jv_fri_layer(l, felt));
     for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(jv_qm31(q));
     { const JVal& ll = f.get("last_layer_poly").get("log_size"); if (ll.kind != JVal::NUM || ll.num > 31) throw std::runtime_error("bad last layer log_size"); sp.fri_proof.last_layer_log_size = (u32)ll.num; }
     return bp;
@@ -120,7 +139,7 @@ struct VerifierConfig { u32 pow_bits = 5, log_blowup = 1, log_last_layer_degree_
 
 // MerkleVerifier::verify — "" on success, else the error name
 inline std::string merkle_verify(const Hash32& root, const std::vector<u32>& column_log_sizes, const std::map<u32, std::vector<size_t>>& queries_per_log,
-                                 const std::vector<u32>& queried_values, const MerkleDecommitment& d, u32 node_conv) {
+                                 const std::vector<u32>& queried_values, const MerkleDecommitment& d, const Conventions& node_conv) {
     if (column_log_sizes.empty()) return "";
     std::map<u32, size_t> ncols_at;
     u32 max_log = 0;
@@ -314,12 +333,15 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
         std::vector<size_t> queries;
         {
             std::set<size_t> qs; u32 cnt = 0; u32 maskq = (u32)((u64(1) << max_log) - 1);
-            while (cnt < cfg.n_queries) { Hash32 r = ch.draw_random_bytes(); for (int k = 0; k < 8 && cnt < cfg.n_queries; k++) { u32 w; memcpy(&w, r.b + 4 * k, 4); qs.insert(w & maskq); cnt++; } }
+            while (cnt < cfg.n_queries) {   // Queries::generate: chunks_exact(4) of the drawn bytes (32 per draw for Blake2s, 31 for Poseidon252)
+                std::vector<u8> r = ch.draw_random_bytes();
+                for (size_t k = 0; 4 * k + 4 <= r.size() && cnt < cfg.n_queries; k++) { u32 w; memcpy(&w, r.data() + 4 * k, 4); qs.insert(w & maskq); cnt++; }
+            }
             queries.assign(qs.begin(), qs.end());
         }
         std::map<u32, std::vector<size_t>> positions_by_log;
         for (u32 l : dom_logs) positions_by_log[l] = v_fold_queries(queries, max_log - l);
-        for (int t = 0; t < 4; t++) { std::string e = merkle_verify(pf.commitments[t], col_logs[t], positions_by_log, pf.queried_values[t], pf.decommitments[t], cv.merkle_node_hash); if (!e.empty()) return "MerkleVerification tree " + std::to_string(t) + ": " + e; }
+        for (int t = 0; t < 4; t++) { std::string e = merkle_verify(pf.commitments[t], col_logs[t], positions_by_log, pf.queried_values[t], pf.decommitments[t], cv); if (!e.empty()) return "MerkleVerification tree " + std::to_string(t) + ": " + e; }
         // fri_answers: per LDE size (descending), the quotient value at every query position
         struct Flat { int t; size_t c; u32 log; };
         std::vector<Flat> flat;
@@ -394,7 +416,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
                 for (int c = 0; c < 4; c++) mlogs.push_back(dom_logs[k]);
             }
             if (wi != fp.first_layer.fri_witness.size()) return "FirstLayerEvaluationsInvalid";
-            std::string e = merkle_verify(fp.first_layer.commitment, mlogs, dpos, dvals, fp.first_layer.decommitment, cv.merkle_node_hash);
+            std::string e = merkle_verify(fp.first_layer.commitment, mlogs, dpos, dvals, fp.first_layer.decommitment, cv);
             if (!e.empty()) return "FirstLayerCommitmentInvalid: " + e;
         }
         auto lq = v_fold_queries(queries, 1);
@@ -416,7 +438,7 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
             size_t wi = 0; std::vector<size_t> pos; Sparse sps;
             if (!rebuild(lq, lev, lp.fri_witness, wi, pos, sps) || wi != lp.fri_witness.size()) return "InnerLayerEvaluationsInvalid";
             std::map<u32, std::vector<size_t>> dpos; dpos[line_log] = pos;
-            std::string e = merkle_verify(lp.commitment, std::vector<u32>(4, line_log), dpos, words_of(sps), lp.decommitment, cv.merkle_node_hash);
+            std::string e = merkle_verify(lp.commitment, std::vector<u32>(4, line_log), dpos, words_of(sps), lp.decommitment, cv);
             if (!e.empty()) return "InnerLayerCommitmentInvalid: " + e;
             std::vector<Q31> nev;
             for (size_t s = 0; s < sps.evals.size(); s++) {

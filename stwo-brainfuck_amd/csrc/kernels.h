@@ -77,7 +77,8 @@ void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy);
 
 // poseidon.hip — Poseidon252 Merkle variant (BASELINE config 5; not used by the reference)
-void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log);
+void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, u32 out_shift = 0, u32 prev_shift = 0,
+                           u32 first = 0, u32 count = 0);
 void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24);
 
 // air.hip

@@ -27,6 +27,8 @@ struct Conventions {
     u32 merkle_node_hash = 0;   // 0 BFHIP_MERKLE_STWO_COMPRESS: zero state, raw compress(state, block, 0,0,0,0) per 64-byte block; 1 BFHIP_MERKLE_RFC7693
     u32 mix_u64 = 0;            // 0 BFHIP_MIX_U64_COMPRESS: raw compression on the digest words; 1 BFHIP_MIX_U64_HASH: Blake2s(digest || pad32(LE64 n))
     u32 logup_mask_order = 0;   // 0 BFHIP_LOGUP_MASK_CUR_PREV: offsets [0, -1] on a component's last logUp column; 1 BFHIP_LOGUP_MASK_PREV_CUR: [-1, 0]
+    // Not a convention but a protocol variant carried in the same struct: which MerkleChannel the proof uses.
+    u32 merkle_channel = 0;     // 0 BFHIP_CHANNEL_BLAKE2S: Blake2sMerkleChannel (the reference, mod.rs:56,486-487); 1 BFHIP_CHANNEL_POSEIDON252
 };
 
 BF_HD u32 m_add(u32 a, u32 b) { u32 s = a + b; u32 t = s - P31; return t < s ? t : s; }           // min(s, s-P) with wraparound

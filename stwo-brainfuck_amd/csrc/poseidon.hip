@@ -112,16 +112,22 @@ struct Sponge {
 };
 
 // consts layout in device memory: P[8], R1[8], R2[8], ARK[273][8]
-__global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__ out, const u32* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n,
-                                                              const u32* __restrict__ consts) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// Replication-aware and range-aware like k_merkle_layer (merkle.hip): node i is stored at slot i >> out_shift, its children at
+// (2i) >> prev_shift and (2i + 1) >> prev_shift; [first, first + n_stored) is the range of stored slots this launch computes (the whole
+// layer, or one rank's share of it in a shard group).
+__global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__ out, const u32* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
+                                                              u32 out_shift, u32 prev_shift, u32 first, const u32* __restrict__ consts) {
+    u32 st = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st >= n_stored) return;
+    st += first;
+    const u32 i = st << out_shift;          // representative node of this stored slot
     const u32* P = consts; const u32* R1 = consts + 8; const u32* R2p = consts + 16; const u32* ark = consts + 24;
     Fe R2 = fe_load_const(R2p);
     Sponge sp; sp.init(ark, P, R1);
     if (prev) {
+        const size_t cl = ((size_t)2 * i) >> prev_shift, cr = ((size_t)2 * i + 1) >> prev_shift;
         Fe l, r;
-        for (int k = 0; k < 8; k++) { l.l[k] = prev[(size_t)16 * i + k]; r.l[k] = prev[(size_t)16 * i + 8 + k]; }
+        for (int k = 0; k < 8; k++) { l.l[k] = prev[8 * cl + k]; r.l[k] = prev[8 * cr + k]; }
         sp.absorb(fe_mul(l, R2, P));        // canonical -> Montgomery
         sp.absorb(fe_mul(r, R2, P));
     }
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__
         for (u32 k = 0; k < 8; k++) {
             u32 c = c0 + k;
             u32 v = 0;
-            if (c < ncols) { ColDesc cd = cols[c]; v = cd.ptr[i >> cd.shift]; }
+            if (c < ncols) { ColDesc cd = cols[c]; v = ld_col(cd, i); }
             u32 sh = 31 * (7 - k), limb = sh >> 5, off = sh & 31;
             w.l[limb] |= v << off;
             if (off > 1 && limb + 1 < 8) w.l[limb + 1] |= v >> (32 - off);
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__
     Fe h = sp.finish();
     Fe one_plain; for (int k = 0; k < 8; k++) one_plain.l[k] = k == 0 ? 1u : 0u;
     h = fe_mul(h, one_plain, P);            // Montgomery -> canonical
-    for (int k = 0; k < 8; k++) out[(size_t)8 * i + k] = h.l[k];
+    for (int k = 0; k < 8; k++) out[(size_t)8 * st + k] = h.l[k];
 }
 
 // Test hook: one Hades permutation of 3 canonical field elements (24 words in, 24 words out).
@@ -174,11 +180,15 @@ static const u32* poseidon_consts() {
     return g_poseidon_consts[dev];
 }
 
-void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log) {
-    u32 n = 1u << log;
+void merkle_layer_poseidon(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, u32 out_shift, u32 prev_shift, u32 first, u32 count) {
+    const u32 total = (1u << log) >> out_shift;
+    const u32 n = count ? count : total;
     u32 threads = n < 128 ? (n < 64 ? 64 : n) : 128;
-    ProfScope ps(stream, "k_merkle_layer_poseidon", 0);
-    hipLaunchKernelGGL(k_merkle_layer_poseidon, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (u32*)out, (const u32*)prev, d_cols, ncols, n, poseidon_consts());
+    // Hades permutations per node: poseidon_hash_many over (2 children +) ceil(ncols / 8) blocks = floor(elements / 2) + 1
+    const u32 elems = (prev ? 2u : 0u) + (ncols + 7) / 8;
+    ProfScope ps(stream, "k_merkle_layer_poseidon", ((prev ? 64.0 : 0.0) + 32.0 + 4.0 * ncols) * n, (double)(elems / 2 + 1) * n, /*dominant=*/true);
+    hipLaunchKernelGGL(k_merkle_layer_poseidon, dim3((n + threads - 1) / threads), dim3(threads), 0, stream, (u32*)out, (const u32*)prev, d_cols, ncols, n, out_shift, prev_shift,
+                       count ? first : 0u, poseidon_consts());
 }
 void hades_once(hipStream_t stream, const u32* d_in24, u32* d_out24) {
     hipLaunchKernelGGL(k_hades_once, dim3(1), dim3(64), 0, stream, d_in24, d_out24, poseidon_consts());

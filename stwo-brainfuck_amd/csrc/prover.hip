@@ -170,9 +170,11 @@ struct HipProver {
                 mk.layers[log] = (u32*)c.arena.alloc((size_t(32) << log) >> mk.shifts[log]);
             }
         }
+        const bool poseidon = c.conv.merkle_channel == 1;   // Poseidon252MerkleHasher: layer kernel of poseidon.hip, no fused top, host channel
+        if (poseidon && step) throw HipError("the device-side channel step is a Blake2s path");
         u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
         while (fused_top > 0 && mk.shifts[fused_top] != 0) fused_top--;   // the fused kernel expects un-replicated layers
-        if (mk.shifts[fused_top] != 0) fused_top = 0;
+        if (mk.shifts[fused_top] != 0 || poseidon) fused_top = 0;
         StageBatch sb(c);
         const ColDesc* d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
         void* const* dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
@@ -193,8 +195,12 @@ struct HipProver {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? (1u << (log - sg.log_count)) : 0u;
-            merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
-                         mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, c.conv.merkle_node_hash, sg.rank * per_rank, per_rank);
+            if (poseidon)
+                merkle_layer_poseidon(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log,
+                                      mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
+            else
+                merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
+                             mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, c.conv.merkle_node_hash, sg.rank * per_rank, per_rank);
             if (share && log == mk.band_lo) {
                 // the smallest share-wise layer is completed on every rank by one all-gather on the device buffer (rank r's block = its
                 // contiguous node range); the levels below are hashed redundantly, so every rank obtains the same root
@@ -850,8 +856,21 @@ struct HipProver {
         memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
         BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
         u32 cur_alpha = 0;
-        ChannelStep step0{d_chan, d_alpha, d_roots};
-        DevMerkle first_tree = merkle_commit(first_cols, nullptr, /*no_readback=*/true, &step0);
+        // Poseidon252Channel is stepped on the host (one root read-back per layer): two serial Hades permutations by a single lane would
+        // cost more than the round trip. commit_step = Merkle tree of a layer + mix_root + draw alpha (alpha || alpha^2 -> d_alpha[idx]).
+        const bool host_channel = c.conv.merkle_channel == 1;
+        auto commit_step = [&](const std::vector<DCol>& cols, u32 alpha_idx, u32 root_idx) -> DevMerkle {
+            if (!host_channel) { ChannelStep st{d_chan, d_alpha + 8 * alpha_idx, d_roots + 8 * root_idx}; return merkle_commit(cols, nullptr, /*no_readback=*/true, &st); }
+            DevMerkle t = merkle_commit(cols);
+            ch.mix_root(t.root);
+            const Q31 a = ch.draw_felt(), sq = q_mul(a, a);
+            const u32 w[8] = {a.a.a, a.a.b, a.b.a, a.b.b, sq.a.a, sq.a.b, sq.b.a, sq.b.b};
+            c.stage_checkpoint();
+            const u32* st = c.stage(w, 8);
+            BF_HIP(hipMemcpyAsync(d_alpha + 8 * alpha_idx, st, 32, hipMemcpyDeviceToDevice, c.stream));
+            return t;
+        };
+        DevMerkle first_tree = commit_step(first_cols, 0, 0);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
@@ -888,8 +907,7 @@ struct HipProver {
             }
             Inner in; in.ev = layer;
             cur_alpha++;
-            ChannelStep step{d_chan, d_alpha + 8 * cur_alpha, d_roots + 8 * (1 + inner.size())};
-            in.tree = merkle_commit(secure_cols(layer), nullptr, /*no_readback=*/true, &step);
+            in.tree = commit_step(secure_cols(layer), cur_alpha, (u32)(1 + inner.size()));
             DSecure next = new_layer(line_log - 1);
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
             u32 first, count; fold_range(line_log, layer.lc != 0, first, count);
@@ -901,17 +919,21 @@ struct HipProver {
         if (layer_partial) for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, layer.c[w], sizeof(u32) << (line_log - lc()));
         if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
         BF_HIP(hipGetLastError());
-        BF_HIP(hipMemcpyAsync(pinned_chan, d_chan, 36, hipMemcpyDeviceToHost, c.stream));
-        BF_HIP(hipMemcpyAsync(pinned_roots, d_roots, 32 * (1 + inner.size()), hipMemcpyDeviceToHost, c.stream));
+        if (!host_channel) {
+            BF_HIP(hipMemcpyAsync(pinned_chan, d_chan, 36, hipMemcpyDeviceToHost, c.stream));
+            BF_HIP(hipMemcpyAsync(pinned_roots, d_roots, 32 * (1 + inner.size()), hipMemcpyDeviceToHost, c.stream));
+        }
         // last layer: 2^last_log evaluations -> line polynomial (host; LineEvaluation::interpolate on <= 2 values for the default config)
         {
             if (last_log != 1 || cfg.log_last_layer_degree_bound != 0) throw HipError("only the default FRI last-layer configuration is supported");
             std::vector<size_t> pos = {0, 1};
             auto v = gather_secure(layer, pos);          // synchronises: roots and the device channel state are on the host now
-            first_tree.root = pinned_roots[0];
-            ch.mix_root(first_tree.root); (void)ch.draw_felt();
-            for (size_t li = 0; li < inner.size(); li++) { inner[li].tree.root = pinned_roots[1 + li]; ch.mix_root(inner[li].tree.root); (void)ch.draw_felt(); }
-            if (memcmp(pinned_chan, ch.digest.b, 32) != 0 || pinned_chan[8] != ch.n_sent) throw HipError("FRI: device channel diverged from the host channel");
+            if (!host_channel) {
+                first_tree.root = pinned_roots[0];
+                ch.mix_root(first_tree.root); (void)ch.draw_felt();
+                for (size_t li = 0; li < inner.size(); li++) { inner[li].tree.root = pinned_roots[1 + li]; ch.mix_root(inner[li].tree.root); (void)ch.draw_felt(); }
+                if (memcmp(pinned_chan, ch.digest.b, 32) != 0 || pinned_chan[8] != ch.n_sent) throw HipError("FRI: device channel diverged from the host channel");
+            }
             // line_ifft on 2 values over LineDomain(half_odds(1)): c0 = (v0 + v1) / 2, c1 = (v0 - v1) / (2 x0) must vanish
             u32 inv2 = m_inv(2);
             Q31 c0 = q_mulm(q_add(v[0], v[1]), inv2);
@@ -922,8 +944,14 @@ struct HipProver {
         }
         tap("fri_commit");
 
-        // proof of work (GrindOps): GPU search in spans, smallest nonce wins
-        {
+        // proof of work (GrindOps): GPU search in spans, smallest nonce wins. Poseidon252Channel: one Hades permutation per nonce and a
+        // 1-in-16 hit rate at pow_bits = 5 (the test reads the top byte of the big-endian digest) — searched on the host.
+        if (host_channel) {
+            u64 nonce = 0;
+            for (;; nonce++) { Channel t = ch; t.mix_u64(nonce); if (t.trailing_zeros() >= cfg.pow_bits) break; if (nonce > (u64(1) << 32)) throw HipError("grind: no nonce found"); }
+            pf.proof_of_work = nonce;
+            ch.mix_u64(nonce);
+        } else {
             c.stage_checkpoint();
             u32* d_digest = (u32*)c.stage(ch.digest.b, 32);
             unsigned long long init = ~0ull;
@@ -944,9 +972,9 @@ struct HipProver {
         std::vector<size_t> queries;
         {
             std::set<size_t> qs; u32 cnt = 0; u32 maskq = (u32)((u64(1) << max_log) - 1);
-            while (cnt < cfg.n_queries) {
-                Hash32 r = ch.draw_random_bytes();
-                for (int k = 0; k < 8 && cnt < cfg.n_queries; k++) { u32 w; memcpy(&w, r.b + 4 * k, 4); qs.insert(w & maskq); cnt++; }
+            while (cnt < cfg.n_queries) {   // Queries::generate: chunks_exact(4) of the drawn bytes (32 per draw for Blake2s, 31 for Poseidon252)
+                std::vector<u8> r = ch.draw_random_bytes();
+                for (size_t k = 0; 4 * k + 4 <= r.size() && cnt < cfg.n_queries; k++) { u32 w; memcpy(&w, r.data() + 4 * k, 4); qs.insert(w & maskq); cnt++; }
             }
             queries.assign(qs.begin(), qs.end());
         }
@@ -1017,7 +1045,7 @@ extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint
 
 static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
     if (proof_json) {
-        std::string js = proof_to_json(bp);
+        std::string js = proof_to_json(bp, pv.c.conv.merkle_channel == 1);
         *proof_json = (char*)malloc(js.size() + 1);
         memcpy(*proof_json, js.c_str(), js.size() + 1);
         if (proof_len) *proof_len = js.size();
@@ -1125,11 +1153,11 @@ extern "C" int32_t bfhip_verify_brainfuck_conv(const char* proof_json, size_t pr
     try {
         Conventions cv;
         if (conv) {
-            if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1) { bfhip_set_error("unknown convention value"); return -1; }
-            cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order;
+            if (conv->merkle_node_hash > 1 || conv->mix_u64 > 1 || conv->logup_mask_order > 1 || conv->merkle_channel > 1) { bfhip_set_error("unknown convention value"); return -1; }
+            cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order; cv.merkle_channel = conv->merkle_channel;
         }
         std::string reason;
-        try { BrainfuckProof bp = proof_from_json(proof_json, proof_len); reason = verify_brainfuck(bp, log_max_rows, cv); }
+        try { BrainfuckProof bp = proof_from_json(proof_json, proof_len, cv.merkle_channel == 1); reason = verify_brainfuck(bp, log_max_rows, cv); }
         catch (const std::exception& e) { reason = std::string("InvalidStructure: ") + e.what(); }
         if (err && err_cap) snprintf(err, err_cap, "%s", reason.c_str());
         return reason.empty() ? 0 : 1;

@@ -14,6 +14,7 @@ P = (1 << 31) - 1
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "single_conv: run under the default stwo conventions only (not parametrised over CONVENTIONS)")
+    config.addinivalue_line("markers", "with_poseidon: also run under the Poseidon252MerkleChannel variant")
 
 
 # Byte-level stwo conventions (include/bfhip.h `bfhip_conventions`: merkle_node_hash, mix_u64, logup_mask_order). Every test that uses the
@@ -21,13 +22,16 @@ def pytest_configure(config):
 #   stwo    = defaults (zero-state raw-compress Merkle nodes, raw-compress mix_u64, mask order [0, -1])
 #   rfc7693 = only the Merkle node hash flipped to the RFC 7693 form (round 1's behaviour; tests/golden has the fib19 digest of both)
 #   flipped = every switch on its alternative value
-CONVENTIONS = {"stwo": (0, 0, 0), "rfc7693": (1, 0, 0), "flipped": (1, 1, 1)}
+#   poseidon = the Poseidon252MerkleChannel variant (BASELINE config 5; 4th field merkle_channel = 1), other switches at their defaults
+CONVENTIONS = {"stwo": (0, 0, 0, 0), "rfc7693": (1, 0, 0, 0), "flipped": (1, 1, 1, 0), "poseidon": (0, 0, 0, 1)}
 
 
 def pytest_generate_tests(metafunc):
     if "conv" in metafunc.fixturenames:
         single = metafunc.definition.get_closest_marker("single_conv") is not None
-        metafunc.parametrize("conv", ["stwo"] if single else list(CONVENTIONS), indirect=True, scope="function")
+        # the Poseidon252 variant hashes ~30x slower (GPU) and its CPU oracle far slower still: only tests marked `with_poseidon` run under it
+        names = [n for n in CONVENTIONS if n != "poseidon" or metafunc.definition.get_closest_marker("with_poseidon") is not None]
+        metafunc.parametrize("conv", ["stwo"] if single else names, indirect=True, scope="function")
 
 
 def load_package():
@@ -61,8 +65,8 @@ class Oracle:
             raise RuntimeError(self.L.orc_last_error().decode())
         return rc
 
-    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0):
-        self._chk(self.L.orc_set_conventions(merkle_node_hash, mix_u64, logup_mask_order))
+    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0, merkle_channel=0):
+        self._chk(self.L.orc_set_conventions(merkle_node_hash, mix_u64, logup_mask_order, merkle_channel))
 
     def hash_node(self, left, right, values):
         """Blake2sMerkleHasher::hash_node under the current convention. left/right: 32-byte strings or None; values: u32 list."""
@@ -181,8 +185,8 @@ def conv(request, _oracle, pkg):
     _oracle.set_conventions(*values)
     pkg.set_default_conventions(*values)
     yield values
-    _oracle.set_conventions(0, 0, 0)
-    pkg.set_default_conventions(0, 0, 0)
+    _oracle.set_conventions(0, 0, 0, 0)
+    pkg.set_default_conventions(0, 0, 0, 0)
 
 
 @pytest.fixture

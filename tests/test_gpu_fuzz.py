@@ -25,3 +25,17 @@ def test_random_program_proof_matches_oracle(ctx, pkg, oracle, seed, max_steps):
             assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows) == want
         finally:
             ctx.set_table_builder(True)
+
+
+@pytest.mark.with_poseidon
+@pytest.mark.parametrize("seed", [401, 402, 403, 404, 405, 406])
+def test_random_program_proof_matches_oracle_all_variants(ctx, pkg, oracle, seed):
+    """A few seeds under every convention set including the Poseidon252MerkleChannel variant (whose CPU oracle is slow)."""
+    code, inp, _ = random_program(seed, 300, min_steps=15)
+    log_max_rows = max(max(oracle.log_sizes(code, inp)[0]), 8)
+    want, otr, _ = oracle.prove(code, inp, log_max_rows=log_max_rows)
+    got, tr = pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows, with_transcript=True)
+    diverged = next((k for k in otr if otr[k] != tr.get(k)), None)
+    assert diverged is None, f"{code!r}: transcript diverges at {diverged}"
+    assert got == want, code
+    assert pkg.verify_brainfuck(got, log_max_rows) == (True, "")

@@ -149,6 +149,7 @@ EDGE = [
 ]
 
 
+@pytest.mark.with_poseidon
 @pytest.mark.parametrize("code,inp", EDGE, ids=[e[0] for e in EDGE])
 def test_edge_programs_match_oracle(pkg, oracle, code, inp, small_ctx):
     got = pkg.prove_brainfuck(code, inp, ctx=small_ctx, log_max_rows=12)
@@ -164,6 +165,7 @@ def small_ctx(pkg):
     c.close()
 
 
+@pytest.mark.with_poseidon
 @pytest.mark.parametrize("code,inp", [("+", b""), (",", b"\x05"), ("+[-]", b""), ("++>+<[->+<]", b"")], ids=["+", ",", "+[-]", "move"])
 def test_smallest_log_max_rows(pkg, oracle, code, inp):
     """LOG_MAX_ROWS exactly the largest component (6..9 here): the smallest preprocessed tree, transforms of 2^5..2^11 cells only,
@@ -270,3 +272,32 @@ def test_reuse_preprocessed_survives_a_convention_change(pkg, oracle):
 def test_log_max_rows_below_lanes_is_an_error(pkg, ctx):
     with pytest.raises(pkg.BfhipError, match="LOG_N_LANES"):
         pkg.prove_brainfuck("+", b"", ctx=ctx, log_max_rows=3)
+
+
+def test_poseidon252_variant_on_a_2_to_22_row_trace(pkg, _oracle):
+    """BASELINE config 5 family (Poseidon252MerkleChannel) at a size no CPU prover reaches in test time: a synthetic nested-counter trace
+    whose Memory component has 2^22 domain rows, LOG_MAX_ROWS 22. Both verifiers must accept, tampering must be rejected, and the same
+    trace under the Blake2s channel gives a different (Blake2s) proof."""
+    code = "+" * 14 + "[>" + "+" * 1000 + "[>+<-]<-]"
+    pkg.set_default_conventions(0, 0, 0, 1)
+    _oracle.set_conventions(0, 0, 0, 1)
+    try:
+        c = pkg.Context(0, max_log_domain=24)
+        try:
+            tr = pkg.Trace(c, code, b"")
+            assert max(tr.log_sizes) == 22
+            proof, _ = tr.prove(22)
+            assert proof == tr.prove(22)[0]
+            assert b'"commitments":["0x' in proof
+            assert pkg.verify_brainfuck(proof, 22) == (True, "")
+            ok, err = _oracle.verify(proof, 22)
+            assert ok, err
+            bad = proof.replace(b'"proof_of_work":', b'"proof_of_work":1', 1)
+            assert not pkg.verify_brainfuck(bad, 22)[0] and not _oracle.verify(bad, 22)[0]
+            assert not pkg.verify_brainfuck(proof, 22, conventions=(0, 0, 0, 0))[0]      # a Blake2s verifier rejects the felt252 hashes
+            tr.close()
+        finally:
+            c.close()
+    finally:
+        pkg.set_default_conventions(0, 0, 0, 0)
+        _oracle.set_conventions(0, 0, 0, 0)

@@ -42,6 +42,7 @@ def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False):
     return proofs
 
 
+@pytest.mark.with_poseidon
 @pytest.mark.parametrize("count", [2, 4, 8])
 @pytest.mark.parametrize("name,inp,lmr", [("hello_kakarot.bf", b"", 17), ("collatz.bf", b"7\n", 21)])
 def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, lmr, count):

@@ -4,6 +4,8 @@ import re
 
 import pytest
 
+pytestmark = pytest.mark.with_poseidon     # also under the Poseidon252MerkleChannel variant (BASELINE config 5)
+
 
 _PROOF = {}
 

@@ -6,6 +6,8 @@ import re
 
 import pytest
 
+pytestmark = pytest.mark.with_poseidon     # also under the Poseidon252MerkleChannel variant (BASELINE config 5)
+
 import numpy as np
 
 from conftest import ROOT, P, splitmix_column
@@ -48,12 +50,15 @@ def test_proof_is_deterministic(oracle):
     assert a == b
 
 
-def test_proof_json_shape(proofs):
+def test_proof_json_shape(proofs, conv):
     p = json.loads(proofs[0][0])
     assert list(p.keys()) == ["claim", "interaction_claim", "proof"]                       # BrainfuckProof (mod.rs:71-76)
     assert list(p["claim"].keys())[:4] == ["memory", "instruction", "program", "processor"]   # BrainfuckClaim order (mod.rs:85-99)
     assert p["claim"]["memory"] == {"log_size": p["claim"]["memory"]["log_size"], "_marker": None}
-    assert len(p["proof"]["commitments"]) == 4 and all(len(c) == 32 for c in p["proof"]["commitments"])
+    if conv[3] == 1:      # Poseidon252MerkleHasher::Hash = FieldElement252: "0x" + minimal lowercase hex (starknet-ff's human-readable serde form)
+        assert len(p["proof"]["commitments"]) == 4 and all(re.fullmatch(r"0x(0|[1-9a-f][0-9a-f]{0,62})", c) and int(c, 16) < 2**251 + 17 * 2**192 + 1 for c in p["proof"]["commitments"])
+    else:
+        assert len(p["proof"]["commitments"]) == 4 and all(len(c) == 32 for c in p["proof"]["commitments"])
     assert [len(t) for t in p["proof"]["sampled_values"]][1:] == [128, 60, 4]               # 128 main, 60 interaction, 4 composition columns
     # the last logUp column of each component is sampled at two points (offsets 0 and -1), all other columns at one
     n_two = sum(1 for c in p["proof"]["sampled_values"][2] if len(c) == 2)
