@@ -190,7 +190,8 @@ struct HipProver {
             // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
             for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
-        prof_run_begin(c.stream, "k_merkle_layer");
+        const char* layer_kernel = poseidon ? "k_merkle_layer_poseidon" : "k_merkle_layer";
+        prof_run_begin(c.stream, layer_kernel);
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
@@ -206,7 +207,7 @@ struct HipProver {
                 // contiguous node range); the levels below are hashed redundantly, so every rank obtains the same root
                 prof_run_end(c.stream);
                 sg.comm->all_gather(c.stream, mk.layers[log], (size_t(32) << log) >> sg.log_count);
-                prof_run_begin(c.stream, "k_merkle_layer");
+                prof_run_begin(c.stream, layer_kernel);
             }
         }
         prof_run_end(c.stream);

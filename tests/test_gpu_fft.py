@@ -57,3 +57,44 @@ def test_replicated_column_matches_full_transform(ctx, oracle, log):
     want_lde = oracle.evaluate(want_coeffs[None, :], log, log + 1)[0]
     assert np.array_equal(np.repeat(got_lde, 16), want_lde)
     ctx.free(p); ctx.free(q)
+
+
+@pytest.mark.single_conv
+@pytest.mark.parametrize("log,ncols", [(22, 2), (24, 1)])
+def test_fft_matches_oracle_at_proof_sizes(pkg, _oracle, log, ncols):
+    """Op-level parity at the sizes of the benchmark proof (2^22, and one column at 2^24 -> LDE 2^25): bit-exact vs the oracle's CPU
+    transform (seconds per column), not only through the proof digest."""
+    c = pkg.Context(0, max_log_domain=log + 1)
+    try:
+        _roundtrip(c, _oracle, log, ncols, seed=log * 16 + 1)
+    finally:
+        c.close()
+
+
+@pytest.mark.single_conv
+def test_three_strided_pass_plan_identity_and_linearity(pkg):
+    """A context with max_log_domain 29 and one column of 2^27 cells: the plan with three strided passes (only reached above 2^26) —
+    evaluate(interpolate(f)) == f on the same domain, and interpolate is linear: interpolate(f + g) == interpolate(f) + interpolate(g)."""
+    log = 27
+    c = pkg.Context(0, max_log_domain=29)
+    try:
+        f = splitmix_column(0x5EED0001, 1 << log); g = splitmix_column(0x5EED0002, 1 << log)
+        fg = ((f.astype(np.uint64) + g) % P).astype(np.uint32)
+        pf, pg, pfg = c.upload(f), c.upload(g), c.upload(fg)
+        q = c.malloc(4 << log)
+        c.interpolate([pf], [q], log)
+        c.evaluate([q], [q], log, log)
+        assert np.array_equal(c.download(q, 1 << log), f)
+        c.interpolate([pf, pg, pfg], [pf, pg, pfg], log)
+        cf, cg, cfg_ = c.download(pf, 1 << log), c.download(pg, 1 << log), c.download(pfg, 1 << log)
+        assert np.array_equal(((cf.astype(np.uint64) + cg) % P).astype(np.uint32), cfg_)
+        # LDE to 2^28 and back: the low half of interpolate(evaluate_2N(coeffs)) are the coefficients, the high half is zero
+        lde = c.malloc(4 << (log + 1))
+        c.evaluate([pf], [lde], log, log + 1)
+        c.interpolate([lde], [lde], log + 1)
+        back = c.download(lde, 1 << (log + 1))
+        assert np.array_equal(back[: 1 << log], cf) and not back[1 << log:].any()
+        for p_ in (pf, pg, pfg, q, lde):
+            c.free(p_)
+    finally:
+        c.close()

@@ -301,3 +301,19 @@ def test_poseidon252_variant_on_a_2_to_22_row_trace(pkg, _oracle):
     finally:
         pkg.set_default_conventions(0, 0, 0, 0)
         _oracle.set_conventions(0, 0, 0, 0)
+
+
+def test_bfprove_tool_prove_then_verify(tmp_path):
+    """tools/bfprove.py: the prove / verify sub-commands of the reference's bin/brainfuck_prover.rs over the C ABI, proof file in between."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "proof.json"
+    inp = tmp_path / "in.bin"; inp.write_bytes(b"\x01")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bfprove.py"), "prove", "--code", "+++>,<[>+.<-]", "--input-file", str(inp), "--output", str(out),
+                        "--log-max-rows", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bfprove.py"), "verify", str(out), "--log-max-rows", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Proof verified" in r.stdout, r.stdout + r.stderr
+    out.write_bytes(out.read_bytes().replace(b'"proof_of_work":', b'"proof_of_work":1', 1))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bfprove.py"), "verify", str(out), "--log-max-rows", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1
