@@ -9,6 +9,10 @@
 //! ```
 #[path = "bfhip_sys.rs"]
 pub mod sys;
+/// stwo's backend trait surface (`Backend`, `ColumnOps`, `FieldOps`, `PolyOps`, `MerkleOps`, `QuotientOps`, `FriOps`, `AccumulationOps`, `GrindOps`,
+/// `ComponentProver`) over the FFI — for `prover::prove::<HipBackend, _>` at `mod.rs:732`.
+#[path = "hip_backend.rs"]
+pub mod hip_backend;
 
 use std::ffi::{c_char, c_void, CStr, CString};
 

@@ -100,3 +100,26 @@ def test_rust_ffi_is_in_step_with_the_header():
     declared = set(re.findall(r"\b(bfhip_\w+)\s*\(", header))
     in_rust = set(re.findall(r"pub fn (bfhip_\w+)\(", committed))
     assert declared == in_rust, declared ^ in_rust
+
+
+def test_hip_backend_covers_the_trait_surface():
+    """bindings/rust/hip_backend.rs (source only: no Rust toolchain in the image) implements every stwo backend trait the reference's
+    generic parameter needs, every method INTEGRATION.md section 2 maps, and only calls FFI functions that
+    bfhip_sys.rs declares."""
+    import re
+    src = open(os.path.join(ROOT, "bindings", "rust", "hip_backend.rs")).read()
+    for tr in ["Backend for HipBackend", "BackendForChannel<Blake2sMerkleChannel> for HipBackend", "ColumnOps<BaseField> for HipBackend", "ColumnOps<SecureField> for HipBackend",
+               "ColumnOps<Blake2sHash> for HipBackend", "FieldOps<BaseField> for HipBackend", "FieldOps<SecureField> for HipBackend", "PolyOps for HipBackend",
+               "MerkleOps<Blake2sMerkleHasher> for HipBackend", "QuotientOps for HipBackend", "FriOps for HipBackend", "AccumulationOps for HipBackend",
+               "GrindOps<Blake2sChannel> for HipBackend", "GkrOps for HipBackend", "ComponentProver<HipBackend> for FrameworkComponent<E>"]:
+        assert f"impl {tr}" in src or f"impl<E: BrainfuckEval> {tr}" in src, f"missing impl {tr}"
+    for method in ["bit_reverse_column", "batch_inverse", "precompute_twiddles", "interpolate_columns", "evaluate_polynomials", "eval_at_point", "extend", "commit_on_layer",
+                   "accumulate_quotients", "fold_line", "fold_circle_into_line", "accumulate", "generate_secure_powers", "grind", "evaluate_constraint_quotients_on_domain",
+                   "zeros", "to_cpu", "from_iter"]:
+        assert re.search(rf"fn {method}\b", src), f"missing method {method}"
+    declared = set(re.findall(r"pub fn (bfhip_\w+)\(", open(os.path.join(ROOT, "bindings", "rust", "bfhip_sys.rs")).read()))
+    used = set(re.findall(r"sys::(bfhip_\w+)", src))
+    assert used and used <= declared, used - declared
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for entry in used:
+        assert entry in integration, f"{entry} is used by hip_backend.rs but not mapped in INTEGRATION.md"
