@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the 2^20..2^26 synthetic sweep (N=1 only; ~15 s)")
     ap.add_argument("--sweep-steps", type=int, default=3)
     ap.add_argument("--sweep-logs", default="20,21,22,23,24,25,26")
-    ap.add_argument("--conventions", default="0,0,0", help="merkle_node_hash,mix_u64,logup_mask_order (include/bfhip.h bfhip_conventions); default = stwo defaults")
+    ap.add_argument("--conventions", default="0,0,0,0", help="merkle_node_hash,mix_u64,logup_mask_order,merkle_channel (include/bfhip.h bfhip_conventions); default = stwo defaults, Blake2s channel")
     ap.add_argument("--reuse-preprocessed", action="store_true", help="NOT the headline: keep the program-independent preprocessed tree across proofs (a deployment option; the reference recommits it per proof)")
     ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + HIP stream each); >1 reports pipelined throughput, no roofline")
     ap.add_argument("--shard", action="store_true", help="NOT the default: with --gpus N > 1 the N ranks prove ONE trace together (strong scaling of a single proof) "
@@ -199,7 +199,7 @@ def main():
     pkg = load_package()
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    conv = tuple(int(v) for v in args.conventions.split(","))
+    conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
     pkg.set_default_conventions(*conv)
     device = pick_device(local_rank, pkg.device_count(), args.device)
     ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)   # one process per GPU: rank r drives device LOCAL_RANK

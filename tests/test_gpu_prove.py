@@ -102,7 +102,7 @@ def test_fib19_full_size_proof_verifies(pkg, oracle, conv):
         import hashlib, json
         digests = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))
         want = next((d for d in digests.values() if tuple(d["conventions"]) == tuple(conv)), None)
-        assert want is not None or tuple(conv) == (1, 1, 1), "no committed digest for the default conventions"
+        assert want is not None or tuple(conv) == (1, 1, 1, 0), "no committed digest for the default conventions"
         if want is not None:
             assert len(proof) == want["proof_bytes"] and hashlib.sha256(proof).hexdigest() == want["sha256"]
         tr.close()
