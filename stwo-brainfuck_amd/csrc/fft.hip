@@ -332,7 +332,10 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
 }
 
 template <bool INV>
-__global__ void __launch_bounds__(128, 3) k_fft_strided7(PassArgs a) {
+#ifndef BF_STRIDED7_WAVES
+#define BF_STRIDED7_WAVES 3
+#endif
+__global__ void __launch_bounds__(128, BF_STRIDED7_WAVES) k_fft_strided7(PassArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_val[4096];
     __shared__ u32 s_tw[128];
     const u32 t = threadIdx.x, lo = a.lo, tile = blockIdx.x;
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(128, 3) k_fft_strided7(PassArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 u32 m = 8 * e + mlow;
-                if (to_global) dst[base | (m << lo) | l] = (INV && a.scale != 1) ? m_mul(v[e], a.scale) : v[e];
+                if (to_global) __builtin_nontemporal_store((INV && a.scale != 1) ? m_mul(v[e], a.scale) : v[e], dst + (base | (m << lo) | l));   // streamed: +2 %
                 else s_val[32 * m + l] = v[e];
             }
         };
