@@ -157,6 +157,83 @@ def run_sweep(pkg, device, steps, logs):
     return out
 
 
+def shard_probe(args):
+    """Child-process mode (--shard-probe): this rank joins the other ranks' probe children in ONE shard group (RCCL on the library's own
+    stream; the 128-byte unique id travels through a file) and times a few proofs of the bench workload proved by all GPUs together.
+    No torch, no torch.distributed: the parent keeps its process group for the contract's timing protocol. Writes one JSON object."""
+    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    out = {"n_gpus": world, "rank": rank}
+    try:
+        pkg = load_package()
+        conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
+        pkg.set_default_conventions(*conv)
+        device = pick_device(local_rank, pkg.device_count(), args.device)
+        ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)
+        trace = pkg.Trace(ctx, FIB19, b"")
+        idf = args.probe_id_file
+        if rank == 0:
+            with open(idf + ".tmp", "wb") as f:
+                f.write(pkg.rccl_unique_id())
+            os.replace(idf + ".tmp", idf)
+        t0 = time.time()
+        while not os.path.exists(idf):
+            if time.time() - t0 > 60:
+                raise RuntimeError("unique id file did not appear")
+            time.sleep(0.02)
+        uid = open(idf, "rb").read()
+        ctx.join_rccl_group(uid, rank, world)
+        for _ in range(2):
+            proof, _ = trace.prove(args.log_max_rows)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.probe_steps):
+            proof, phases = trace.prove(args.log_max_rows)
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / args.probe_steps
+        want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == args.log_max_rows), None)
+        stats = ctx.group_stats()
+        out.update({"ms_per_proof": round(dt * 1e3, 3), "cells_per_s": trace.cells / dt, "steps": args.probe_steps,
+                    "parity_checked": bool(want is not None and hashlib.sha256(proof).hexdigest() == want["sha256"]),
+                    "transport": ctx.group_info()[2], "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
+                    "per_proof": {k: round(v / (args.probe_steps + 2), 1) for k, v in stats.items()}})
+        ctx.leave_group(); trace.close(); ctx.close()
+    except Exception as e:
+        out["error"] = repr(e)
+    with open(args.probe_out + ".tmp", "w") as f:
+        json.dump(out, f)
+    os.replace(args.probe_out + ".tmp", args.probe_out)
+    return 0
+
+
+def run_shard_probe(args, rank, world):
+    """Parent side, BEFORE this process touches the GPU (a child must not be exec'd from a process that has initialised it): every rank
+    starts its probe child, waits for it (bounded) and kills exactly that PID on timeout. Returns rank 0's result (or an error record)."""
+    import subprocess
+    import tempfile
+    base = os.path.join(tempfile.gettempdir(), f"bfhip_probe_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
+    out_path = f"{base}_rank{rank}.json"
+    for path in (out_path, f"{base}.id") if rank == 0 else (out_path,):
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--probe-out", out_path, "--probe-id-file", f"{base}.id", "--probe-steps", str(args.probe_steps),
+           "--log-max-rows", str(args.log_max_rows), "--conventions", args.conventions]
+    if args.device is not None:
+        cmd += ["--device", str(args.device)]
+    child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        child.wait(timeout=args.probe_timeout)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.wait()
+        return {"n_gpus": world, "error": f"probe child did not finish within {args.probe_timeout} s (killed)"}
+    try:
+        return json.load(open(out_path))
+    except Exception as e:
+        return {"n_gpus": world, "error": f"probe child left no result (exit code {child.returncode}): {e!r}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,12 +256,30 @@ def main():
                     "instead of N independent replicas")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
+    ap.add_argument("--no-shard-probe", action="store_true", help="N > 1, replicas mode: skip the extra strong-scaling measurement (one proof over all N GPUs) taken in child "
+                    "processes before the timed replicas run")
+    ap.add_argument("--probe-steps", type=int, default=8)
+    ap.add_argument("--probe-timeout", type=int, default=180)
+    ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-out", help=argparse.SUPPRESS)
+    ap.add_argument("--probe-id-file", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.shard_probe:
+        return shard_probe(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    # N > 1, replicas mode: besides the contract's weak-scaling number, measure ONE proof over all N GPUs (shard group, strong scaling) in
+    # child processes first — bounded, killed on timeout, never allowed to cost the main line.
+    shard_probe_result = None
+    if world > 1 and not args.shard and not args.no_shard_probe and world & (world - 1) == 0:
+        try:
+            shard_probe_result = run_shard_probe(args, rank, world)
+        except Exception as e:
+            shard_probe_result = {"n_gpus": world, "error": repr(e)}
 
     import torch
     dist = None
@@ -353,6 +448,9 @@ def main():
             "fft": fft,
             "sweep": sweep,
         }
+        if shard_probe_result is not None:
+            # strong scaling beside the weak-scaling value: the same workload proved ONCE by all N GPUs together
+            out["shard_group"] = shard_probe_result
         if world == 1 and not args.no_cpu_baseline:
             full = args.cpu_baseline == "full"
             if args.cpu_baseline == "auto":

@@ -84,7 +84,7 @@ int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx**
 }
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
 // ---- shard groups: one proof over several GPUs (comm.h) ------------------------------------------------------------------------------
-struct bfhip_local_group { LocalGroup* g; uint32_t count; };
+struct bfhip_local_group { std::shared_ptr<LocalGroup> g; uint32_t count; };
 static void join_group(bfhip_ctx* ctx, std::unique_ptr<Comm> comm) {
     u32 count = comm->count, lc = 0;
     while ((1u << lc) < count) lc++;
@@ -103,7 +103,7 @@ int32_t bfhip_local_group_create(uint32_t count, bfhip_local_group** out) {
     return 0;
     API_CATCH
 }
-int32_t bfhip_local_group_destroy(bfhip_local_group* g) { if (g) { local_group_destroy(g->g); delete g; } return 0; }
+int32_t bfhip_local_group_destroy(bfhip_local_group* g) { delete g; return 0; }   // members that have not left yet keep the rendezvous alive
 int32_t bfhip_ctx_join_local_group(bfhip_ctx* ctx, bfhip_local_group* group, uint32_t rank) {
     API_CTX(ctx)
     if (!group) throw HipError("null group");

@@ -31,11 +31,10 @@ struct Comm {
     virtual const char* transport() const = 0;
 };
 
-// LocalComm rendezvous object shared by the N contexts of one process.
+// LocalComm rendezvous object shared by the N contexts of one process (reference counted: it lives until the last member has left).
 struct LocalGroup;
-LocalGroup* local_group_create(u32 count);
-void local_group_destroy(LocalGroup* g);
-std::unique_ptr<Comm> local_comm_join(LocalGroup* g, u32 rank);
+std::shared_ptr<LocalGroup> local_group_create(u32 count);
+std::unique_ptr<Comm> local_comm_join(const std::shared_ptr<LocalGroup>& g, u32 rank);
 
 // RCCL: rank 0 creates the 128-byte unique id, the host program distributes it (control plane), every rank joins.
 void rccl_unique_id(unsigned char id[128]);

@@ -27,8 +27,7 @@ struct LocalGroup {
             throw HipError("shard group: a rank did not reach the rendezvous (another rank failed or diverged)");
     }
 };
-LocalGroup* local_group_create(u32 count) { return new LocalGroup(count); }
-void local_group_destroy(LocalGroup* g) { delete g; }
+std::shared_ptr<LocalGroup> local_group_create(u32 count) { return std::make_shared<LocalGroup>(count); }
 
 __global__ void k_max_u32_n(u32* __restrict__ out, const u32* const* __restrict__ bufs, u32 nbufs, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,10 +38,10 @@ __global__ void k_max_u32_n(u32* __restrict__ out, const u32* const* __restrict_
 }
 
 struct LocalComm : Comm {
-    LocalGroup* g;
+    std::shared_ptr<LocalGroup> g;
     u32* scratch = nullptr; size_t scratch_words = 0;
     const u32** d_ptrs = nullptr;
-    LocalComm(LocalGroup* g_, u32 r) : g(g_) {
+    LocalComm(const std::shared_ptr<LocalGroup>& g_, u32 r) : g(g_) {
         rank = r; count = g_->count;
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].done, hipEventDisableTiming));
@@ -100,7 +99,7 @@ struct LocalComm : Comm {
         finish(s);
     }
 };
-std::unique_ptr<Comm> local_comm_join(LocalGroup* g, u32 rank) {
+std::unique_ptr<Comm> local_comm_join(const std::shared_ptr<LocalGroup>& g, u32 rank) {
     if (!g || rank >= g->count) throw HipError("shard group: bad rank");
     return std::unique_ptr<Comm>(new LocalComm(g, rank));
 }
