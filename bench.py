@@ -259,7 +259,7 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true", help="N > 1, replicas mode: skip the extra strong-scaling measurement (one proof over all N GPUs) taken in child "
                     "processes before the timed replicas run")
     ap.add_argument("--probe-steps", type=int, default=8)
-    ap.add_argument("--probe-timeout", type=int, default=180)
+    ap.add_argument("--probe-timeout", type=int, default=120)
     ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-out", help=argparse.SUPPRESS)
     ap.add_argument("--probe-id-file", help=argparse.SUPPRESS)

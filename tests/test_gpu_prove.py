@@ -317,3 +317,29 @@ def test_bfprove_tool_prove_then_verify(tmp_path):
     out.write_bytes(out.read_bytes().replace(b'"proof_of_work":', b'"proof_of_work":1', 1))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "bfprove.py"), "verify", str(out), "--log-max-rows", "16"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys; the timed proof is checked against the committed digest (parity_checked),
+    the roofline is the VALU one with a measured compression count, and the sweep points verify."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "sample", "--sweep-logs", "20,22", "--sweep-steps", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert d["parity_checked"] is True and d["parity"]["own_verifier_accepts"] is True
+    assert abs(d["value"] - d["config"]["cells_per_proof"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["kernel"] == "k_merkle_layer" and rf["bound"] == "valu" and 0.5 < rf["frac"] < 1.0 and rf["compressions_per_proof"] == 674228124
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["hbm"]["peak"] == 8000.0
+    assert d["fft"]["algorithmic_GBps"] > 0 and any(k.startswith("k_fft_strided7") for k in d["fft"]["kernels"])
+    assert [p["log_domain_rows"] for p in d["sweep"]] == [20, 22] and all(p["verified"] for p in d["sweep"])
+    assert d["config"]["headline_2^22"]["cells_per_s"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
