@@ -183,10 +183,13 @@ struct HipProver {
         // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
         const ShardGroup& sg = c.shard;
         if (sg.count > 1) {
-            int hi = -1;
-            for (int log = (int)mk.max_log; log >= 0; log--) if (mk.shifts[log] == 0) { hi = log; break; }
+            // Share-wise layers: every layer with at least 256 STORED nodes per rank, replicated ones included (rank r takes the slots
+            // [r * stored / count, (r + 1) * stored / count); a slot's children are slots of the same rank in the layer below, whether
+            // that layer is stored at the same replication or one step finer). log - shift is non-decreasing in log, so these layers
+            // form one band [band_lo, max_log]; the band's lowest layer is completed on every rank by one all-gather.
             int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
-            if (hi >= lo) { mk.band_hi = hi; mk.band_lo = lo; }
+            while (lo <= (int)mk.max_log && (int)lo - (int)mk.shifts[lo] < (int)sg.log_count + 8) lo++;
+            if (lo <= (int)mk.max_log) { mk.band_hi = (int)mk.max_log; mk.band_lo = lo; }
             // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
             for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
@@ -195,7 +198,7 @@ struct HipProver {
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
             size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
-            const u32 per_rank = share ? (1u << (log - sg.log_count)) : 0u;
+            const u32 per_rank = share ? ((1u << (log - mk.shifts[log])) >> sg.log_count) : 0u;   // in stored slots
             if (poseidon)
                 merkle_layer_poseidon(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log,
                                       mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
@@ -206,7 +209,7 @@ struct HipProver {
                 // the smallest share-wise layer is completed on every rank by one all-gather on the device buffer (rank r's block = its
                 // contiguous node range); the levels below are hashed redundantly, so every rank obtains the same root
                 prof_run_end(c.stream);
-                sg.comm->all_gather(c.stream, mk.layers[log], (size_t(32) << log) >> sg.log_count);
+                sg.comm->all_gather(c.stream, mk.layers[log], ((size_t(32) << log) >> mk.shifts[log]) >> sg.log_count);
                 prof_run_begin(c.stream, layer_kernel);
             }
         }
