@@ -189,7 +189,9 @@ struct HipProver {
             // form one band [band_lo, max_log]; the band's lowest layer is completed on every rank by one all-gather.
             int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
             while (lo <= (int)mk.max_log && (int)lo - (int)mk.shifts[lo] < (int)sg.log_count + 8) lo++;
-            if (lo <= (int)mk.max_log) { mk.band_hi = (int)mk.max_log; mk.band_lo = lo; }
+            // a tree with fewer than 2^14 stored leaves per rank is hashed whole by every rank: cheaper than the latency of its all-gather
+            const bool worth = (int)mk.max_log - (int)mk.shifts[mk.max_log] >= (int)sg.log_count + (int)SLICE_MIN_LOG_PER_RANK;
+            if (worth && lo <= (int)mk.max_log) { mk.band_hi = (int)mk.max_log; mk.band_lo = lo; }
             // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
             for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
@@ -283,11 +285,12 @@ struct HipProver {
     }
 
     // ---- shard group (one proof over several GPUs): which columns are cut into row ranges ---------------------------------------------
-    // A full-size column of the interaction / composition trees, a quotient column or an FRI layer with at least 2^12 rows per rank is
+    // A full-size column of the preprocessed / interaction / composition trees, a quotient column or an FRI layer with at least 2^14 rows per rank is
     // ROW-sharded: rank r holds rows [r * 2^(log - lc), (r + 1) * 2^(log - lc)) — a contiguous range of a bit-reversed circle domain, i.e.
     // a sub-coset, so Merkle subtrees, offset-0 masks, quotient rows and FRI sibling pairs are all local. Smaller columns, the 16x-replicated
     // (row-granular) columns and the preprocessed / main trees stay complete on every rank.
-    static constexpr u32 SLICE_MIN_LOG_PER_RANK = 12;
+    // 2^14 rows per rank: below that a transform, a fold or a subtree costs less than the latency of the exchange that would divide it
+    static constexpr u32 SLICE_MIN_LOG_PER_RANK = 14;
     bool sharded() const { return c.shard.count > 1; }
     u32 lc() const { return c.shard.log_count; }
     bool slice_log(u32 log) const { return sharded() && log >= lc() + SLICE_MIN_LOG_PER_RANK; }
@@ -878,7 +881,7 @@ struct HipProver {
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
-        // Shard group: a layer with >= 2^12 rows per rank is row-sharded like the quotients (a fold maps the sibling pair (2i, 2i+1) to cell
+        // Shard group: a layer with >= 2^14 rows per rank is row-sharded like the quotients (a fold maps the sibling pair (2i, 2i+1) to cell
         // i, so a rank's row range of the source folds into its row range of the destination). The first layer below that size is produced
         // range-wise into a complete buffer and finished by one all-gather; everything smaller is folded redundantly on every rank.
         auto new_layer = [&](u32 log) {
