@@ -58,11 +58,13 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
         assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
 
 
-def test_fib19_full_size_in_a_shard_group_of_two(pkg):
-    """The benchmark workload: both ranks reproduce the committed digest of the oracle's proof."""
+@pytest.mark.parametrize("count", [2, 8])
+def test_fib19_full_size_in_a_shard_group(pkg, count):
+    """The benchmark workload (BASELINE config 4: the 2^24-row trace over 8 ranks): every rank reproduces the committed digest of the
+    oracle's proof."""
     import hashlib, json
     code = open(os.path.join(PROGS, "fib19.bf")).read()
-    proofs = _prove_sharded(pkg, code, b"", 24, 2)
+    proofs = _prove_sharded(pkg, code, b"", 24, count)
     want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fib19_lmr24_oracle_proof.json")))["stwo"]
     for p in proofs:
         assert hashlib.sha256(p).hexdigest() == want["sha256"]

@@ -9,9 +9,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_package
 
 FIB19 = open(os.path.join(ROOT, "tests", "golden", "programs", "fib19.bf")).read()
+# optional: SHARD_LOCAL_POSEIDON=1 proves with the Poseidon252MerkleChannel variant, SHARD_LOCAL_LOG=k uses the synthetic 2^k-row trace of
+# bench.py's sweep with LOG_MAX_ROWS = k (BASELINE config 5 family) instead of fib19
+POSEIDON = os.environ.get("SHARD_LOCAL_POSEIDON") == "1"
+SYN_LOG = int(os.environ.get("SHARD_LOCAL_LOG", "0"))
 
 
 def run(pkg, n, steps, lmr=24):
+    global FIB19
+    if SYN_LOG:
+        lmr = SYN_LOG
+        FIB19 = "+" * 14 + "[>" + "+" * (250 << (SYN_LOG - 20)) + "[>+<-]<-]"
+    pkg.set_default_conventions(0, 0, 0, 1 if POSEIDON else 0)
     group = pkg.LocalGroup(n) if n > 1 else None
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(n)]
     traces = [pkg.Trace(c, FIB19, b"") for c in ctxs]
@@ -66,7 +75,8 @@ def main():
         n = row["ranks_on_one_gpu"]
         s = (row["ms_per_proof"] - t1) / (n - 1)          # T(N) = N S + P, T(1) = S + P
         row["replicated_ms_S"] = round(s, 2); row["divided_ms_P"] = round(t1 - s, 2); row["projected_ms_with_one_gpu_per_rank"] = round(s + (t1 - s) / n, 2)
-    print(json.dumps(out, indent=1))
+    print(json.dumps({"workload": (f"synthetic 2^{SYN_LOG}-row trace" if SYN_LOG else "fib19.bf") + (", Poseidon252MerkleChannel" if POSEIDON else ", Blake2sMerkleChannel"),
+                      "runs": out}, indent=1))
 
 
 if __name__ == "__main__":
