@@ -186,3 +186,161 @@ def test_channel_primitives(oracle, conv):
         want = hashlib.blake2s(before + struct.pack("<Q", nonce) + bytes(24)).digest()
     assert bytes(d) == want
     oracle.L.orc_channel_free(ch)
+
+
+# ---- the circle-FFT conventions restated from their DEFINITION in pure Python --------------------------------------
+# Independent of the oracle's and the product's code: circle group law on the generator (2, 1268011823), CanonicCoset(n) = odds(n) with
+# circle_domain() = half_odds(n - 1) followed by its conjugates, evaluations stored bit-reversed, monomial basis y^b0 x^b1 pi(x)^b2 ...
+# with pi(x) = 2 x^2 - 1. O(n^2) evaluation by the definition, small sizes only.
+def _cadd(p, q):
+    return ((p[0] * q[0] - p[1] * q[1]) % P, (p[0] * q[1] + p[1] * q[0]) % P)
+
+
+def _cpow(g, e):
+    r, b = (1, 0), g
+    while e:
+        if e & 1:
+            r = _cadd(r, b)
+        b = _cadd(b, b)
+        e >>= 1
+    return r
+
+
+_GEN = (2, 1268011823)        # M31_CIRCLE_GEN, order 2^31
+
+
+def _domain_point(log, i):
+    """CanonicCoset(log).circle_domain().at(i): half_coset = Coset(initial = subgroup_gen(log + 1), step = subgroup_gen(log - 1), log - 1);
+    at(i) = half_coset.at(i) for i < 2^(log-1), else the conjugate of half_coset.at(i - 2^(log-1)). subgroup_gen(k) = G^(2^(31-k))."""
+    half = 1 << (log - 1)
+    j = i if i < half else i - half
+    idx = ((1 << (31 - (log + 1))) + j * (1 << (31 - (log - 1)))) % (1 << 31)
+    x, y = _cpow(_GEN, idx)
+    return (x, y) if i < half else (x, (P - y) % P)
+
+
+def _basis(log, j, pt):
+    """j-th basis function of a circle polynomial of 2^log coefficients at pt: bit 0 of j selects y, bit k >= 1 selects pi^(k-1)(x)."""
+    x, y = pt
+    r = y if j & 1 else 1
+    f = x
+    for k in range(1, log):
+        if (j >> k) & 1:
+            r = r * f % P
+        f = (2 * f * f - 1) % P
+    return r
+
+
+@pytest.mark.parametrize("log", [3, 4, 6])
+def test_fft_conventions_match_the_definition(oracle, log):
+    n = 1 << log
+    assert (_cpow(_GEN, 1 << 30), _cpow(_GEN, 1 << 31)) == ((P - 1, 0), (1, 0))       # the generator has order 2^31
+    for i in (0, 1, n // 2, n - 1):                                                   # the oracle's domain points are the defined ones
+        xy = (ctypes.c_uint32 * 2)()
+        oracle.L.orc_domain_point(log, i, xy)
+        assert (xy[0], xy[1]) == _domain_point(log, i)
+    coeffs = splitmix_column(4242 + log, n)
+    br = lambda i: int(format(i, f"0{log}b")[::-1], 2)
+    want = np.zeros(n, dtype=np.uint32)
+    for i in range(n):                                                                # stored index bit_reverse(i) holds f(domain.at(i))
+        pt = _domain_point(log, i)
+        want[br(i)] = sum(int(coeffs[j]) * _basis(log, j, pt) for j in range(n)) % P
+    assert np.array_equal(oracle.evaluate(coeffs[None, :], log, log)[0], want)        # evaluate = the definition
+    assert np.array_equal(oracle.interpolate(want[None, :], log)[0], coeffs)          # interpolate = its inverse
+    # LDE: the same polynomial (coefficients zero-extended) on the canonic domain of twice the size
+    lde_want = np.zeros(2 * n, dtype=np.uint32)
+    brl = lambda i: int(format(i, f"0{log + 1}b")[::-1], 2)
+    for i in range(2 * n):
+        pt = _domain_point(log + 1, i)
+        lde_want[brl(i)] = sum(int(coeffs[j]) * _basis(log + 1, j, pt) for j in range(n)) % P
+    assert np.array_equal(oracle.evaluate(coeffs[None, :], log, log + 1)[0], lde_want)
+
+
+def _qmul_m(q, m):
+    return [x * m % P for x in q]
+
+
+def _qadd(a, b):
+    return [(x + y) % P for x, y in zip(a, b)]
+
+
+def _qmul(a, b):
+    """QM31 product from the definition: (a0 + a1 i) + (a2 + a3 i) u, i^2 = -1, u^2 = 2 + i."""
+    def cm(x, y):
+        return ((x[0] * y[0] - x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+    a0, a1, b0, b1 = (a[0], a[1]), (a[2], a[3]), (b[0], b[1]), (b[2], b[3])
+    t = cm(a1, b1)
+    r = ((2 * t[0] - t[1]) % P, (t[0] + 2 * t[1]) % P)                 # (2 + i) * a1 * b1
+    lo = cm(a0, b0); hi0 = cm(a0, b1); hi1 = cm(a1, b0)
+    return [(lo[0] + r[0]) % P, (lo[1] + r[1]) % P, (hi0[0] + hi1[0]) % P, (hi0[1] + hi1[1]) % P]
+
+
+@pytest.mark.parametrize("log", [2, 3, 5])
+def test_fold_line_matches_the_definition(oracle, log):
+    """FriOps::fold_line from its definition: for p(x) = p0(pi(x)) + x p1(pi(x)) given by its evaluations on LineDomain(half_odds(log))
+    (bit-reversed), the fold with alpha is 2 (p0 + alpha p1) on the doubled domain — no 1/2 normalisation."""
+    n = 1 << log
+    br = lambda i, l: int(format(i, f"0{l}b")[::-1], 2) if l else 0
+    def line_x(l, i):       # x-coordinate of Coset::half_odds(l).at(i): initial subgroup_gen(l + 2), step subgroup_gen(l)
+        return _cpow(_GEN, ((1 << (31 - (l + 2))) + i * (1 << (31 - l))) % (1 << 31))[0]
+    def basis(l, j, x):     # line basis: bit k of j selects pi^k(x)
+        r, f = 1, x
+        for k in range(l):
+            if (j >> k) & 1:
+                r = r * f % P
+            f = (2 * f * f - 1) % P
+        return r
+    c = [int(v) for v in splitmix_column(777 + log, n)]
+    alpha = [int(v) for v in splitmix_column(778 + log, 4)]
+    src = [np.zeros(n, dtype=np.uint32) for _ in range(4)]
+    for i in range(n):
+        src[0][br(i, log)] = sum(c[j] * basis(log, j, line_x(log, i)) for j in range(n)) % P     # base-field polynomial embedded in QM31
+    want = [np.zeros(n // 2, dtype=np.uint32) for _ in range(4)]
+    for i in range(n // 2):
+        y = line_x(log - 1, i)
+        p0 = sum(c[2 * j] * basis(log - 1, j, y) for j in range(n // 2)) % P
+        p1 = sum(c[2 * j + 1] * basis(log - 1, j, y) for j in range(n // 2)) % P
+        val = _qadd([2 * p0 % P, 0, 0, 0], _qmul_m(alpha, 2 * p1 % P))
+        for k in range(4):
+            want[k][br(i, log - 1)] = val[k]
+    got = [np.zeros(n // 2, dtype=np.uint32) for _ in range(4)]
+    sp = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in src]); dp = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in got])
+    assert oracle.L.orc_fold_line(sp, log, (ctypes.c_uint32 * 4)(*alpha), dp) == 0
+    for k in range(4):
+        assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("log", [3, 4])
+def test_fold_circle_into_line_matches_the_definition(oracle, log):
+    """FriOps::fold_circle_into_line from its definition: f(x, y) = g0(x) + y g1(x) on CanonicCoset(log).circle_domain() (bit-reversed) folds
+    to dst * alpha^2 + 2 (g0 + alpha g1) on LineDomain(half_odds(log - 1))."""
+    n = 1 << log
+    br = lambda i, l: int(format(i, f"0{l}b")[::-1], 2) if l else 0
+    c = [int(v) for v in splitmix_column(881 + log, n)]
+    alpha = [int(v) for v in splitmix_column(882 + log, 4)]
+    dst0 = [[int(v) for v in splitmix_column(883 + k, n // 2)] for k in range(4)]
+    src = [np.zeros(n, dtype=np.uint32) for _ in range(4)]
+    for i in range(n):
+        src[0][br(i, log)] = sum(c[j] * _basis(log, j, _domain_point(log, i)) for j in range(n)) % P
+    a2 = _qmul(alpha, alpha)
+    want = [np.zeros(n // 2, dtype=np.uint32) for _ in range(4)]
+    def xbasis(l, j, x):    # basis of the line polynomial in x: bit k of j selects pi^k(x)
+        r, f = 1, x
+        for k in range(l):
+            if (j >> k) & 1:
+                r = r * f % P
+            f = (2 * f * f - 1) % P
+        return r
+    for i in range(n // 2):
+        x = _domain_point(log, i)[0]          # the first half of the circle domain is the half-coset: its x-coordinates are the line domain
+        g0 = sum(c[2 * j] * xbasis(log - 1, j, x) for j in range(n // 2)) % P
+        g1 = sum(c[2 * j + 1] * xbasis(log - 1, j, x) for j in range(n // 2)) % P
+        slot = br(i, log - 1)
+        val = _qadd(_qmul([dst0[k][slot] for k in range(4)], a2), _qadd([2 * g0 % P, 0, 0, 0], _qmul_m(alpha, 2 * g1 % P)))
+        for k in range(4):
+            want[k][slot] = val[k]
+    dst = [np.array(dst0[k], dtype=np.uint32) for k in range(4)]
+    sp = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in src]); dp = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in dst])
+    assert oracle.L.orc_fold_circle_into_line(dp, sp, log, (ctypes.c_uint32 * 4)(*alpha)) == 0
+    for k in range(4):
+        assert np.array_equal(dst[k], want[k]), k
