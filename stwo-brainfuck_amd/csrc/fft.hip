@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
 // Fast path (transforms of >= 2^12 cells): register-radix butterflies, one LDS round trip per 4 layers.
 //   k_fft_tile12 : contiguous 4096-cell tile, layers [0, k), 6 <= k <= 12. 256 lanes x 16 cells. Layers 0,1 and 10,11 are done
 //                  in registers on the 16-byte global accesses; layers 2..5 and 6..9 are two radix-16 rounds through LDS.
-//   k_fft_strided7: 128 rows x 32 cells (128-B rows at stride 2^lo), layers [lo, lo+7). 128 lanes x 32 cells. Layers lo..lo+2 in
+//   k_fft_strided7: 128 rows x 32 or 64 cells (128- or 256-byte rows at stride 2^lo), layers [lo, lo+7). 32 cells per lane. Layers lo..lo+2 in
 //                  registers on the 16-byte accesses, layers lo+3..lo+6 as one radix-16 round with 4-byte coalesced row accesses.
 // LDS index padding p(i) = i + 4*(i >> 6) keeps the stride-4 round conflict-free and the 16-byte accesses aligned.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -331,17 +331,17 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
     }
 }
 
-template <bool INV>
-#ifndef BF_STRIDED7_WAVES
-#define BF_STRIDED7_WAVES 3
-#endif
-__global__ void __launch_bounds__(128, BF_STRIDED7_WAVES) k_fft_strided7(PassArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_val[4096];
+// CL = log2 of the cells per row: 5 (128-byte rows, 128 lanes) or 6 (256-byte rows, 256 lanes: longer contiguous bursts per DRAM page at
+// the same per-lane work; needs lo >= 6). Per lane always 32 cells: 8 rows x 4 cells in the 16-byte phase, 2 x 16 in the 4-byte phase.
+template <bool INV, int CL>
+__global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(PassArgs a) {
+    constexpr u32 C = 1u << CL, NT = 4u << CL;
+    __shared__ __attribute__((aligned(16))) u32 s_val[128 * C];
     __shared__ u32 s_tw[128];
     const u32 t = threadIdx.x, lo = a.lo, tile = blockIdx.x;
-    const u32 n_lhi_log = lo - 5;
+    const u32 n_lhi_log = lo - CL;
     const u32 H = tile >> n_lhi_log, Lhi = tile & ((1u << n_lhi_log) - 1);
-    const u32 base = (H << (lo + 7)) | (Lhi << 5);
+    const u32 base = (H << (lo + 7)) | (Lhi << CL);
     // twiddles: local layer j (global lo + j) entry q < 2^(6-j) at 128 - 2^(7-j) + q; global h = (H << (6-j)) + q
     if (t < 127) {
         u32 j = __clz(~(t << 25));
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(128, BF_STRIDED7_WAVES) k_fft_strided7(PassArg
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[128u - (128u >> layer) + idx]; };
     const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
-    const u32 l4 = 4 * (t & 7), r4 = t >> 3;      // 16-byte phase: rows m = 8*r4 + q (q = 0..7), cells l4..l4+3
+    const u32 l4 = 4 * (t & (C / 4 - 1)), r4 = t >> (CL - 2);      // 16-byte phase: rows m = 8*r4 + q (q = 0..7), cells l4..l4+3
     for (u32 col = col0; col < col1; col++) {
         g_cu32p src = as_global(a.src[col]);
         g_u32p dst = as_global(a.dst[col]);
@@ -369,19 +369,19 @@ __global__ void __launch_bounds__(128, BF_STRIDED7_WAVES) k_fft_strided7(PassArg
             }
         };
         auto narrow_task = [&](u32 id, bool from_global, bool to_global) {   // layers 3..6 over e for fixed (mlow3, l)
-            u32 l = id & 31, mlow = id >> 5;
+            u32 l = id & (C - 1), mlow = id >> CL;
             u32 v[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 u32 m = 8 * e + mlow;
-                v[e] = from_global ? __builtin_nontemporal_load(src + ((base | (m << lo) | l) & a.src_mask)) : s_val[32 * m + l];
+                v[e] = from_global ? __builtin_nontemporal_load(src + ((base | (m << lo) | l) & a.src_mask)) : s_val[C * m + l];
             }
             radix16<INV>(v, 4, [&](int jl, int pe) -> u32 { return TW(3 + jl, pe); });
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 u32 m = 8 * e + mlow;
                 if (to_global) __builtin_nontemporal_store((INV && a.scale != 1) ? m_mul(v[e], a.scale) : v[e], dst + (base | (m << lo) | l));   // streamed: +2 %
-                else s_val[32 * m + l] = v[e];
+                else s_val[C * m + l] = v[e];
             }
         };
         if (INV) {
@@ -390,17 +390,17 @@ __global__ void __launch_bounds__(128, BF_STRIDED7_WAVES) k_fft_strided7(PassArg
             for (int q = 0; q < 8; q++) { uint4 v = ld16_stream(src + ((base | ((8 * r4 + q) << lo) | l4) & a.src_mask)); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
             wide_stage(r);
 #pragma unroll
-            for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
+            for (int q = 0; q < 8; q++) *reinterpret_cast<uint4*>(&s_val[C * (8 * r4 + q) + l4]) = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
             __syncthreads();
             narrow_task(t, false, true);
-            narrow_task(t + 128, false, true);
+            narrow_task(t + NT, false, true);
         } else {
             narrow_task(t, true, false);
-            narrow_task(t + 128, true, false);
+            narrow_task(t + NT, true, false);
             __syncthreads();
             u32 r[8][4];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<uint4*>(&s_val[32 * (8 * r4 + q) + l4]); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
+            for (int q = 0; q < 8; q++) { uint4 v = *reinterpret_cast<uint4*>(&s_val[C * (8 * r4 + q) + l4]); r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w; }
             wide_stage(r);
 #pragma unroll
             for (int q = 0; q < 8; q++) st16(dst + (base | ((8 * r4 + q) << lo) | l4), make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]));
@@ -479,8 +479,18 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
             } else {
                 a.lo = k0 + 7 * (p - 1); a.k = 7;
                 ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", 8.0 * ncols * (double)(1u << log), alg);
-                if (inverse) hipLaunchKernelGGL(k_fft_strided7<true>, grid, dim3(128), 0, stream, a);
-                else hipLaunchKernelGGL(k_fft_strided7<false>, grid, dim3(128), 0, stream, a);
+#ifndef BF_STRIDED_WIDE_MIN_LOG
+#define BF_STRIDED_WIDE_MIN_LOG 20
+#endif
+                // 256-byte rows for big transforms (enough tiles to fill the chip twice over), 128-byte rows otherwise
+                if (a.lo >= 6 && log >= BF_STRIDED_WIDE_MIN_LOG) {
+                    dim3 gw(ntiles / 2, grid.y);
+                    if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), gw, dim3(256), 0, stream, a);
+                    else hipLaunchKernelGGL((k_fft_strided7<false, 6>), gw, dim3(256), 0, stream, a);
+                } else {
+                    if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 5>), grid, dim3(128), 0, stream, a);
+                    else hipLaunchKernelGGL((k_fft_strided7<false, 5>), grid, dim3(128), 0, stream, a);
+                }
             }
         }
         return;
