@@ -51,6 +51,34 @@ impl Context {
         Ok(out)
     }
 
+    /// `prove_brainfuck(&Machine)` as the reference receives it (`mod.rs:471-473`): the executed machine's register trace
+    /// (`inputs.trace()`, `mod.rs:508`; 7 words per row: clk, ip, ci, ni, mp, mv, mvi) and its program words — no re-execution.
+    pub fn prove_machine(&self, trace7: &[u32], program: &[u32], log_max_rows: u32) -> Result<Vec<u8>, String> {
+        assert!(trace7.len() % 7 == 0);
+        let mut tr: *mut sys::BfhipTrace = std::ptr::null_mut();
+        let rc = unsafe {
+            sys::bfhip_trace_create_from_registers(self.0, trace7.as_ptr(), trace7.len() / 7, program.as_ptr(), program.len(), &mut tr, std::ptr::null_mut(),
+                                                   std::ptr::null_mut(), std::ptr::null_mut())
+        };
+        if rc != 0 {
+            return Err(last_error());
+        }
+        let (mut js, mut len): (*mut c_char, usize) = (std::ptr::null_mut(), 0);
+        let rc = unsafe { sys::bfhip_prove_trace(self.0, tr, log_max_rows, &mut js, &mut len, std::ptr::null_mut(), std::ptr::null_mut()) };
+        unsafe { sys::bfhip_trace_destroy(self.0, tr) };
+        if rc != 0 {
+            return Err(last_error());
+        }
+        let out = unsafe { std::slice::from_raw_parts(js as *const u8, len) }.to_vec();
+        unsafe { sys::bfhip_free_host(js as *mut c_void) };
+        Ok(out)
+    }
+
+    /// Byte-level stwo conventions / Merkle channel of this context (`bfhip_conventions`; all zero = defaults).
+    pub fn set_conventions(&self, conv: &sys::BfhipConventions) -> Result<(), String> {
+        if unsafe { sys::bfhip_ctx_set_conventions(self.0, conv) } != 0 { Err(last_error()) } else { Ok(()) }
+    }
+
     /// Keep the program-independent preprocessed tree across proofs (the reference recommits it in every call).
     pub fn reuse_preprocessed(&self, on: bool) {
         unsafe { sys::bfhip_ctx_reuse_preprocessed(self.0, on as i32) };
