@@ -13,6 +13,9 @@ Prints ONE JSON line on rank 0 (driver contract). Checked and measured inside th
                   Blake2s compressions counted from the launch shapes; HBM figure beside it)
   fft             the circle-FFT kernels' moved and algorithmic GB/s (north-star figure), from one extra untimed, fully instrumented proof
   sweep           synthetic nested-counter traces of 2^20..2^26 domain rows (BASELINE metric "at 2^22 rows": config.headline_2^22)
+  poseidon252     BASELINE config 5 on one GPU: the 2^26-row synthetic trace with the Poseidon252 MerkleChannel variant
+  shard_group     N > 1 only: ONE proof over all N GPUs (strong scaling, RCCL), taken in child processes before the timed replicas run: the
+                  bench workload, a 2^24-row trace (configs 3/4) and the 2^26-row Poseidon252 trace (config 5); SHA-256 of each proof
   cpu_baseline    the CPU oracle ("port") — see cpu_baseline()
 """
 import argparse
@@ -149,7 +152,7 @@ def run_sweep(pkg, device, steps, logs):
                 dt = (time.perf_counter() - t0) / steps
                 ok, why = pkg.verify_brainfuck(proof, k)
                 out.append({"log_domain_rows": k, "log_max_rows": k, "vm_steps": tr.n_steps, "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 3),
-                            "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "verified": bool(ok)})
+                            "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok)})
             finally:
                 tr.close()
     finally:
@@ -157,19 +160,60 @@ def run_sweep(pkg, device, steps, logs):
     return out
 
 
+def run_poseidon_point(pkg, device, log):
+    """BASELINE config 5 on one GPU: the synthetic 2^log-row trace proved with the Poseidon252 MerkleChannel variant (one warm-up, one timed
+    proof; the shard probe proves the same trace over N GPUs and reports the same SHA-256)."""
+    conv = (0, 0, 0, 1)
+    c = pkg.Context(device, max_log_domain=log + 2)
+    try:
+        c.set_conventions(*conv)
+        tr = pkg.Trace(c, sweep_program(log), b"")
+        try:
+            tr.prove(log)
+            c.sync()
+            t0 = time.perf_counter()
+            proof, phases = tr.prove(log)
+            c.sync()
+            dt = time.perf_counter() - t0
+            ok, _ = pkg.verify_brainfuck(proof, log, conv)
+            return {"log_domain_rows": log, "log_max_rows": log, "conventions": list(conv), "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 1),
+                    "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok),
+                    "phase_ms": {k: round(v * 1e3, 1) for k, v in phases.items()}}
+        finally:
+            tr.close()
+    finally:
+        c.close()
+
+
+def probe_stages(args):
+    """(name, program, LOG_MAX_ROWS, conventions, warm-up proofs, timed proofs): the bench workload, then BASELINE configs 3/4 (a 2^24-row
+    synthetic trace) and 5 (a 2^26-row trace with the Poseidon252 MerkleChannel) proved by the whole group."""
+    conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
+    stages = [("fib19", FIB19, args.log_max_rows, conv, 2, args.probe_steps)]
+    if not args.probe_fib19_only:
+        stages.append(("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3))
+        stages.append(("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1))
+    return stages
+
+
 def shard_probe(args):
     """Child-process mode (--shard-probe): this rank joins the other ranks' probe children in ONE shard group (RCCL on the library's own
-    stream; the 128-byte unique id travels through a file) and times a few proofs of the bench workload proved by all GPUs together.
-    No torch, no torch.distributed: the parent keeps its process group for the contract's timing protocol. Writes one JSON object."""
+    stream; the 128-byte unique id travels through a file) and times a few proofs per stage, each proved by all GPUs together.
+    No torch, no torch.distributed: the parent keeps its process group for the contract's timing protocol. The result file is rewritten
+    after every stage, so a stage that hangs (the parent kills this child on its timeout) does not cost the earlier ones."""
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    out = {"n_gpus": world, "rank": rank}
+    out = {"n_gpus": world, "rank": rank, "stages": {}}
+
+    def flush():
+        with open(args.probe_out + ".tmp", "w") as f:
+            json.dump(out, f)
+        os.replace(args.probe_out + ".tmp", args.probe_out)
+
     try:
         pkg = load_package()
-        conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
-        pkg.set_default_conventions(*conv)
+        stages = probe_stages(args)
         device = pick_device(local_rank, pkg.device_count(), args.device)
-        ctx = pkg.Context(device, max_log_domain=args.log_max_rows + 2)
-        trace = pkg.Trace(ctx, FIB19, b"")
+        ctx = pkg.Context(device, max_log_domain=max(s[2] for s in stages) + 2)
         idf = args.probe_id_file
         if rank == 0:
             with open(idf + ".tmp", "wb") as f:
@@ -182,26 +226,45 @@ def shard_probe(args):
             time.sleep(0.02)
         uid = open(idf, "rb").read()
         ctx.join_rccl_group(uid, rank, world)
-        for _ in range(2):
-            proof, _ = trace.prove(args.log_max_rows)
-        ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(args.probe_steps):
-            proof, phases = trace.prove(args.log_max_rows)
-        ctx.sync()
-        dt = (time.perf_counter() - t0) / args.probe_steps
-        want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == args.log_max_rows), None)
-        stats = ctx.group_stats()
-        out.update({"ms_per_proof": round(dt * 1e3, 3), "cells_per_s": trace.cells / dt, "steps": args.probe_steps,
-                    "parity_checked": bool(want is not None and hashlib.sha256(proof).hexdigest() == want["sha256"]),
-                    "transport": ctx.group_info()[2], "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
-                    "per_proof": {k: round(v / (args.probe_steps + 2), 1) for k, v in stats.items()}})
-        ctx.leave_group(); trace.close(); ctx.close()
+        out["transport"] = ctx.group_info()[2]
+        flush()
+        for name, code, lmr, conv, warm, steps in stages:
+            row = {"log_max_rows": lmr, "conventions": list(conv)}
+            out["stages"][name] = row
+            try:
+                ctx.set_conventions(*conv)
+                trace = pkg.Trace(ctx, code, b"")
+                try:
+                    before = ctx.group_stats()
+                    for _ in range(warm):
+                        proof, _ = trace.prove(lmr)
+                    ctx.sync()
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        proof, phases = trace.prove(lmr)
+                    ctx.sync()
+                    dt = (time.perf_counter() - t0) / steps
+                    after = ctx.group_stats()
+                    row.update({"ms_per_proof": round(dt * 1e3, 3), "cells": trace.cells, "cells_per_s": trace.cells / dt, "steps": steps,
+                                "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
+                                "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
+                                "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after}})
+                    if rank == 0:
+                        row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
+                    if name == "fib19":
+                        want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
+                        row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
+                finally:
+                    trace.close()
+            except Exception as e:      # a failed stage ends the probe: the other ranks may be inside its collectives
+                row["error"] = repr(e)
+                flush()
+                raise
+            flush()
+        ctx.leave_group(); ctx.close()
     except Exception as e:
         out["error"] = repr(e)
-    with open(args.probe_out + ".tmp", "w") as f:
-        json.dump(out, f)
-    os.replace(args.probe_out + ".tmp", args.probe_out)
+    flush()
     return 0
 
 
@@ -219,6 +282,8 @@ def run_shard_probe(args, rank, world):
             pass
     cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--probe-out", out_path, "--probe-id-file", f"{base}.id", "--probe-steps", str(args.probe_steps),
            "--log-max-rows", str(args.log_max_rows), "--conventions", args.conventions]
+    if args.probe_fib19_only:
+        cmd.append("--probe-fib19-only")
     if args.device is not None:
         cmd += ["--device", str(args.device)]
     child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -227,7 +292,12 @@ def run_shard_probe(args, rank, world):
     except subprocess.TimeoutExpired:
         child.kill()
         child.wait()
-        return {"n_gpus": world, "error": f"probe child did not finish within {args.probe_timeout} s (killed)"}
+        try:
+            partial = json.load(open(out_path))       # the stages that completed before the one that hung
+        except Exception:
+            partial = {"n_gpus": world}
+        partial["error"] = f"probe child did not finish within {args.probe_timeout} s (killed); stages listed without ms_per_proof did not complete"
+        return partial
     try:
         return json.load(open(out_path))
     except Exception as e:
@@ -248,6 +318,8 @@ def main():
     ap.add_argument("--kernel-events", default="dominant", choices=["dominant", "all"], help="HIP-event timing of the dominant kernel only (default, ~0.5%% overhead) or of every kernel (~10%%) inside the timed region")
     ap.add_argument("--no-sweep", action="store_true", help="skip the 2^20..2^26 synthetic sweep (N=1 only; ~15 s)")
     ap.add_argument("--sweep-steps", type=int, default=3)
+    ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon252 2^26-row point (BASELINE config 5 on one GPU; ~15 s)")
+    ap.add_argument("--poseidon-log", type=int, default=26)
     ap.add_argument("--sweep-logs", default="20,21,22,23,24,25,26")
     ap.add_argument("--conventions", default="0,0,0,0", help="merkle_node_hash,mix_u64,logup_mask_order,merkle_channel (include/bfhip.h bfhip_conventions); default = stwo defaults, Blake2s channel")
     ap.add_argument("--reuse-preprocessed", action="store_true", help="NOT the headline: keep the program-independent preprocessed tree across proofs (a deployment option; the reference recommits it per proof)")
@@ -259,7 +331,8 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true", help="N > 1, replicas mode: skip the extra strong-scaling measurement (one proof over all N GPUs) taken in child "
                     "processes before the timed replicas run")
     ap.add_argument("--probe-steps", type=int, default=8)
-    ap.add_argument("--probe-timeout", type=int, default=120)
+    ap.add_argument("--probe-timeout", type=int, default=300)
+    ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-out", help=argparse.SUPPRESS)
     ap.add_argument("--probe-id-file", help=argparse.SUPPRESS)
@@ -436,6 +509,12 @@ def main():
             sweep = run_sweep(pkg, device, args.sweep_steps, [int(v) for v in args.sweep_logs.split(",")])
         except Exception as e:      # the sweep must never cost the headline line
             sweep = {"error": repr(e)}
+    poseidon = None
+    if world == 1 and not args.no_sweep and not args.no_poseidon and rank == 0:
+        try:
+            poseidon = run_poseidon_point(pkg, device, args.poseidon_log)
+        except Exception as e:
+            poseidon = {"error": repr(e)}
 
     cells = trace.cells
     if rank == 0:
@@ -468,6 +547,7 @@ def main():
             "fft": fft,
             "pipelined": pipelined,
             "sweep": sweep,
+            "poseidon252": poseidon,
         }
         if shard_probe_result is not None:
             # strong scaling beside the weak-scaling value: the same workload proved ONCE by all N GPUs together

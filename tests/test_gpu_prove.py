@@ -324,8 +324,8 @@ def test_bench_line_contract(tmp_path):
     the roofline is the VALU one with a measured compression count, and the sweep points verify."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "sample", "--sweep-logs", "20,22", "--sweep-steps", "1"],
-                       capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-baseline", "sample", "--sweep-logs", "20,22", "--sweep-steps", "1",
+                        "--poseidon-log", "20"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -340,6 +340,7 @@ def test_bench_line_contract(tmp_path):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["hbm"]["peak"] == 8000.0
     assert d["fft"]["algorithmic_GBps"] > 0 and any(k.startswith("k_fft_strided7") for k in d["fft"]["kernels"])
     assert [p["log_domain_rows"] for p in d["sweep"]] == [20, 22] and all(p["verified"] for p in d["sweep"])
-    assert d["config"]["headline_2^22"]["cells_per_s"] > 0
+    assert d["config"]["headline_2^22"]["cells_per_s"] > 0 and all(len(p["proof_sha256"]) == 64 for p in d["sweep"])
+    assert d["poseidon252"]["verified"] is True and d["poseidon252"]["conventions"] == [0, 0, 0, 1] and d["poseidon252"]["log_domain_rows"] == 20
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
