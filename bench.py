@@ -215,17 +215,18 @@ def shard_probe(args):
         device = pick_device(local_rank, pkg.device_count(), args.device)
         ctx = pkg.Context(device, max_log_domain=max(s[2] for s in stages) + 2)
         idf = args.probe_id_file
-        if rank == 0:
-            with open(idf + ".tmp", "wb") as f:
-                f.write(pkg.rccl_unique_id())
-            os.replace(idf + ".tmp", idf)
-        t0 = time.time()
-        while not os.path.exists(idf):
-            if time.time() - t0 > 60:
-                raise RuntimeError("unique id file did not appear")
-            time.sleep(0.02)
-        uid = open(idf, "rb").read()
-        ctx.join_rccl_group(uid, rank, world)
+        if world > 1:                       # world == 1: the stages on a single GPU (how the probe itself is tested on a 1-GPU box)
+            if rank == 0:
+                with open(idf + ".tmp", "wb") as f:
+                    f.write(pkg.rccl_unique_id())
+                os.replace(idf + ".tmp", idf)
+            t0 = time.time()
+            while not os.path.exists(idf):
+                if time.time() - t0 > 60:
+                    raise RuntimeError("unique id file did not appear")
+                time.sleep(0.02)
+            uid = open(idf, "rb").read()
+            ctx.join_rccl_group(uid, rank, world)
         out["transport"] = ctx.group_info()[2]
         flush()
         for name, code, lmr, conv, warm, steps in stages:
@@ -261,7 +262,9 @@ def shard_probe(args):
                 flush()
                 raise
             flush()
-        ctx.leave_group(); ctx.close()
+        if world > 1:
+            ctx.leave_group()
+        ctx.close()
     except Exception as e:
         out["error"] = repr(e)
     flush()

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Time-bounded randomized parity campaign on one GPU box (test infrastructure; the committed suite runs a fixed subset of this):
+seeded random Brainfuck programs of four size classes, every convention set (Poseidon252 on the smaller classes — its CPU oracle is slow),
+proved (a) by the CPU oracle, (b) by one context, (c) by a local shard group of 2/4/8 contexts. All proofs of one case must be the
+same bytes and both verifiers must accept them. Prints one JSON summary; exit code 1 on any mismatch.
+Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000]"""
+import json, os, random, sys, threading, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package, Oracle, CONVENTIONS
+from bf_fuzz import random_program, _simulate
+
+CLASSES = [("small", 400), ("medium", 6000), ("large", 60000), ("xl", 400000)]
+
+
+def program(seed, cls, bound):
+    """small/medium: tests/bf_fuzz.py as the suite uses it; large/xl: a random body inside a counted outer loop, accepted when it halts within
+    the bound, stays right of cell 0 and has enough input."""
+    if cls in ("small", "medium"):
+        return random_program(seed, bound, min_steps=bound // 20)
+    rng = random.Random(seed)
+    while True:
+        body, _, body_steps = random_program(rng.randrange(1 << 30), 300, min_steps=10)
+        n = max(2, min(250, bound // (2 * body_steps + 4)))
+        code = "+" * n + "[>" + body + "<-]" + rng.choice(["", ".", ">+."])
+        if cls == "xl":
+            code = "+" * rng.randint(8, 14) + "[>" + code + "<-]"
+        inp = bytes(rng.randrange(256) for _ in range(4096))
+        steps = _simulate(code, inp, bound)
+        if steps is not None and steps >= bound // 8:
+            return code, inp, steps
+
+
+def prove_sharded(pkg, code, inp, lmr, count, conv):
+    group = pkg.LocalGroup(count)
+    ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(count)]
+    proofs, errors = [None] * count, []
+
+    def run(rank):
+        try:
+            ctxs[rank].set_conventions(*conv)
+            ctxs[rank].join_local_group(group, rank)
+            proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr)
+        except Exception as e:
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(count)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for c in ctxs:
+        c.leave_group(); c.close()
+    group.close()
+    if errors:
+        raise RuntimeError("; ".join(errors))
+    return proofs
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    pkg = load_package()
+    orc = Oracle()
+    orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
+    convs = list(CONVENTIONS.items())
+    t_end = time.time() + budget
+    summary = {"seconds": budget, "first_seed": seed, "cases": 0, "by_class": {}, "by_conventions": {}, "by_shard_count": {}, "failures": []}
+    k = 0
+    while time.time() < t_end:
+        cls, bound = CLASSES[(k // 3) % 4 if k % 11 else 3]           # mostly small..large, an xl case every 11th
+        cname, conv = convs[k % len(convs)]
+        if cname == "poseidon" and cls in ("large", "xl"):
+            cname, conv = convs[0]
+        count = (1, 2, 4, 8)[(k // 2) % 4]
+        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count}
+        try:
+            code, inp, steps = program(seed, cls, bound)
+            case["vm_steps"] = steps
+            orc.set_conventions(*conv)
+            lmr = max(max(orc.log_sizes(code, inp)[0]), 8)
+            want, _, _ = orc.prove(code, inp, log_max_rows=lmr)
+            c1 = pkg.Context(0, max_log_domain=lmr + 2)
+            c1.set_conventions(*conv)
+            got = pkg.prove_brainfuck(code, inp, ctx=c1, log_max_rows=lmr)
+            c1.close()
+            problems = []
+            if got != want:
+                problems.append("single-context proof differs from the oracle's")
+            if count > 1:
+                for r, p in enumerate(prove_sharded(pkg, code, inp, lmr, count, conv)):
+                    if p != want:
+                        problems.append(f"rank {r} of {count} differs from the oracle's proof")
+            if pkg.verify_brainfuck(got, lmr, conv) != (True, ""):
+                problems.append("own verifier rejects")
+            if not orc.verify(got, lmr)[0]:
+                problems.append("oracle verifier rejects")
+            if problems:
+                case["problems"] = problems; case["code"] = code; case["input_hex"] = inp.hex()[:256]
+                summary["failures"].append(case)
+        except Exception as e:
+            case["problems"] = [repr(e)]
+            summary["failures"].append(case)
+        summary["cases"] += 1
+        for key, v in (("by_class", cls), ("by_conventions", cname), ("by_shard_count", str(count))):
+            summary[key][v] = summary[key].get(v, 0) + 1
+        seed += 1; k += 1
+    summary["last_seed"] = seed - 1
+    summary["ok"] = not summary["failures"]
+    print(json.dumps(summary, indent=1))
+    return 0 if summary["ok"] else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
