@@ -709,7 +709,9 @@ struct HipProver {
         }
         trees[3].polys = cur;
         trees[3].owner.assign(4, OWNER_ALL);
-        if (cur_owned) for (int w = 0; w < 4; w++) trees[3].owner[w] = owner_of(w);
+        // The composition LDE is one size above the largest accumulator: it can be row-sharded (quotients, FRI first layer) although no
+        // accumulator was. Then every rank holds the complete coefficients and coordinate w's owner alone extends them.
+        if (cur_owned || (sharded() && slice_log(cur[0].log_size + cfg.log_blowup))) for (int w = 0; w < 4; w++) trees[3].owner[w] = owner_of(w);
     }
 
     // PolyOps::eval_at_point for every (column, mask point)

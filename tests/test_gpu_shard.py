@@ -58,6 +58,19 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
         assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
 
 
+@pytest.mark.parametrize("seed,count", [(311, 2), (313, 2), (302, 4), (306, 4), (303, 8), (304, 8), (302, 2), (303, 4), (301, 8), (311, 8)])
+def test_shard_group_at_the_row_sharding_threshold(pkg, oracle, seed, count):
+    """Sizes around the granularity threshold (2^14 rows per rank). With the largest component at 2^(log2(count) + 12) rows no constraint
+    accumulator is row-sharded but the composition LDE (two sizes up) is — found by tools/fuzz_campaign.py ("quotients: inconsistent
+    row-sharding in a size group" in round 2); one size above and below it for the neighbouring cases."""
+    from bf_fuzz import random_program
+    code, inp, _ = random_program(seed, 6000, min_steps=300)
+    lmr = max(max(oracle.log_sizes(code, inp)[0]), 8)
+    want, _, _ = oracle.prove(code, inp, log_max_rows=lmr)
+    for r, p in enumerate(_prove_sharded(pkg, code, inp, lmr, count)):
+        assert p == want, f"rank {r} of {count} differs from the oracle's proof"
+
+
 @pytest.mark.parametrize("count", [2, 8])
 def test_fib19_full_size_in_a_shard_group(pkg, count):
     """The benchmark workload (BASELINE config 4: the 2^24-row trace over 8 ranks): every rank reproduces the committed digest of the
