@@ -196,9 +196,64 @@ def probe_stages(args):
     return stages
 
 
+def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
+    """Runs every stage on `members` (the contexts this process drives: one with RCCL, all N of an in-process group — one host thread
+    each). Results go to out["stages"][name]; a failed stage ends the probe (the other members may be inside its collectives)."""
+    import threading
+    for name, code, lmr, conv, warm, steps in stages:
+        row = {"log_max_rows": lmr, "conventions": list(conv)}
+        out["stages"][name] = row
+        n = len(members)
+        gate = threading.Barrier(n)
+        res, errors = [None] * n, []
+
+        def run(k):
+            ctx, trace = members[k], None
+            try:
+                ctx.set_conventions(*conv)
+                trace = pkg.Trace(ctx, code, b"")
+                before = ctx.group_stats()
+                for _ in range(warm):
+                    trace.prove(lmr)
+                ctx.sync()
+                gate.wait(timeout=600)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    proof, phases = trace.prove(lmr)
+                ctx.sync()
+                res[k] = (time.perf_counter() - t0, proof, phases, trace.cells, before, ctx.group_stats())
+            except Exception as e:
+                errors.append(repr(e))
+                gate.abort()
+            finally:
+                if trace is not None:
+                    trace.close()
+
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(n)]
+        [t.start() for t in threads]; [t.join() for t in threads]
+        if errors:
+            row["error"] = "; ".join(errors)
+            flush()
+            raise RuntimeError(row["error"])
+        dt = max(r[0] for r in res) / steps
+        _, proof, phases, cells, before, after = res[0]
+        row.update({"ms_per_proof": round(dt * 1e3, 3), "cells": cells, "cells_per_s": cells / dt, "steps": steps,
+                    "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
+                    "all_members_same_proof": all(r[1] == proof for r in res),
+                    "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
+                    "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after}})
+        if is_rank0:
+            row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
+        if name == "fib19":
+            want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
+            row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
+        flush()
+
+
 def shard_probe(args):
-    """Child-process mode (--shard-probe): this rank joins the other ranks' probe children in ONE shard group (RCCL on the library's own
-    stream; the 128-byte unique id travels through a file) and times a few proofs per stage, each proved by all GPUs together.
+    """Child-process mode (--shard-probe): ONE proof over all N GPUs, a few proofs per stage (probe_stages). Two transports:
+    default — this rank's child joins the other ranks' children in an RCCL shard group (the 128-byte unique id travels through a file);
+    --probe-local — rank 0's child alone drives all N GPUs from N host threads over the library's in-process transport (peer copies).
     No torch, no torch.distributed: the parent keeps its process group for the contract's timing protocol. The result file is rewritten
     after every stage, so a stage that hangs (the parent kills this child on its timeout) does not cost the earlier ones."""
     rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,59 +267,46 @@ def shard_probe(args):
     try:
         pkg = load_package()
         stages = probe_stages(args)
-        device = pick_device(local_rank, pkg.device_count(), args.device)
-        ctx = pkg.Context(device, max_log_domain=max(s[2] for s in stages) + 2)
-        idf = args.probe_id_file
-        if world > 1:                       # world == 1: the stages on a single GPU (how the probe itself is tested on a 1-GPU box)
-            if rank == 0:
-                with open(idf + ".tmp", "wb") as f:
-                    f.write(pkg.rccl_unique_id())
-                os.replace(idf + ".tmp", idf)
-            t0 = time.time()
-            while not os.path.exists(idf):
-                if time.time() - t0 > 60:
-                    raise RuntimeError("unique id file did not appear")
-                time.sleep(0.02)
-            uid = open(idf, "rb").read()
-            ctx.join_rccl_group(uid, rank, world)
-        out["transport"] = ctx.group_info()[2]
+        max_log = max(s[2] for s in stages) + 2
+        if args.probe_local:
+            n_dev = pkg.device_count()
+            devices = [pick_device(r, n_dev, args.device) for r in range(world)]
+            out["devices"] = devices
+            members = [pkg.Context(d, max_log_domain=max_log) for d in devices]
+            group = pkg.LocalGroup(world) if world > 1 else None
+            if group is not None:
+                import threading
+                errs = []
+                def join(r):
+                    try:
+                        members[r].join_local_group(group, r)
+                    except Exception as e:
+                        errs.append(repr(e))
+                th = [threading.Thread(target=join, args=(r,)) for r in range(world)]
+                [t.start() for t in th]; [t.join() for t in th]
+                if errs:
+                    raise RuntimeError("; ".join(errs))
+        else:
+            members = [pkg.Context(pick_device(local_rank, pkg.device_count(), args.device), max_log_domain=max_log)]
+            if world > 1:                       # world == 1: the stages on a single GPU (how the probe itself is tested on a 1-GPU box)
+                idf = args.probe_id_file
+                if rank == 0:
+                    with open(idf + ".tmp", "wb") as f:
+                        f.write(pkg.rccl_unique_id())
+                    os.replace(idf + ".tmp", idf)
+                t0 = time.time()
+                while not os.path.exists(idf):
+                    if time.time() - t0 > 60:
+                        raise RuntimeError("unique id file did not appear")
+                    time.sleep(0.02)
+                members[0].join_rccl_group(open(idf, "rb").read(), rank, world)
         flush()
-        for name, code, lmr, conv, warm, steps in stages:
-            row = {"log_max_rows": lmr, "conventions": list(conv)}
-            out["stages"][name] = row
-            try:
-                ctx.set_conventions(*conv)
-                trace = pkg.Trace(ctx, code, b"")
-                try:
-                    before = ctx.group_stats()
-                    for _ in range(warm):
-                        proof, _ = trace.prove(lmr)
-                    ctx.sync()
-                    t0 = time.perf_counter()
-                    for _ in range(steps):
-                        proof, phases = trace.prove(lmr)
-                    ctx.sync()
-                    dt = (time.perf_counter() - t0) / steps
-                    after = ctx.group_stats()
-                    row.update({"ms_per_proof": round(dt * 1e3, 3), "cells": trace.cells, "cells_per_s": trace.cells / dt, "steps": steps,
-                                "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
-                                "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
-                                "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after}})
-                    if rank == 0:
-                        row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
-                    if name == "fib19":
-                        want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
-                        row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
-                finally:
-                    trace.close()
-            except Exception as e:      # a failed stage ends the probe: the other ranks may be inside its collectives
-                row["error"] = repr(e)
-                flush()
-                raise
-            flush()
-        if world > 1:
-            ctx.leave_group()
-        ctx.close()
+        probe_run_stages(pkg, members, stages, out, flush, rank == 0)
+        out["transport"] = members[0].group_info()[2]
+        for m in members:
+            if world > 1:
+                m.leave_group()
+            m.close()
     except Exception as e:
         out["error"] = repr(e)
     flush()
@@ -272,39 +314,62 @@ def shard_probe(args):
 
 
 def run_shard_probe(args, rank, world):
-    """Parent side, BEFORE this process touches the GPU (a child must not be exec'd from a process that has initialised it): every rank
-    starts its probe child, waits for it (bounded) and kills exactly that PID on timeout. Returns rank 0's result (or an error record)."""
+    """Parent side, BEFORE this process touches the GPU (a child must not be exec'd from a process that has initialised it).
+    (1) every rank starts its RCCL probe child, waits for it (bounded) and kills exactly that PID on timeout; (2) rank 0 alone starts the
+    in-process probe child (N host threads driving the N GPUs) while the other ranks wait for its completion marker.
+    Returns rank 0's RCCL result with the in-process result under "single_process" (or error records)."""
     import subprocess
     import tempfile
     base = os.path.join(tempfile.gettempdir(), f"bfhip_probe_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
-    out_path = f"{base}_rank{rank}.json"
-    for path in (out_path, f"{base}.id") if rank == 0 else (out_path,):
+    marker = f"{base}.localdone"
+
+    def run_child(extra, out_path):
         try:
-            os.remove(path)
+            os.remove(out_path)
         except OSError:
             pass
-    cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--probe-out", out_path, "--probe-id-file", f"{base}.id", "--probe-steps", str(args.probe_steps),
-           "--log-max-rows", str(args.log_max_rows), "--conventions", args.conventions]
-    if args.probe_fib19_only:
-        cmd.append("--probe-fib19-only")
-    if args.device is not None:
-        cmd += ["--device", str(args.device)]
-    child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    try:
-        child.wait(timeout=args.probe_timeout)
-    except subprocess.TimeoutExpired:
-        child.kill()
-        child.wait()
+        cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--probe-out", out_path, "--probe-id-file", f"{base}.id", "--probe-steps", str(args.probe_steps),
+               "--log-max-rows", str(args.log_max_rows), "--conventions", args.conventions] + extra
+        if args.probe_fib19_only:
+            cmd.append("--probe-fib19-only")
+        if args.device is not None:
+            cmd += ["--device", str(args.device)]
+        child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         try:
-            partial = json.load(open(out_path))       # the stages that completed before the one that hung
-        except Exception:
-            partial = {"n_gpus": world}
-        partial["error"] = f"probe child did not finish within {args.probe_timeout} s (killed); stages listed without ms_per_proof did not complete"
-        return partial
-    try:
-        return json.load(open(out_path))
-    except Exception as e:
-        return {"n_gpus": world, "error": f"probe child left no result (exit code {child.returncode}): {e!r}"}
+            child.wait(timeout=args.probe_timeout)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            child.wait()
+            try:
+                partial = json.load(open(out_path))       # the stages that completed before the one that hung
+            except Exception:
+                partial = {"n_gpus": world}
+            partial["error"] = f"probe child did not finish within {args.probe_timeout} s (killed); stages listed without ms_per_proof did not complete"
+            return partial
+        try:
+            return json.load(open(out_path))
+        except Exception as e:
+            return {"n_gpus": world, "error": f"probe child left no result (exit code {child.returncode}): {e!r}"}
+
+    if rank == 0:
+        for path in (f"{base}.id", marker):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    result = run_child([], f"{base}_rank{rank}.json")
+    if args.no_local_probe:
+        return result
+    if rank == 0:
+        try:
+            result["single_process"] = run_child(["--probe-local"], f"{base}_local.json")
+        finally:
+            open(marker, "w").close()
+    else:
+        t0 = time.time()
+        while not os.path.exists(marker) and time.time() - t0 < args.probe_timeout + 60:
+            time.sleep(0.2)
+    return result
 
 
 def main():
@@ -336,6 +401,8 @@ def main():
     ap.add_argument("--probe-steps", type=int, default=8)
     ap.add_argument("--probe-timeout", type=int, default=300)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
+    ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
+    ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-out", help=argparse.SUPPRESS)
     ap.add_argument("--probe-id-file", help=argparse.SUPPRESS)

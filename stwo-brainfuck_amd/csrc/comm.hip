@@ -1,4 +1,5 @@
-// Shard-group transports (comm.h): RCCL over xGMI for one process per GPU, and an in-process transport for N contexts on one GPU.
+// Shard-group transports (comm.h): RCCL over xGMI for one process per GPU, and an in-process transport for N contexts of one process
+// (on one GPU — how a 1-GPU box tests the group logic — or on one GPU each: N host threads driving N GPUs).
 #include "ctx.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -9,14 +10,16 @@
 namespace bf {
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// LocalComm: the ranks are host threads of one process, their buffers live on one device. A transfer is a device-to-device copy
-// enqueued on the RECEIVER's stream after the sender's "ready" event; the sender's stream then waits for the receivers' "done" events
-// before it may touch the source again. A host rendezvous (barrier) separates publishing the pointers from reading them.
+// LocalComm: the ranks are host threads of one process; their contexts may share a device or own one each. A transfer is a
+// device-to-device copy enqueued on the RECEIVER's stream after the sender's "ready" event (events and copies work across devices; peer
+// access is enabled on first use so that the copies go over xGMI instead of through the host); the sender's stream then waits for the
+// receivers' "done" events before it may touch the source again. A host rendezvous (barrier) separates publishing the pointers from
+// reading them. No kernel reads another rank's memory.
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct LocalGroup {
     u32 count;
     std::mutex mu; std::condition_variable cv; u32 arrived = 0; u64 generation = 0; u32 joined = 0;
-    struct Slot { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; std::vector<Xfer> sends; };
+    struct Slot { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; std::vector<Xfer> sends; int device = -1; };
     std::vector<Slot> slots;
     explicit LocalGroup(u32 n) : count(n), slots(n) {}
     void barrier() {
@@ -29,31 +32,55 @@ struct LocalGroup {
 };
 std::shared_ptr<LocalGroup> local_group_create(u32 count) { return std::make_shared<LocalGroup>(count); }
 
-__global__ void k_max_u32_n(u32* __restrict__ out, const u32* const* __restrict__ bufs, u32 nbufs, size_t n) {
+// out[i] = max over the nbufs gathered copies (copy b at gathered + b * n)
+__global__ void k_max_u32_n(u32* __restrict__ out, const u32* __restrict__ gathered, u32 nbufs, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 m = 0;
-    for (u32 b = 0; b < nbufs; b++) { u32 v = bufs[b][i]; m = v > m ? v : m; }
+    for (u32 b = 0; b < nbufs; b++) { u32 v = gathered[b * n + i]; m = v > m ? v : m; }
     out[i] = m;
 }
 
 struct LocalComm : Comm {
     std::shared_ptr<LocalGroup> g;
-    u32* scratch = nullptr; size_t scratch_words = 0;
-    const u32** d_ptrs = nullptr;
+    u32* scratch = nullptr; size_t scratch_words = 0;     // (count + 1) * n words: the gathered copies, then the result
+    bool peers_checked = false, multi_device = false;
     LocalComm(const std::shared_ptr<LocalGroup>& g_, u32 r) : g(g_) {
         rank = r; count = g_->count;
+        BF_HIP(hipGetDevice(&g->slots[r].device));        // the C-ABI entry has bound this thread to the context's GPU
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].done, hipEventDisableTiming));
-        BF_HIP(hipMalloc((void**)&d_ptrs, sizeof(u32*) * count));
     }
     ~LocalComm() override {
         (void)hipEventDestroy(g->slots[rank].ready); (void)hipEventDestroy(g->slots[rank].done);
         g->slots[rank].ready = g->slots[rank].done = nullptr;
-        (void)hipFree(scratch); (void)hipFree((void*)d_ptrs);
+        (void)hipFree(scratch);
     }
-    const char* transport() const override { return "local (N contexts of one process, device-to-device copies ordered by HIP events)"; }
-    void publish(hipStream_t s, void* buf) { g->slots[rank].buf = buf; BF_HIP(hipEventRecord(g->slots[rank].ready, s)); g->barrier(); }
+    const char* transport() const override {
+        return multi_device ? "local (N contexts of one process on one GPU each, peer copies ordered by HIP events)"
+                            : "local (N contexts of one process, device-to-device copies ordered by HIP events)";
+    }
+    // first collective (every rank has joined by its rendezvous): best-effort peer access to the other ranks' GPUs
+    void check_peers() {
+        if (peers_checked) return;
+        peers_checked = true;
+        const int mine = g->slots[rank].device;
+        for (u32 p = 0; p < count; p++) {
+            const int d = g->slots[p].device;
+            if (d == mine || d < 0) continue;
+            multi_device = true;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, mine, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);   // "already enabled" is fine
+            (void)hipGetLastError();
+        }
+    }
+    // copy `bytes` from rank p's memory into mine on my stream
+    void copy_from(u32 p, void* dst, const void* src, size_t bytes, hipStream_t s) {
+        const int mine = g->slots[rank].device, theirs = g->slots[p].device;
+        if (theirs != mine) BF_HIP(hipMemcpyPeerAsync(dst, mine, src, theirs, bytes, s));
+        else BF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    void publish(hipStream_t s, void* buf) { g->slots[rank].buf = buf; BF_HIP(hipEventRecord(g->slots[rank].ready, s)); g->barrier(); check_peers(); }
     void finish(hipStream_t s) {
         BF_HIP(hipEventRecord(g->slots[rank].done, s));
         g->barrier();
@@ -65,22 +92,24 @@ struct LocalComm : Comm {
         for (u32 p = 0; p < count; p++) {
             if (p == rank) continue;
             BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0));
-            BF_HIP(hipMemcpyAsync((char*)buf + p * bpr, (const char*)g->slots[p].buf + p * bpr, bpr, hipMemcpyDeviceToDevice, s));
+            copy_from(p, (char*)buf + p * bpr, (const char*)g->slots[p].buf + p * bpr, bpr, s);
         }
         finish(s);
     }
     void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
         n_all_reduce++; bytes_sent += n * sizeof(u32);
         if (n == 0) { g->barrier(); g->barrier(); return; }
-        if (scratch_words < n) { (void)hipFree(scratch); scratch = nullptr; BF_HIP(hipMalloc((void**)&scratch, n * sizeof(u32))); scratch_words = n; }
+        const size_t need = (size_t)(count + 1) * n;
+        if (scratch_words < need) { BF_HIP(hipStreamSynchronize(s)); (void)hipFree(scratch); scratch = nullptr; scratch_words = 0; BF_HIP(hipMalloc((void**)&scratch, need * sizeof(u32))); scratch_words = need; }
         publish(s, buf);
-        std::vector<const u32*> ptrs(count);
-        for (u32 p = 0; p < count; p++) { ptrs[p] = (const u32*)g->slots[p].buf; if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0)); }
-        BF_HIP(hipMemcpyAsync((void*)d_ptrs, ptrs.data(), sizeof(u32*) * count, hipMemcpyHostToDevice, s));
-        BF_HIP(hipStreamSynchronize(s));   // `ptrs` is a stack object; tiny operation on a latency-insensitive path (tests)
-        hipLaunchKernelGGL(k_max_u32_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, d_ptrs, count, n);
-        finish(s);                         // every rank has computed its result from the unmodified inputs
-        BF_HIP(hipMemcpyAsync(buf, scratch, n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+        for (u32 p = 0; p < count; p++) {   // gather every rank's (unmodified) input into this rank's scratch, then reduce locally
+            if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0));
+            copy_from(p, scratch + (size_t)p * n, g->slots[p].buf, n * sizeof(u32), s);
+        }
+        u32* result = scratch + (size_t)count * n;
+        hipLaunchKernelGGL(k_max_u32_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, result, scratch, count, n);
+        finish(s);                         // every rank has read the unmodified inputs
+        BF_HIP(hipMemcpyAsync(buf, result, n * sizeof(u32), hipMemcpyDeviceToDevice, s));
     }
     void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
         n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
@@ -93,7 +122,7 @@ struct LocalComm : Comm {
             while (k < ps.size() && ps[k].peer != rank) k++;
             if (k >= ps.size() || ps[k].bytes != r.bytes) throw HipError("shard group: unmatched send/receive");
             if (r.peer != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[r.peer].ready, 0));
-            if (r.bytes) BF_HIP(hipMemcpyAsync(r.ptr, ps[k].ptr, r.bytes, hipMemcpyDeviceToDevice, s));
+            if (r.bytes) copy_from(r.peer, r.ptr, ps[k].ptr, r.bytes, s);
             k++;
         }
         finish(s);
