@@ -178,14 +178,15 @@ void bfhip_free_host(void* p);
  *   - the full-size columns of the interaction and composition trees are COLUMN-sharded for interpolation / LDE (greedy by size), then one
  *     grouped send-receive cuts every LDE column into contiguous bit-reversed ROW ranges (contiguous ranges of a bit-reversed circle domain
  *     are sub-cosets), together with a previous-row copy of each component's last logUp column (its mask offset -1 is not a halo);
- *   - Merkle subtrees, constraint evaluation, FRI quotients and the FRI folds down to 2^12 rows per rank are row-local; one all-gather per
+ *   - Merkle subtrees, constraint evaluation, FRI quotients and the FRI folds down to 2^14 rows per rank are row-local; one all-gather per
  *     tree completes the layer of 256 nodes per rank, the top is hashed redundantly so that every rank feeds the same root to its channel;
  *   - out-of-domain samples and decommitment words are each produced by one rank and completed by a max-reduce (exact: zero elsewhere).
  * Every exchange is issued by the library on the context's own stream with device buffers on both ends; the host program supplies no
  * callbacks. Two transports:
  *   RCCL  — one process per GPU: rank 0 calls bfhip_rccl_unique_id, the host program hands the 128 bytes to the other ranks (any control
  *           channel: torch.distributed, MPI, a file), every rank calls bfhip_ctx_join_rccl_group. librccl is loaded on first use.
- *   local — the N contexts belong to one process and are driven by N host threads (used by the tests to run N ranks on one GPU).
+ *   local — the N contexts belong to one process and are driven by N host threads; they may share a GPU (how the tests run N ranks on a
+ *           one-GPU box) or own one each (peer copies between the GPUs, ordered by HIP events).
  * count must be a power of two in [2, 64]. Every rank must issue the same sequence of prove calls on the same trace. */
 typedef struct bfhip_local_group bfhip_local_group;
 int32_t bfhip_local_group_create(uint32_t count, bfhip_local_group** out);
