@@ -399,7 +399,7 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true", help="N > 1, replicas mode: skip the extra strong-scaling measurement (one proof over all N GPUs) taken in child "
                     "processes before the timed replicas run")
     ap.add_argument("--probe-steps", type=int, default=8)
-    ap.add_argument("--probe-timeout", type=int, default=300)
+    ap.add_argument("--probe-timeout", type=int, default=150)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
     ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)

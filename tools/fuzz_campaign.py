@@ -3,7 +3,10 @@
 seeded random Brainfuck programs of four size classes, every convention set (Poseidon252 on the smaller classes — its CPU oracle is slow),
 proved (a) by the CPU oracle, (b) by one context, (c) by a local shard group of 2/4/8 contexts. All proofs of one case must be the
 same bytes and both verifiers must accept them. Prints one JSON summary; exit code 1 on any mismatch.
-Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000]"""
+Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000] [fresh|persistent]
+persistent: ONE set of 8 long-lived contexts instead of fresh ones per case — between cases they join and leave groups of changing size,
+switch conventions, toggle the preprocessed-tree cache and prove with LOG_MAX_ROWS above the trace's need (state carried across proofs:
+arena, caches, staging ring, group membership)."""
 import json, os, random, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -54,9 +57,90 @@ def prove_sharded(pkg, code, inp, lmr, count, conv):
     return proofs
 
 
+def persistent(budget, seed):
+    pkg = load_package()
+    orc = Oracle()
+    orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
+    convs = list(CONVENTIONS.items())
+    MAXLOG = 21
+    ctxs = [pkg.Context(0, max_log_domain=MAXLOG + 2) for _ in range(8)]
+    rng = random.Random(seed)
+    t_end = time.time() + budget
+    summary = {"mode": "persistent", "seconds": budget, "first_seed": seed, "cases": 0, "by_shard_count": {}, "by_conventions": {}, "reuse_preprocessed_on": 0, "lmr_slack": {}, "failures": []}
+    while time.time() < t_end:
+        cls, bound = CLASSES[rng.randrange(3)]
+        cname, conv = convs[rng.randrange(len(convs))]
+        if cname == "poseidon" and cls == "large":
+            cname, conv = convs[0]
+        count = rng.choice((1, 1, 2, 4, 8))
+        reuse = rng.random() < 0.4
+        slack = rng.choice((0, 0, 1, 2))
+        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack}
+        try:
+            code, inp, steps = program(seed, cls, bound)
+            orc.set_conventions(*conv)
+            lmr = max(max(orc.log_sizes(code, inp)[0]), 8) + slack
+            if lmr > MAXLOG:
+                seed += 1
+                continue
+            want, _, _ = orc.prove(code, inp, log_max_rows=lmr)
+            members = ctxs[:count]
+            group = pkg.LocalGroup(count) if count > 1 else None
+            proofs, errors = [None] * count, []
+
+            def run(r):
+                try:
+                    c = members[r]
+                    c.set_conventions(*conv)
+                    pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 1 if reuse else 0)
+                    if group is not None:
+                        c.join_local_group(group, r)
+                    a = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
+                    b = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)      # second proof: the cached tree (if on), a warm arena
+                    proofs[r] = (a, b)
+                except Exception as e:
+                    errors.append(repr(e))
+
+            th = [threading.Thread(target=run, args=(r,)) for r in range(count)]
+            [t.start() for t in th]; [t.join() for t in th]
+            for c in members:
+                if group is not None:
+                    c.leave_group()
+            if group is not None:
+                group.close()
+            problems = list(errors)
+            for r, pr in enumerate(proofs):
+                if pr is not None and (pr[0] != want or pr[1] != want):
+                    problems.append(f"rank {r} of {count}: proof differs from the oracle's (first {pr[0] == want}, second {pr[1] == want})")
+            if problems:
+                case["problems"] = problems; case["code"] = code
+                summary["failures"].append(case)
+                if errors:                    # a failed group leaves contexts in an unknown state: start over with fresh ones
+                    for c in ctxs:
+                        c.close()
+                    ctxs = [pkg.Context(0, max_log_domain=MAXLOG + 2) for _ in range(8)]
+        except Exception as e:
+            case["problems"] = [repr(e)]
+            summary["failures"].append(case)
+        summary["cases"] += 1
+        summary["by_shard_count"][str(count)] = summary["by_shard_count"].get(str(count), 0) + 1
+        summary["by_conventions"][cname] = summary["by_conventions"].get(cname, 0) + 1
+        summary["lmr_slack"][str(slack)] = summary["lmr_slack"].get(str(slack), 0) + 1
+        summary["reuse_preprocessed_on"] += int(reuse)
+        seed += 1
+    for c in ctxs:
+        c.close()
+    summary["last_seed"] = seed - 1
+    summary["ok"] = not summary["failures"]
+    print(json.dumps(summary, indent=1))
+    return 0 if summary["ok"] else 1
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    if len(sys.argv) > 3 and sys.argv[3] == "persistent":
+        return persistent(budget, seed)
     pkg = load_package()
     orc = Oracle()
     orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
