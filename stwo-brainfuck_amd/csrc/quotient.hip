@@ -159,6 +159,33 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
         for (int r = 0; r < 4; r++) { n64[r][0] = 0; n64[r][1] = 0; n64[r][2] = 0; n64[r][3] = 0; }
         s64[0] = 0; s64[1] = 0; s64[2] = 0; s64[3] = 0;
         u32 pending = 0;
+#ifdef BF_QUOT_PIPE
+        // software pipeline: the descriptor chain (entry -> column descriptor -> cells) of column k + 1 is in flight while column k is accumulated
+        auto cells = [&](const ColDesc& cd) { return cd.shift == 0 ? ld16(as_global(cd.ptr) + row0) : make_uint4(ld_col(cd, row0), 0u, 0u, 0u); };
+        QuotientEntry qe = a.entries[e];
+        ColDesc cd = a.cols[qe.col];
+        uint4 v = cells(cd);
+        for (u32 k = 0; k < qb.n_cols; k++, e++) {
+            QuotientEntry qn = qe; ColDesc cn = cd; uint4 vn = v;
+            if (k + 1 < qb.n_cols) { qn = a.entries[e + 1]; cn = a.cols[qn.col]; vn = cells(cn); }
+            if (pending == 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { n64[r][0] = m_fold(n64[r][0]); n64[r][1] = m_fold(n64[r][1]); n64[r][2] = m_fold(n64[r][2]); n64[r][3] = m_fold(n64[r][3]); }
+                s64[0] = m_fold(s64[0]); s64[1] = m_fold(s64[1]); s64[2] = m_fold(s64[2]); s64[3] = m_fold(s64[3]);
+                pending = 0;
+            }
+            pending++;
+            const u32 c0 = qe.c.a.a, c1 = qe.c.a.b, c2 = qe.c.b.a, c3 = qe.c.b.b;
+            if (cd.shift == 0) {
+                const u32 vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) { n64[r][0] += (u64)c0 * vr[r]; n64[r][1] += (u64)c1 * vr[r]; n64[r][2] += (u64)c2 * vr[r]; n64[r][3] += (u64)c3 * vr[r]; }
+            } else {
+                s64[0] += (u64)c0 * v.x; s64[1] += (u64)c1 * v.x; s64[2] += (u64)c2 * v.x; s64[3] += (u64)c3 * v.x;
+            }
+            qe = qn; cd = cn; v = vn;
+        }
+#else
         for (u32 k = 0; k < qb.n_cols; k++, e++) {
             const QuotientEntry qe = a.entries[e];
             ColDesc cd = a.cols[qe.col];
@@ -180,6 +207,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
                 s64[0] += (u64)c0 * v; s64[1] += (u64)c1 * v; s64[2] += (u64)c2 * v; s64[3] += (u64)c3 * v;
             }
         }
+#endif
         Q31 num[4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
