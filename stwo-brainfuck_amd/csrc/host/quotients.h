@@ -24,6 +24,7 @@ struct ColumnSample { PtQ point; Q31 value; };
 // samples[k] = the (point, value) samples of column k of one size group, in mask order.
 inline void build_quotient_batches(const std::vector<std::vector<ColumnSample>>& samples, Q31 random_coeff,
                                    std::vector<QuotientBatch>& batches, std::vector<QuotientEntry>& entries) {
+    const size_t b0 = batches.size();
     std::map<PtQ, std::vector<std::pair<u32, Q31>>, PointLess> by_point;
     for (size_t k = 0; k < samples.size(); k++)
         for (auto& s : samples[k]) by_point[s.point].push_back({(u32)k, s.value});
@@ -48,6 +49,21 @@ inline void build_quotient_batches(const std::vector<std::vector<ColumnSample>>&
         qb.batch_coeff = q_pow(random_coeff, kv.second.size());
         qb.n_cols = (u32)kv.second.size();
         batches.push_back(qb);
+    }
+    // The row value is the Horner sum over batches, acc = acc * batch_coeff_b + term_b, i.e. sum_b term_b * w_b with w_b = the product of the
+    // later batches' coefficients. term_b = (sum_k c_k f_k - (A y + B)) / den_b is linear in (c_k, A, B), so the weight is folded into
+    // them here and the kernel only adds the terms (exact field arithmetic: the same values, 16 products less per row and extra batch).
+    Q31 w = q_one();
+    size_t e_end = entries.size();
+    for (size_t b = batches.size(); b-- > b0;) {
+        QuotientBatch& qb = batches[b];
+        const size_t e_begin = e_end - qb.n_cols;
+        if (b + 1 < batches.size()) {
+            qb.a_sum = q_mul(qb.a_sum, w); qb.b_sum = q_mul(qb.b_sum, w);
+            for (size_t e = e_begin; e < e_end; e++) entries[e].c = q_mul(entries[e].c, w);
+        }
+        w = q_mul(w, qb.batch_coeff);
+        e_end = e_begin;
     }
 }
 

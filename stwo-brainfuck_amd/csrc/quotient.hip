@@ -145,9 +145,10 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
     u32 row0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (a.n_rows) { if (row0 >= a.n_rows) return; row0 += a.row0; }
     else if (row0 >= (1u << a.log)) return;
-    u32 x[4], y[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) domain_point(a.tw, a.tw_total, a.log, row0 + r, x[r], y[r]);
+    // The lane's 4 rows are the points (x, y), (x, -y), (-x, -y), (-x, y) of the bit-reversed domain (domain_point: rows 4j..4j+3 share
+    // one twiddle-table entry up to signs), so every product with a row coordinate is formed once and only its sign varies per row.
+    u32 xv, yv;
+    domain_point(a.tw, a.tw_total, a.log, row0, xv, yv);
     Q31 acc[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
     u32 e = 0;
     for (u32 b = 0; b < a.n_batches; b++) {
@@ -159,33 +160,6 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
         for (int r = 0; r < 4; r++) { n64[r][0] = 0; n64[r][1] = 0; n64[r][2] = 0; n64[r][3] = 0; }
         s64[0] = 0; s64[1] = 0; s64[2] = 0; s64[3] = 0;
         u32 pending = 0;
-#ifdef BF_QUOT_PIPE
-        // software pipeline: the descriptor chain (entry -> column descriptor -> cells) of column k + 1 is in flight while column k is accumulated
-        auto cells = [&](const ColDesc& cd) { return cd.shift == 0 ? ld16(as_global(cd.ptr) + row0) : make_uint4(ld_col(cd, row0), 0u, 0u, 0u); };
-        QuotientEntry qe = a.entries[e];
-        ColDesc cd = a.cols[qe.col];
-        uint4 v = cells(cd);
-        for (u32 k = 0; k < qb.n_cols; k++, e++) {
-            QuotientEntry qn = qe; ColDesc cn = cd; uint4 vn = v;
-            if (k + 1 < qb.n_cols) { qn = a.entries[e + 1]; cn = a.cols[qn.col]; vn = cells(cn); }
-            if (pending == 3) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) { n64[r][0] = m_fold(n64[r][0]); n64[r][1] = m_fold(n64[r][1]); n64[r][2] = m_fold(n64[r][2]); n64[r][3] = m_fold(n64[r][3]); }
-                s64[0] = m_fold(s64[0]); s64[1] = m_fold(s64[1]); s64[2] = m_fold(s64[2]); s64[3] = m_fold(s64[3]);
-                pending = 0;
-            }
-            pending++;
-            const u32 c0 = qe.c.a.a, c1 = qe.c.a.b, c2 = qe.c.b.a, c3 = qe.c.b.b;
-            if (cd.shift == 0) {
-                const u32 vr[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int r = 0; r < 4; r++) { n64[r][0] += (u64)c0 * vr[r]; n64[r][1] += (u64)c1 * vr[r]; n64[r][2] += (u64)c2 * vr[r]; n64[r][3] += (u64)c3 * vr[r]; }
-            } else {
-                s64[0] += (u64)c0 * v.x; s64[1] += (u64)c1 * v.x; s64[2] += (u64)c2 * v.x; s64[3] += (u64)c3 * v.x;
-            }
-            qe = qn; cd = cn; v = vn;
-        }
-#else
         for (u32 k = 0; k < qb.n_cols; k++, e++) {
             const QuotientEntry qe = a.entries[e];
             ColDesc cd = a.cols[qe.col];
@@ -207,19 +181,19 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
                 s64[0] += (u64)c0 * v; s64[1] += (u64)c1 * v; s64[2] += (u64)c2 * v; s64[3] += (u64)c3 * v;
             }
         }
-#endif
-        Q31 num[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            num[r] = q_make(m_canon(m_fold(n64[r][0]) + m_fold(s64[0])), m_canon(m_fold(n64[r][1]) + m_fold(s64[1])),
-                            m_canon(m_fold(n64[r][2]) + m_fold(s64[2])), m_canon(m_fold(n64[r][3]) + m_fold(s64[3])));
-        C31 den[4]; u32 nrm[4];
+        // line part A y + B for y = +yv (rows 0, 3) and y = -yv (rows 1, 2)
+        const Q31 ay = q_mulm(qb.a_sum, yv);
+        const Q31 line_p = q_add(qb.b_sum, ay), line_m = q_sub(qb.b_sum, ay);
+        // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x in CM31 = kden - x * Pi.y + y * Pi.x (x, y in M31): kden -+ P +- Q with P = xv * Pi.y, Q = yv * Pi.x
+        const C31 P = {m_mul(xv, qb.piy.a), m_mul(xv, qb.piy.b)}, Q = {m_mul(yv, qb.pix.a), m_mul(yv, qb.pix.b)};
+        const C31 km = c_sub(qb.kden, P), kp = c_add(qb.kden, P);
+        C31 den[4] = {c_add(km, Q), c_sub(km, Q), c_sub(kp, Q), c_add(kp, Q)};
+        Q31 num[4]; u32 nrm[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            num[r] = q_sub(num[r], q_add(q_mulm(qb.a_sum, y[r]), qb.b_sum));
-            // den = (Pr.x - x) * Pi.y - (Pr.y - y) * Pi.x in CM31 = kden - x * Pi.y + y * Pi.x (x, y in M31: 4 products instead of 8)
-            den[r].a = m_add(m_sub(qb.kden.a, m_mul(x[r], qb.piy.a)), m_mul(y[r], qb.pix.a));
-            den[r].b = m_add(m_sub(qb.kden.b, m_mul(x[r], qb.piy.b)), m_mul(y[r], qb.pix.b));
+            num[r] = q_make(m_canon(m_fold(n64[r][0]) + m_fold(s64[0])), m_canon(m_fold(n64[r][1]) + m_fold(s64[1])),
+                            m_canon(m_fold(n64[r][2]) + m_fold(s64[2])), m_canon(m_fold(n64[r][3]) + m_fold(s64[3])));
+            num[r] = q_sub(num[r], (r == 0 || r == 3) ? line_p : line_m);
             nrm[r] = m_add(m_sqr(den[r].a), m_sqr(den[r].b));
         }
         u32 p01 = m_mul(nrm[0], nrm[1]), p012 = m_mul(p01, nrm[2]), inv_all = m_inv(m_mul(p012, nrm[3]));
@@ -231,7 +205,7 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
         for (int r = 0; r < 4; r++) {
             C31 dinv = {m_mul(den[r].a, ninv[r]), m_neg(m_mul(den[r].b, ninv[r]))};
             Q31 term = q_mulc(num[r], dinv);
-            acc[r] = b ? q_add(q_mul(acc[r], qb.batch_coeff), term) : term;   // 0 * coeff + term for the first batch
+            acc[r] = b ? q_add(acc[r], term) : term;     // the batches' Horner weights are folded into their constants (host/quotients.h)
         }
     }
     *reinterpret_cast<uint4*>(a.out[0] + row0) = make_uint4(acc[0].a.a, acc[1].a.a, acc[2].a.a, acc[3].a.a);
