@@ -64,7 +64,7 @@ BF_HD Fq combine3(const Lookup& l, Fm a, Fm b, Fm c) { const u32 v[3] = {a.v, b.
 BF_HD Fq combine7(const Lookup& l, Fm a, Fm b, Fm c, Fm d, Fm e, Fm f, Fm g) { const u32 v[7] = {a.v, b.v, c.v, d.v, e.v, f.v, g.v}; return combine_base<7>(l, v); }
 
 // Evaluator concept E:
-//   typename E::F;  F is_first();  F trace();  F cst(u32);
+//   typename E::F;  is_first() -> F, or a tag T with T * F -> a type constraint() accepts;  F trace();  F cst(u32);
 //   void constraint(F) / constraint(Fq);
 //   void logup_mid(Fq numerator, Fq denominator) / logup_last(..) — one per add_to_relation, in order; the last closes the row
 //                                                (add_to_relation + finalize_logup of the reference)
@@ -72,7 +72,7 @@ BF_HD Fq combine7(const Lookup& l, Fm a, Fm b, Fm c, Fm d, Fm e, Fm f, Fm g) { c
 // memory/component.rs:62-137
 template <class E> BF_HD void air_memory(E& e, const Lookups& el) {
     typedef typename E::F F;
-    F is_first = e.is_first();
+    auto is_first = e.is_first();   // F for a per-point evaluator; a tag for the row-group evaluator (the AIRs are linear in IsFirst)
     F clk = e.trace(), mp = e.trace(), mv = e.trace(), d = e.trace(), next_clk = e.trace(), next_mp = e.trace(), next_mv = e.trace(), next_d = e.trace();
     F one = e.cst(1);
     e.constraint(is_first * clk);
@@ -91,7 +91,7 @@ template <class E> BF_HD void air_memory(E& e, const Lookups& el) {
 // instruction/component.rs:65-142
 template <class E> BF_HD void air_instruction(E& e, const Lookups& el) {
     typedef typename E::F F;
-    F is_first = e.is_first();
+    auto is_first = e.is_first();   // F for a per-point evaluator; a tag for the row-group evaluator (the AIRs are linear in IsFirst)
     F ip = e.trace(), ci = e.trace(), ni = e.trace(), d = e.trace(), next_ip = e.trace(), next_ci = e.trace(), next_ni = e.trace(), next_d = e.trace();
     F one = e.cst(1);
     e.constraint(is_first * ip);
@@ -109,7 +109,7 @@ template <class E> BF_HD void air_instruction(E& e, const Lookups& el) {
 // program/component.rs:60-104
 template <class E> BF_HD void air_program(E& e, const Lookups& el) {
     typedef typename E::F F;
-    F is_first = e.is_first();
+    auto is_first = e.is_first();   // F for a per-point evaluator; a tag for the row-group evaluator (the AIRs are linear in IsFirst)
     F ip = e.trace(), ci = e.trace(), ni = e.trace(), d = e.trace();
     F one = e.cst(1);
     e.constraint(is_first * ip);
@@ -121,7 +121,7 @@ template <class E> BF_HD void air_program(E& e, const Lookups& el) {
 // processor/component.rs:79-153 — three relation entries in the order Processor, Instruction, Memory
 template <class E> BF_HD void air_processor(E& e, const Lookups& el) {
     typedef typename E::F F;
-    F is_first = e.is_first();
+    auto is_first = e.is_first();   // F for a per-point evaluator; a tag for the row-group evaluator (the AIRs are linear in IsFirst)
     F clk = e.trace(), ip = e.trace(), ci = e.trace(), ni = e.trace(), mp = e.trace(), mv = e.trace(), mvi = e.trace(), d = e.trace(), next_clk = e.trace();
     F one = e.cst(1);
     e.constraint(is_first * clk);

@@ -12,6 +12,7 @@
 // processor/table.rs:456-529, instructions/table.rs:466, jump/table.rs:436, end_of_execution/table.rs:220).
 #include "kernels.h"
 #include "air.h"
+#include <cstdlib>
 
 namespace bf {
 
@@ -19,6 +20,7 @@ namespace bf {
 // Constraint evaluation
 // ------------------------------------------------------------------------------------------------------------------------------
 typedef ConstraintLaunch ConstraintArgs;   // lives in HBM (staged by the host); read through scalar loads
+
 
 // LDE row (bit-reversed storage, blowup 2) of the point at trace-coset offset -1 from LDE row `row` of a component of 2^log_size rows
 __device__ __forceinline__ u32 prev_lde_row(u32 row, u32 log_size) {
@@ -93,28 +95,167 @@ __global__ void __launch_bounds__(256) k_constraints(const ConstraintArgs* __res
     acc3[row] = m_add(acc3[row], r.b.b);
 }
 
+// ---- row-group variant --------------------------------------------------------------------------------------------------------
+// Every main-trace column and every logUp column but the last is 16x replicated, so within 16 consecutive LDE rows
+// only IsFirst (t), the last logUp column (cur) and its previous-row value (prev) change, and the combined constraint value is affine in
+// them:   sum_j coeff_j c_j  =  A + t * B + K * (cur - prev)      (A, B, K in QM31, functions of the replicated cells only)
+//   base constraints  t * g_j   -> B += coeff_j g_j ; the others -> A += coeff_j c_j
+//   non-last logUp    (cur_k - prev_col) d - n  is replicated    -> A
+//   last logUp        (cur - (prev - total t) - prev_col) d - n  -> K = coeff d, B += K total, A -= K prev_col + coeff n
+// The AIR is evaluated once per group of 16 rows, then 24 products per row instead of ~100. Exact field arithmetic: the same canonical
+// values as the per-row kernel (which stays for columns that are not stored replicated).
+struct IsFirstTag {};
+struct FmT { u32 v; };   // t * v
+__device__ __forceinline__ FmT operator*(IsFirstTag, Fm x) { return {x.v}; }
+
+struct GroupEval {
+    typedef Fm F;
+    const ConstraintArgs& a; u32 row; int ti = 0, ii = 0, ci = 0;
+    u64 accA[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0}; int pendA = 0, pendB = 0;
+    Q31 extA, extB, K, prev_col;
+    __device__ GroupEval(const ConstraintArgs& a_, u32 row_) : a(a_), row(row_) { extA = q_zero(); extB = q_zero(); K = q_zero(); prev_col = q_zero(); }
+    __device__ __forceinline__ IsFirstTag is_first() { return {}; }
+    __device__ __forceinline__ Fm trace() { return {ld_col(a.trace[ti++], row)}; }
+    __device__ __forceinline__ Fm cst(u32 k) { return {k}; }
+    __device__ __forceinline__ void dot(u64 (&acc)[4], int& pending, const Q31& k, u32 v) {
+        if (pending == 3) { for (int w = 0; w < 4; w++) acc[w] = m_fold(acc[w]); pending = 0; }
+        acc[0] += (u64)k.a.a * v; acc[1] += (u64)k.a.b * v; acc[2] += (u64)k.b.a * v; acc[3] += (u64)k.b.b * v;
+        pending++;
+    }
+    __device__ __forceinline__ void constraint(Fm c) { dot(accA, pendA, a.coeff[ci++], c.v); }
+    __device__ __forceinline__ void constraint(FmT c) { dot(accB, pendB, a.coeff[ci++], c.v); }
+    __device__ __forceinline__ void logup_mid(Fq n, Fq d) {
+        const Q31 cur = q_make(ld_col(a.inter[ii], row), ld_col(a.inter[ii + 1], row), ld_col(a.inter[ii + 2], row), ld_col(a.inter[ii + 3], row));
+        ii += 4;
+        const Q31 diff = q_sub(cur, prev_col);
+        prev_col = cur;
+        extA = q_add(extA, q_mul(a.coeff[ci++], q_sub(q_mul(diff, d.v), n.v)));
+    }
+    __device__ __forceinline__ void logup_last(Fq n, Fq d) {
+        const Q31 c = a.coeff[ci++];
+        K = q_mul(c, d.v);
+        extB = q_add(extB, q_mul(K, a.total_sum));
+        extA = q_sub(extA, q_add(q_mul(K, prev_col), q_mul(c, n.v)));
+    }
+    __device__ __forceinline__ Q31 A() { return q_add(q_make(m_canon(accA[0]), m_canon(accA[1]), m_canon(accA[2]), m_canon(accA[3])), extA); }
+    __device__ __forceinline__ Q31 B() { return q_add(q_make(m_canon(accB[0]), m_canon(accB[1]), m_canon(accB[2]), m_canon(accB[3])), extB); }
+};
+
+// One workgroup covers 4096 rows = 256 groups of 16: every lane first evaluates the AIR for one group (replicated cells: consecutive lanes
+// read consecutive stored cells) and leaves A, B, K (times 1/vanishing) in LDS; then every lane walks 4 quads of rows, 256 quads apart, so
+// that the full-size columns and the accumulator are read and written as coalesced 16-byte accesses.
+// Previous row of the last logUp column: in bit-reversed storage prev(row) = row ^ M, M covering only high bits (the leading zeros / ones of
+// row >> 1 and the bit below them; even rows step back in the first half-coset, odd rows forward in the conjugate one), so the four rows of a
+// quad read elements 0, 2 of the quad at prev(r0) and elements 1, 3 of the quad at prev(r0 + 1) - 1 — except next to the wrap-around.
 template <int COMP>
-static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size, u32 n_rows) {
-    u32 n = n_rows ? n_rows : 2u << log_size;
-    ProfScope ps(s, "k_constraints", 0);
-    hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+__global__ void __launch_bounds__(256) k_constraints_block(const ConstraintArgs* __restrict__ ap) {
+    __shared__ uint4 s_abk[256 * 3];
+    const ConstraintArgs& a = *ap;
+    const u32 n = a.n_rows ? a.n_rows : 2u << a.log_size, row_first = a.n_rows ? a.row0 : 0u;
+    const u32 base = blockIdx.x * 4096u;
+    {
+        const u32 rel = base + threadIdx.x * 16u;
+        if (rel < n) {
+            const u32 row = row_first + rel;
+            GroupEval e(a, row);
+            air_eval<COMP>(e, a.el);
+            const u32 dinv = a.denom_inv[row >> a.log_size];      // a group lies in one half of the domain
+            const Q31 A = q_mulm(e.A(), dinv), B = q_mulm(e.B(), dinv), K = q_mulm(e.K, dinv);
+            s_abk[threadIdx.x * 3] = make_uint4(A.a.a, A.a.b, A.b.a, A.b.b);
+            s_abk[threadIdx.x * 3 + 1] = make_uint4(B.a.a, B.a.b, B.b.a, B.b.b);
+            s_abk[threadIdx.x * 3 + 2] = make_uint4(K.a.a, K.a.b, K.b.a, K.b.b);
+        }
+    }
+    __syncthreads();
+    constexpr int last = 4 * ((COMP == C_PROCESSOR ? 3 : 1) - 1);   // first coordinate of the last logUp column (full size)
+    g_cu32p first = as_global(a.is_first);
+    g_cu32p cur_p[4] = {as_global(a.inter[last].ptr), as_global(a.inter[last + 1].ptr), as_global(a.inter[last + 2].ptr), as_global(a.inter[last + 3].ptr)};
+    g_cu32p acc_p[4] = {as_global(a.acc[0]), as_global(a.acc[1]), as_global(a.acc[2]), as_global(a.acc[3])};
+#pragma unroll 1
+    for (u32 i = 0; i < 4; i++) {
+        const u32 q = i * 256u + threadIdx.x, rel = base + 4u * q;
+        if (rel >= n) break;
+        const u32 r0 = row_first + rel;
+        const uint4 a4 = s_abk[(q >> 2) * 3], b4 = s_abk[(q >> 2) * 3 + 1], k4 = s_abk[(q >> 2) * 3 + 2];
+        const Q31 A = q_make(a4.x, a4.y, a4.z, a4.w), B = q_make(b4.x, b4.y, b4.z, b4.w), K = q_make(k4.x, k4.y, k4.z, k4.w);
+        const uint4 t4 = ld16(first + r0);
+        uint4 c4[4];
+        u32 pv[4][4];                                             // [coordinate][row of the quad]
+#pragma unroll
+        for (int w = 0; w < 4; w++) c4[w] = ld16(cur_p[w] + r0);
+        if (a.inter_prev[0]) {                                    // materialised previous-row copy (row-sharded columns)
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const uint4 p = ld16(as_global(a.inter_prev[w]) + r0); pv[w][0] = p.x; pv[w][1] = p.y; pv[w][2] = p.z; pv[w][3] = p.w; }
+        } else {
+            const u32 pr[4] = {prev_lde_row(r0, a.log_size), prev_lde_row(r0 + 1, a.log_size), prev_lde_row(r0 + 2, a.log_size), prev_lde_row(r0 + 3, a.log_size)};
+            if ((pr[0] & 3u) == 0 && pr[2] == pr[0] + 2 && (pr[1] & 3u) == 1 && pr[3] == pr[1] + 2) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint4 pe = ld16(cur_p[w] + pr[0]), po = ld16(cur_p[w] + (pr[1] - 1));
+                    pv[w][0] = pe.x; pv[w][2] = pe.z; pv[w][1] = po.y; pv[w][3] = po.w;
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; w++) { pv[w][0] = cur_p[w][pr[0]]; pv[w][1] = cur_p[w][pr[1]]; pv[w][2] = cur_p[w][pr[2]]; pv[w][3] = cur_p[w][pr[3]]; }
+            }
+        }
+        const u32 t[4] = {t4.x, t4.y, t4.z, t4.w};
+        const u32 cv[4][4] = {{c4[0].x, c4[0].y, c4[0].z, c4[0].w}, {c4[1].x, c4[1].y, c4[1].z, c4[1].w}, {c4[2].x, c4[2].y, c4[2].z, c4[2].w}, {c4[3].x, c4[3].y, c4[3].z, c4[3].w}};
+        u32 out[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const Q31 X = q_make(m_sub(cv[0][r], pv[0][r]), m_sub(cv[1][r], pv[1][r]), m_sub(cv[2][r], pv[2][r]), m_sub(cv[3][r], pv[3][r]));
+            const Q31 v = q_add(q_add(A, q_mulm(B, t[r])), q_mul(K, X));
+            out[0][r] = v.a.a; out[1][r] = v.a.b; out[2][r] = v.b.a; out[3][r] = v.b.b;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint4 o = make_uint4(out[w][0], out[w][1], out[w][2], out[w][3]);
+            if (!a.overwrite) { const uint4 old = ld16(acc_p[w] + r0); o = make_uint4(m_add(old.x, o.x), m_add(old.y, o.y), m_add(old.z, o.z), m_add(old.w, o.w)); }
+            *reinterpret_cast<uint4*>(a.acc[w] + r0) = o;
+        }
+    }
 }
 
-void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size, u32 n_rows) {
+template <int COMP>
+static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size, u32 n_rows, u32 group_rows) {
+    u32 n = n_rows ? n_rows : 2u << log_size;
+    ProfScope ps(s, "k_constraints", 0);
+    if (group_rows) hipLaunchKernelGGL(k_constraints_block<COMP>, dim3((n + 4095) / 4096), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
+// 16 = the row-group kernel applies (every main column and every logUp column but the last stored replicated, shift >= 4, the last one
+// full size), 0 = per-row kernel.
+u32 constraint_group_rows(const ConstraintLaunch& L, int comp) {
+    const u32 last = 4 * (n_logup_cols(comp) - 1);
+    for (u32 j = 0; j < n_main_cols(comp); j++) if (L.trace[j].shift < LOG_N_LANES) return 0;
+    for (u32 j = 0; j < last; j++) if (L.inter[j].shift < LOG_N_LANES) return 0;
+    for (u32 j = last; j < last + 4; j++) if (L.inter[j].shift != 0) return 0;
+    const u32 rows = L.n_rows ? L.n_rows : 2u << L.log_size;
+    if (rows % 16 != 0 || L.row0 % 16 != 0) return 0;
+    // below 512 workgroups the per-row kernel's wider launch wins (measured: equal at 2^20 rows). BFHIP_CONSTRAINT_GROUP_MIN_LOG: test knob
+    // (the suite runs the row-group kernel on small domains too)
+    u32 min_log = 21;
+    if (const char* v = getenv("BFHIP_CONSTRAINT_GROUP_MIN_LOG")) min_log = (u32)atoi(v);
+    return (min_log < 32 && rows >= (1u << min_log)) ? 16 : 0;
+}
+
+void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size, u32 n_rows, u32 group_rows) {
     switch (comp) {
-        case C_MEMORY: launch_c<C_MEMORY>(stream, a, log_size, n_rows); break;
-        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a, log_size, n_rows); break;
-        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a, log_size, n_rows); break;
-        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a, log_size, n_rows); break;
-        case C_JNZ: launch_c<C_JNZ>(stream, a, log_size, n_rows); break;
-        case C_JZ: launch_c<C_JZ>(stream, a, log_size, n_rows); break;
-        case C_INPUT: launch_c<C_INPUT>(stream, a, log_size, n_rows); break;
-        case C_LEFT: launch_c<C_LEFT>(stream, a, log_size, n_rows); break;
-        case C_MINUS: launch_c<C_MINUS>(stream, a, log_size, n_rows); break;
-        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a, log_size, n_rows); break;
-        case C_PLUS: launch_c<C_PLUS>(stream, a, log_size, n_rows); break;
-        case C_RIGHT: launch_c<C_RIGHT>(stream, a, log_size, n_rows); break;
-        default: launch_c<C_EOE>(stream, a, log_size, n_rows); break;
+        case C_MEMORY: launch_c<C_MEMORY>(stream, a, log_size, n_rows, group_rows); break;
+        case C_INSTRUCTION: launch_c<C_INSTRUCTION>(stream, a, log_size, n_rows, group_rows); break;
+        case C_PROGRAM: launch_c<C_PROGRAM>(stream, a, log_size, n_rows, group_rows); break;
+        case C_PROCESSOR: launch_c<C_PROCESSOR>(stream, a, log_size, n_rows, group_rows); break;
+        case C_JNZ: launch_c<C_JNZ>(stream, a, log_size, n_rows, group_rows); break;
+        case C_JZ: launch_c<C_JZ>(stream, a, log_size, n_rows, group_rows); break;
+        case C_INPUT: launch_c<C_INPUT>(stream, a, log_size, n_rows, group_rows); break;
+        case C_LEFT: launch_c<C_LEFT>(stream, a, log_size, n_rows, group_rows); break;
+        case C_MINUS: launch_c<C_MINUS>(stream, a, log_size, n_rows, group_rows); break;
+        case C_OUTPUT: launch_c<C_OUTPUT>(stream, a, log_size, n_rows, group_rows); break;
+        case C_PLUS: launch_c<C_PLUS>(stream, a, log_size, n_rows, group_rows); break;
+        case C_RIGHT: launch_c<C_RIGHT>(stream, a, log_size, n_rows, group_rows); break;
+        default: launch_c<C_EOE>(stream, a, log_size, n_rows, group_rows); break;
     }
 }
 

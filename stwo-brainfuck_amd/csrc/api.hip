@@ -439,7 +439,7 @@ int32_t bfhip_eval_constraints(bfhip_ctx* ctx, int32_t component, uint32_t log_s
     // 1 / coset_vanishing(CanonicCoset(log_size).coset, eval_domain.at(i)) takes two values, by the parity of the (bit-reversed) cell index
     for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log_size, canonic_domain_at(eval_log, i)));
     c.stage_checkpoint();
-    eval_constraints(c.stream, component, c.stage(&L, 1), log_size);
+    eval_constraints(c.stream, component, c.stage(&L, 1), log_size, 0, constraint_group_rows(L, component));
     BF_HIP(hipGetLastError());
     return 0;
     API_CATCH

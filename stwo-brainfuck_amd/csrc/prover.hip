@@ -667,7 +667,7 @@ struct HipProver {
         }
         c.stage_checkpoint();
         const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());   // one copy for the 13 parameter blocks
-        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k], launches[k].n_rows);
+        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k], launches[k].n_rows, constraint_group_rows(launches[k], k));
         BF_HIP(hipGetLastError());
         // finalize (DomainEvaluationAccumulator::finalize): ascending sizes; the reference evaluates the running polynomial on the next
         // populated size, adds the evaluations and interpolates the sum. Interpolation is linear and evaluating a polynomial on a larger

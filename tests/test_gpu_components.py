@@ -59,9 +59,14 @@ def _lde(oracle, cols, log):
     return oracle.evaluate(oracle.interpolate(cols, log), log, log + 1)
 
 
-@pytest.mark.parametrize("replicated", [True, False], ids=["row_granular", "full_size"])
+@pytest.mark.parametrize("replicated", [True, False, "row_group_kernel"], ids=["row_granular", "full_size", "row_group_kernel"])
 @pytest.mark.parametrize("prog", [ALL_OPS, HELLO], ids=["all_ops", "hello"])
-def test_eval_constraints_matches_oracle(ctx, pkg, oracle, prog, replicated):
+def test_eval_constraints_matches_oracle(ctx, pkg, oracle, prog, replicated, monkeypatch):
+    """row_granular / full_size: the per-row kernel on replicated / full-size storage (small domains); row_group_kernel: the kernel that
+    evaluates the AIR once per 16 rows (k_constraints_block, used from 2^21 rows up) forced onto these small domains."""
+    if replicated == "row_group_kernel":
+        monkeypatch.setenv("BFHIP_CONSTRAINT_GROUP_MIN_LOG", "5")
+        replicated = True
     code, inp = prog
     elems = _elems(77)
     for comp in range(N_COMPONENTS):

@@ -39,3 +39,14 @@ def test_random_program_proof_matches_oracle_all_variants(ctx, pkg, oracle, seed
     assert diverged is None, f"{code!r}: transcript diverges at {diverged}"
     assert got == want, code
     assert pkg.verify_brainfuck(got, log_max_rows) == (True, "")
+
+
+@pytest.mark.parametrize("seed", [501, 502, 503, 504, 505, 506, 507, 508])
+def test_random_program_proof_matches_oracle_row_group_constraint_kernel(ctx, pkg, oracle, seed, monkeypatch):
+    """The row-group constraint kernel (production: domains of 2^21 rows and more; covered at full size by the fib19 digest tests) forced
+    onto small traces: whole proofs still equal the oracle's."""
+    monkeypatch.setenv("BFHIP_CONSTRAINT_GROUP_MIN_LOG", "5")
+    code, inp, _ = random_program(seed, 2000, min_steps=100)
+    log_max_rows = max(max(oracle.log_sizes(code, inp)[0]), 8)
+    want, _, _ = oracle.prove(code, inp, log_max_rows=log_max_rows)
+    assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows) == want

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 --kernel-trace CSV and lists, for the LAST proof in the trace, every circle-FFT launch with its grid and duration,
-then totals per (kernel, grid). Usage: fft_launches.py <kernel_trace.csv>"""
+then totals per (kernel, grid). Usage: fft_launches.py <kernel_trace.csv> [kernel name prefix = k_fft]"""
 import csv
 import sys
 from collections import defaultdict
 
 
 def main():
+    prefix = sys.argv[2] if len(sys.argv) > 2 else "k_fft"
     rows = []
     with open(sys.argv[1]) as f:
         for r in csv.DictReader(f):
@@ -19,13 +20,13 @@ def main():
     agg = defaultdict(lambda: [0, 0.0])
     tot = 0.0
     for s, e, name, gx, gy, wx in rows:
-        if not name.startswith("k_fft"):
+        if not name.startswith(prefix):
             continue
         us = (e - s) / 1e3
         tot += us
         key = (name, gx // max(wx, 1), gy)
         agg[key][0] += 1; agg[key][1] += us
-    print(f"FFT kernels of the last proof: {tot / 1e3:.3f} ms")
+    print(f"{prefix}* kernels of the last proof: {tot / 1e3:.3f} ms")
     for (name, bx, by), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{name:28s} blocks {bx:6d} x {by:3d}  launches {n:3d}  total {us:9.1f} us  avg {us / n:8.1f} us")
 
