@@ -18,11 +18,17 @@ cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_s
 rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --steps 3 --warmup 1 > /dev/null 2>&1
 python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
 python3 "$ROOT/tools/fft_launches.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) > "$OUT/${R}_fft_launches.txt" 2>&1
+for K in k_quotients k_constraints k_fold k_eval; do python3 "$ROOT/tools/fft_launches.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) $K | head -12; done > "$OUT/${R}_field_kernel_launches.txt" 2>&1
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sweep > "$OUT/pmc_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/${R}_pmc_traffic.json"
+# 3b. effective clock and issue-slot accounting of the Merkle kernel and of the register-only Blake2s micro-benchmark (one counter pass each)
+CNT="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"
+rm -rf /tmp/prof_clock; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_clock -- python3 "$ROOT/tools/merkle_shapes.py" > /dev/null 2>&1
+python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_clock > "$OUT/${R}_merkle_clock.json" 2>&1
+hipcc -O3 --offload-arch=gfx950 -o /tmp/ubench_blake "$ROOT/tools/ubench_blake.hip" 2>/dev/null && { rm -rf /tmp/prof_ub; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_ub -- /tmp/ubench_blake > /dev/null 2>&1; python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_ub k_bench > "$OUT/${R}_ubench_blake_clock.json" 2>&1; }
 # 4. FFT kernel run (BASELINE config 3 (i)), Merkle shapes, one-call end-to-end, large synthetic trace
 python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
 python3 "$ROOT/tools/merkle_shapes.py" > "$OUT/${R}_merkle_shapes.txt" 2>&1
