@@ -148,37 +148,44 @@ struct HipProver {
     // no_readback: the root stays on the device (the caller collects it; FRI commit phase).
     // step: FRI commit phase — the device channel mixes the root and draws the next alpha right behind the tree (fused into the top kernel).
     struct ChannelStep { u32* chan; u32* alpha8; u32* root_copy; };
-    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
+    // A tree is committed in two steps so that several trees can share ONE staging copy (the FRI commit phase plans all its layers first:
+    // every separate copy is a ~9 us blit in front of the kernels that need it): merkle_plan = host-side layout (levels, replication shifts,
+    // arena storage, column descriptors written to the staging ring — inside the caller's StageBatch), merkle_run = the launches.
+    struct MerklePlan {
+        DevMerkle mk; std::vector<DCol> cols; std::vector<size_t> off; std::vector<double> bytes; size_t n_all = 0;
+        const ColDesc* d_all = nullptr; void* const* dl = nullptr; u32 fused_top = 0; bool poseidon = false;
+    };
+    MerklePlan merkle_plan(const std::vector<DCol>& cols_in) {
         if (cols_in.empty()) throw HipError("merkle_commit: no columns");
-        std::vector<DCol> cols = cols_in;
+        MerklePlan p;
+        p.cols = cols_in;
+        std::vector<DCol>& cols = p.cols;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
-        c.stage_checkpoint();
-        DevMerkle mk;
+        DevMerkle& mk = p.mk;
         mk.max_log = cols[0].log_size;
         mk.layers.resize(mk.max_log + 1);
         mk.shifts.assign(mk.max_log + 1, 0);
         u32 min_col_log = cols.back().log_size;
         // one staging copy for the column descriptors of every level; replication shift of every level
-        std::vector<ColDesc> all; std::vector<size_t> off(mk.max_log + 2, 0); std::vector<double> bytes(mk.max_log + 1, 0.0);
+        std::vector<ColDesc> all; p.off.assign(mk.max_log + 2, 0); p.bytes.assign(mk.max_log + 1, 0.0);
         {
             size_t ci = 0;
             for (int log = (int)mk.max_log; log >= 0; log--) {
-                off[log] = all.size();
+                p.off[log] = all.size();
                 u32 sh = log < (int)mk.max_log ? (mk.shifts[log + 1] ? mk.shifts[log + 1] - 1 : 0) : 32;
-                while (ci < cols.size() && cols[ci].log_size == (u32)log) { sh = std::min(sh, cols[ci].shift); bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
+                while (ci < cols.size() && cols[ci].log_size == (u32)log) { sh = std::min(sh, cols[ci].shift); p.bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
                 mk.shifts[log] = std::min<u32>(sh == 32 ? 0 : sh, (u32)log);
                 mk.layers[log] = (u32*)c.arena.alloc((size_t(32) << log) >> mk.shifts[log]);
             }
         }
-        const bool poseidon = c.conv.merkle_channel == 1;   // Poseidon252MerkleHasher: layer kernel of poseidon.hip, no fused top, host channel
-        if (poseidon && step) throw HipError("the device-side channel step is a Blake2s path");
+        p.n_all = all.size();
+        p.poseidon = c.conv.merkle_channel == 1;   // Poseidon252MerkleHasher: layer kernel of poseidon.hip, no fused top, host channel
         u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
         while (fused_top > 0 && mk.shifts[fused_top] != 0) fused_top--;   // the fused kernel expects un-replicated layers
-        if (mk.shifts[fused_top] != 0 || poseidon) fused_top = 0;
-        StageBatch sb(c);
-        const ColDesc* d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
-        void* const* dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
-        sb.end();
+        if (mk.shifts[fused_top] != 0 || p.poseidon) fused_top = 0;
+        p.fused_top = fused_top;
+        p.d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
+        p.dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
         // Shard group: the un-replicated layers with at least 256 nodes per rank are hashed share-wise; the smallest of them is
         // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
         const ShardGroup& sg = c.shard;
@@ -195,17 +202,25 @@ struct HipProver {
             // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
             for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
+        return p;
+    }
+    DevMerkle merkle_run(MerklePlan& p, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
+        DevMerkle& mk = p.mk;
+        const ShardGroup& sg = c.shard;
+        const bool poseidon = p.poseidon;
+        const u32 fused_top = p.fused_top;
+        if (poseidon && step) throw HipError("the device-side channel step is a Blake2s path");
         const char* layer_kernel = poseidon ? "k_merkle_layer_poseidon" : "k_merkle_layer";
         prof_run_begin(c.stream, layer_kernel);
         for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
-            size_t n = (log > 0 ? off[log - 1] : all.size()) - off[log];
+            size_t n = (log > 0 ? p.off[log - 1] : p.n_all) - p.off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? ((1u << (log - mk.shifts[log])) >> sg.log_count) : 0u;   // in stored slots
             if (poseidon)
-                merkle_layer_poseidon(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log,
+                merkle_layer_poseidon(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? p.d_all + p.off[log] : nullptr, (u32)n, (u32)log,
                                       mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, sg.rank * per_rank, per_rank);
             else
-                merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? d_all + off[log] : nullptr, (u32)n, (u32)log, bytes[log],
+                merkle_layer(c.stream, mk.layers[log], log < (int)mk.max_log ? mk.layers[log + 1] : nullptr, n ? p.d_all + p.off[log] : nullptr, (u32)n, (u32)log, p.bytes[log],
                              mk.shifts[log], log < (int)mk.max_log ? mk.shifts[log + 1] : 0, c.conv.merkle_node_hash, sg.rank * per_rank, per_rank);
             if (share && log == mk.band_lo) {
                 // the smallest share-wise layer is completed on every rank by one all-gather on the device buffer (rank r's block = its
@@ -216,13 +231,20 @@ struct HipProver {
             }
         }
         prof_run_end(c.stream);
-        if (fused_top > 0) merkle_top(c.stream, dl, fused_top, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
+        if (fused_top > 0) merkle_top(c.stream, p.dl, fused_top, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
         if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
         c.read_back(mk.root.b, mk.layers[0], 32);
         return mk;
+    }
+    DevMerkle merkle_commit(const std::vector<DCol>& cols_in, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
+        c.stage_checkpoint();
+        StageBatch sb(c);
+        MerklePlan p = merkle_plan(cols_in);
+        sb.end();
+        return merkle_run(p, pinned_root, no_readback, step);
     }
 
     // MerkleProver::decommit — control flow on the host, data through one gather.
@@ -868,8 +890,33 @@ struct HipProver {
         // Poseidon252Channel is stepped on the host (one root read-back per layer): two serial Hades permutations by a single lane would
         // cost more than the round trip. commit_step = Merkle tree of a layer + mix_root + draw alpha (alpha || alpha^2 -> d_alpha[idx]).
         const bool host_channel = c.conv.merkle_channel == 1;
-        auto commit_step = [&](const std::vector<DCol>& cols, u32 alpha_idx, u32 root_idx) -> DevMerkle {
-            if (!host_channel) { ChannelStep st{d_chan, d_alpha + 8 * alpha_idx, d_roots + 8 * root_idx}; return merkle_commit(cols, nullptr, /*no_readback=*/true, &st); }
+        u32 line_log = quotients[0].log_size - 1;
+        const u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
+        if (line_log > last_log + max_layers) throw HipError("FRI: too many layers");
+        // Shard group: a layer with >= 2^14 rows per rank is row-sharded like the quotients (a fold maps the sibling pair (2i, 2i+1) to cell
+        // i, so a rank's row range of the source folds into its row range of the destination). The first layer below that size is produced
+        // range-wise into a complete buffer and finished by one all-gather; everything smaller is folded redundantly on every rank.
+        auto new_layer = [&](u32 log) {
+            DSecure l; l.log_size = log; l.lc = slice_log(log) ? lc() : 0;
+            for (int w = 0; w < 4; w++) l.c[w] = l.lc ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
+            return l;
+        };
+        // Every layer's storage and (device channel) every tree's layout exist before the first launch: the column descriptors and level
+        // tables of all ~26 trees reach the device in ONE staging copy instead of one in front of every layer of the serial chain.
+        const u32 n_inner = line_log > last_log ? line_log - last_log : 0;
+        std::vector<DSecure> layers(n_inner + 1);
+        for (u32 i = 0; i <= n_inner; i++) layers[i] = new_layer(line_log - i);
+        std::vector<MerklePlan> plans;                  // [0] first layer, [1 + i] inner layer i
+        if (!host_channel) {
+            c.stage_checkpoint();
+            StageBatch sb(c);
+            plans.reserve(n_inner + 1);
+            plans.push_back(merkle_plan(first_cols));
+            for (u32 i = 0; i < n_inner; i++) plans.push_back(merkle_plan(secure_cols(layers[i])));
+            sb.end();
+        }
+        auto commit_step = [&](size_t plan_idx, const std::vector<DCol>& cols, u32 alpha_idx, u32 root_idx) -> DevMerkle {
+            if (!host_channel) { ChannelStep st{d_chan, d_alpha + 8 * alpha_idx, d_roots + 8 * root_idx}; return merkle_run(plans[plan_idx], nullptr, /*no_readback=*/true, &st); }
             DevMerkle t = merkle_commit(cols);
             ch.mix_root(t.root);
             const Q31 a = ch.draw_felt(), sq = q_mul(a, a);
@@ -879,28 +926,17 @@ struct HipProver {
             BF_HIP(hipMemcpyAsync(d_alpha + 8 * alpha_idx, st, 32, hipMemcpyDeviceToDevice, c.stream));
             return t;
         };
-        DevMerkle first_tree = commit_step(first_cols, 0, 0);
+        DevMerkle first_tree = commit_step(0, first_cols, 0, 0);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
-        u32 line_log = quotients[0].log_size - 1;
-        // Shard group: a layer with >= 2^14 rows per rank is row-sharded like the quotients (a fold maps the sibling pair (2i, 2i+1) to cell
-        // i, so a rank's row range of the source folds into its row range of the destination). The first layer below that size is produced
-        // range-wise into a complete buffer and finished by one all-gather; everything smaller is folded redundantly on every rank.
-        auto new_layer = [&](u32 log) {
-            DSecure l; l.log_size = log; l.lc = slice_log(log) ? lc() : 0;
-            for (int w = 0; w < 4; w++) l.c[w] = l.lc ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
-            return l;
-        };
         // destination range of a fold whose SOURCE has 2^src_log rows: the image of this rank's source range when the source is sharded
         auto fold_range = [&](u32 src_log, bool src_sliced, u32& first, u32& count) {
             if (src_sliced) { first = (u32)(slice_first(src_log) >> 1); count = (u32)(slice_cells(src_log) >> 1); } else { first = 0; count = 0; }
         };
-        DSecure layer = new_layer(line_log);
+        DSecure layer = layers[0];
         bool layer_fresh = true;                     // nothing folded into `layer` yet: the first circle fold writes it (no zero fill)
         bool layer_partial = false;                  // a complete (unsharded) buffer of which every rank has filled only its range so far
         size_t qi = 0;
-        u32 last_log = cfg.log_last_layer_degree_bound + cfg.log_blowup;
-        if (line_log > last_log + max_layers) throw HipError("FRI: too many layers");
         while (line_log > last_log) {
             while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
                 const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
@@ -916,8 +952,8 @@ struct HipProver {
             }
             Inner in; in.ev = layer;
             cur_alpha++;
-            in.tree = commit_step(secure_cols(layer), cur_alpha, (u32)(1 + inner.size()));
-            DSecure next = new_layer(line_log - 1);
+            in.tree = commit_step(1 + inner.size(), secure_cols(layer), cur_alpha, (u32)(1 + inner.size()));
+            DSecure next = layers[inner.size() + 1];
             const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
             u32 first, count; fold_range(line_log, layer.lc != 0, first, count);
             if (layer.lc != 0 && next.lc == 0) layer_partial = true;
