@@ -89,6 +89,7 @@ static void join_group(bfhip_ctx* ctx, std::unique_ptr<Comm> comm) {
     u32 count = comm->count, lc = 0;
     while ((1u << lc) < count) lc++;
     ctx->c.sync();
+    preprocessed_cache_invalidate(&ctx->c);
     ShardGroup g; g.rank = comm->rank; g.count = count; g.log_count = lc; g.comm = std::shared_ptr<Comm>(std::move(comm));
     ctx->c.shard = g;
 }
@@ -158,6 +159,7 @@ int32_t bfhip_rccl_selftest(bfhip_ctx* ctx) {
 int32_t bfhip_ctx_leave_group(bfhip_ctx* ctx) {
     API_CTX(ctx)
     ctx->c.sync();
+    preprocessed_cache_invalidate(&ctx->c);
     ctx->c.shard = ShardGroup();
     return 0;
     API_CATCH

@@ -103,6 +103,8 @@ struct Ctx {
 };
 
 // Scope of one staging batch: blocks staged inside are moved by one copy at end(); an exception unwinds the batch without copying.
+void preprocessed_cache_invalidate(Ctx* c);   // prover.hip: called when the context joins or leaves a shard group
+
 struct StageBatch {
     Ctx& c; bool open = true;
     explicit StageBatch(Ctx& c_) : c(c_) { c.stage_begin(); }

@@ -96,6 +96,14 @@ struct PreprocessedCache {
 static std::mutex g_cache_mutex;   // contexts may be driven from different host threads (bench.py --inflight)
 static std::map<Ctx*, PreprocessedCache>& preprocessed_caches() { static std::map<Ctx*, PreprocessedCache> m; return m; }
 static PreprocessedCache& preprocessed_cache_of(Ctx* c) { std::lock_guard<std::mutex> g(g_cache_mutex); return preprocessed_caches()[c]; }   // map nodes are address-stable
+// Group membership changes drop the cached tree: the ranks of a group must take the same decision (reuse or rebuild with its exchanges) in
+// every proof, and they do when each starts its membership with an empty cache and then issues the group's common sequence of calls. (A cache
+// that survived an earlier membership could match on some ranks only — found by tools/fuzz_campaign.py persistent, seed 60806.)
+void preprocessed_cache_invalidate(Ctx* c) {
+    std::lock_guard<std::mutex> g(g_cache_mutex);
+    auto it = preprocessed_caches().find(c);
+    if (it != preprocessed_caches().end()) it->second.valid = false;
+}
 
 struct PhaseTimes { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, decommit = 0, tables = 0, total = 0; };
 

@@ -83,6 +83,48 @@ def test_fib19_full_size_in_a_shard_group(pkg, count):
         assert hashlib.sha256(p).hexdigest() == want["sha256"]
 
 
+def test_preprocessed_cache_does_not_survive_a_membership(pkg):
+    """Long-lived contexts with the preprocessed-tree cache on, regrouped between proofs: 4 ranks, then ranks 0-1 alone on another size,
+    then the 4 again. A cache that outlived the first membership matched on ranks 2-3 only, the group's exchanges diverged ("unmatched
+    send/receive", tools/fuzz_campaign.py persistent, seed 60806). Joining or leaving a group now drops the cached tree."""
+    big = open(os.path.join(PROGS, "hello_kakarot.bf")).read()
+    small = "++>,<[>+.<-]"
+    ctxs = [pkg.Context(0, max_log_domain=19) for _ in range(4)]
+    single = pkg.prove_brainfuck(big, b"", ctx=ctxs[0], log_max_rows=17)
+    for c in ctxs:
+        pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 1)
+
+    def round_(members, code, inp, lmr):
+        group = pkg.LocalGroup(len(members))
+        out, errors = [None] * len(members), []
+
+        def run(r):
+            try:
+                members[r].join_local_group(group, r)
+                out[r] = [pkg.prove_brainfuck(code, inp, ctx=members[r], log_max_rows=lmr) for _ in range(2)]   # second proof: cache hit
+            except Exception as e:
+                errors.append(e)
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(len(members))]
+        [t.start() for t in th]; [t.join() for t in th]
+        for c in members:
+            c.leave_group()
+        group.close()
+        assert not errors, errors
+        return out
+
+    try:
+        for pair in round_(ctxs, big, b"", 17):
+            assert pair[0] == single and pair[1] == single
+        round_(ctxs[:2], small, b"\x01", 16)
+        for pair in round_(ctxs, big, b"", 17):
+            assert pair[0] == single and pair[1] == single
+    finally:
+        for c in ctxs:
+            pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 0)
+            c.close()
+
+
 def test_shard_arguments_are_checked(pkg, ctx):
     with pytest.raises(pkg.BfhipError, match="power of two"):
         pkg.LocalGroup(3)
