@@ -205,7 +205,9 @@ int32_t bfhip_ctx_group_info(bfhip_ctx* ctx, uint32_t* rank, uint32_t* count, co
 
 /* Optional (off by default): keep the preprocessed tree (IsFirst(LOG_MAX_ROWS..=4): polynomials, LDE columns, Merkle layers, root) of
  * the first proof in the context and reuse it for later proofs with the same LOG_MAX_ROWS. The reference recommits it in every
- * prove_brainfuck call (mod.rs:495-500); proof bytes are identical either way. Call with on = 0 before bfhip_ctx_destroy to release it. */
+ * prove_brainfuck call (mod.rs:495-500); proof bytes are identical either way. Call with on = 0 before bfhip_ctx_destroy to release it.
+ * Joining or leaving a shard group drops the cached tree (it is rebuilt by the next proof): the ranks of a group must all reuse or all rebuild,
+ * which holds when every rank sets this option the same way and starts its membership with an empty cache. */
 int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on);
 
 /* The two halves of prove_brainfuck, so that a caller (and the benchmark) can keep the prover input resident in HBM:
