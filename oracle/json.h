@@ -90,8 +90,20 @@ struct JsonParser {
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }
         } else if (*p == '"') { p++; const char* s0 = p; while (p < end && *p != '"') p++; if (p >= end) throw std::runtime_error("json: string"); v.kind = JVal::STR; v.str.assign(s0, p); p++; }
-        else if (*p == 'n') { if (end - p < 4) throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
-        else if (*p >= '0' && *p <= '9') { v.kind = JVal::NUM; u64 x = 0; while (p < end && *p >= '0' && *p <= '9') { x = x * 10 + (u64)(*p - '0'); p++; } v.num = x; }
+        else if (*p == 'n') { if (end - p < 4 || std::string(p, p + 4) != "null") throw std::runtime_error("json: null"); p += 4; v.kind = JVal::NUL; }
+        else if (*p >= '0' && *p <= '9') {
+            // what serde_json takes for a u32 / u64 field: a plain decimal integer below 2^64 without leading zeros, fraction or exponent
+            // (a reader that wraps modulo 2^64 would accept 2^64 + v in place of v)
+            v.kind = JVal::NUM; u64 x = 0; const char* first = p;
+            for (; p < end && *p >= '0' && *p <= '9'; p++) {
+                const u64 digit = (u64)(*p - '0');
+                if (x > 1844674407370955161ull || (x == 1844674407370955161ull && digit > 5)) throw std::runtime_error("json: integer does not fit 64 bits");
+                x = x * 10 + digit;
+            }
+            if (*first == '0' && p - first > 1) throw std::runtime_error("json: leading zero");
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) throw std::runtime_error("json: not an integer");
+            v.num = x;
+        }
         else throw std::runtime_error("json: unexpected char");
         return v;
     }
@@ -134,6 +146,8 @@ static inline FriLayerProof j_fri_layer(const JVal& v) {
 static inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     JsonParser jp{s, s + len};
     JVal root = jp.parse();
+    jp.ws();
+    if (jp.p != jp.end) throw std::runtime_error("json: bytes after the proof object");   // serde_json::from_slice refuses trailing characters
     BrainfuckProof bp;
     for (int c = 0; c < N_COMPONENTS; c++) {
         bp.log_sizes[c] = (u32)root.get("claim").get(CLAIM_KEYS[c]).get("log_size").num;

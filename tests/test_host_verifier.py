@@ -75,3 +75,22 @@ def test_rejects_garbage(pkg):
 
 def test_rejects_wrong_log_max_rows(pkg, proof):
     assert not pkg.verify_brainfuck(proof, 13)[0]
+
+
+def test_verifiers_agree_on_mutated_proofs(pkg, oracle, proof, conv):
+    """Differential check (a fixed slice of tools/fuzz_verifier.py): structural and textual mutations of a valid proof get the same verdict
+    from the product's verifier and the oracle's — here always a rejection. The campaign found the oracle's JSON reader wrapping 2^64 + v to v
+    and ignoring bytes after the proof object (round 2); both readers now take exactly what serde_json takes."""
+    import json, os, random, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_verifier import mutate, text_mutations
+    rng = random.Random(7)
+    tree = json.loads(proof)
+    cases = [(json.dumps(m, separators=(",", ":")).encode(), what) for m, what in filter(None, (mutate(tree, rng) for _ in range(120)))]
+    cases += text_mutations(proof, rng)
+    assert len(cases) > 80
+    for js, what in cases:
+        a = pkg.verify_brainfuck(js, 12, conv)[0]
+        b = oracle.verify(js, 12)[0]
+        assert a == b, what
+        assert not a, f"both verifiers accept the proof after: {what}"
