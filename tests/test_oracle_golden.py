@@ -164,3 +164,15 @@ def test_host_run_ram_size(pkg):
     assert L.bfhip_host_run_ram(code, b"", ctypes.c_size_t(0), ctypes.c_size_t(0), *args) != 0          # 0 = the default size
     assert L.bfhip_host_run_ram(code, b"", ctypes.c_size_t(0), ctypes.c_size_t(30001), *args) == 0
     assert n_rows.value == 30002
+
+
+@pytest.mark.single_conv
+def test_host_side_agrees_with_the_oracle_on_unconstrained_programs(pkg, oracle):
+    """A fixed slice of tools/fuzz_vm.py: random strings over the instruction set — most are invalid or fail at run time. Compile status and
+    words, run status, output, register trace and all 13 tables of the product's host side equal the oracle's."""
+    import random, subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_vm.py"), "8", "424242"], capture_output=True, text=True, timeout=300)
+    d = json.loads(r.stdout)
+    assert r.returncode == 0 and d["ok"], d["problems"]
+    assert d["programs"] > 2000 and d["compile_errors"] > 100 and d["run_errors"] > 100 and d["ran"] > 300 and d["tables_compared"] > 3000
