@@ -53,6 +53,7 @@ static inline Table memory_table(const std::vector<Registers>& trace) {
         if (k > 0) { const Registers& p = trace[order[k - 1]]; u32 nc = madd(p.clk, 1); if (e.mp == p.mp && e.clk > nc) n += e.clk - nc; }
         n++;
     }
+    if (n > (size_t(1) << 28)) throw std::runtime_error("the Memory table would have more than 2^28 rows (2^32 domain rows): not a provable trace");
     size_t rows = next_pow2(n);
     t.init(8, rows);
     u32 *clk = t.cols[0].data(), *mp = t.cols[1].data(), *mv = t.cols[2].data(), *d = t.cols[3].data();

@@ -171,16 +171,24 @@ __global__ void __launch_bounds__(256) k_pair4(const u32* __restrict__ a0, const
 
 // ---- memory table: memory/table.rs:249-251 (sort), :259-283 (clk-gap fill), :291-303 (pad), :121-151 (pairing) --------------------------------
 // count[i] = 1 + number of dummies inserted before sorted entry i
-__global__ void __launch_bounds__(256) k_memory_counts(TraceSoA t, const u32* __restrict__ order, u32* __restrict__ counts) {
+__global__ void __launch_bounds__(256) k_memory_counts(TraceSoA t, const u32* __restrict__ order, u32* __restrict__ counts, unsigned long long* __restrict__ total64) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.n) return;
-    u32 c = 1;
-    if (i > 0) {
-        u32 k = order[i], kp = order[i - 1];
-        u32 next_clk = m_add(t.clk[kp], 1);
-        if (t.mp[k] == t.mp[kp] && t.clk[k] > next_clk) c += t.clk[k] - next_clk;
+    u32 c = 0;
+    if (i < t.n) {
+        c = 1;
+        if (i > 0) {
+            u32 k = order[i], kp = order[i - 1];
+            u32 next_clk = m_add(t.clk[kp], 1);
+            if (t.mp[k] == t.mp[kp] && t.clk[k] > next_clk) c += t.clk[k] - next_clk;
+        }
+        counts[i] = c;
     }
-    counts[i] = c;
+    // exact row total in 64 bits (the u32 prefix sums wrap on register rows that are not a VM trace: bfhip_trace_create_from_registers
+    // takes caller data) — one atomic per wave
+    unsigned long long s = c;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total64, s);
 }
 // entries (clk, mp, mv, d) of size rows + 1, produced from the output side: entry j belongs to the sorted trace row i with pos[i] <= j < pos[i] + count[i]
 __global__ void __launch_bounds__(256) k_memory_entries(TraceSoA t, const u32* __restrict__ order, const u32* __restrict__ pos, const u32* __restrict__ total_ptr, u32 rows,
@@ -243,7 +251,9 @@ void build_tables_device(Ctx& c, const std::vector<u32> trace7_soa[7], u32 n, co
     hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, s, t.mp, t.clk, keys, vals, n);
     BF_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys, keys_sorted, vals, mem_order, n, 0, 64, s));
     u32* mem_counts = tmp_u32(n); u32* mem_pos = tmp_u32(n); u32* mem_tot = tmp_u32(nb + 2);
-    hipLaunchKernelGGL(k_memory_counts, dim3((n + 255) / 256), dim3(256), 0, s, t, mem_order, mem_counts);
+    unsigned long long* d_mem_total64 = (unsigned long long*)c.arena.alloc(256);
+    BF_HIP(hipMemsetAsync(d_mem_total64, 0, 8, s));
+    hipLaunchKernelGGL(k_memory_counts, dim3((n + 255) / 256), dim3(256), 0, s, t, mem_order, mem_counts, d_mem_total64);
     const u32* d_mem_total = exclusive_scan_u32(s, mem_counts, mem_pos, mem_tot, n);
     // instruction: sort by (ip, clk)
     hipLaunchKernelGGL(k_make_keys, dim3((n + 255) / 256), dim3(256), 0, s, t.ip, t.clk, keys, vals, n);
@@ -252,7 +262,10 @@ void build_tables_device(Ctx& c, const std::vector<u32> trace7_soa[7], u32 n, co
     u32 h_counts[9];
     for (int q = 0; q < 8; q++) BF_HIP(hipMemcpyAsync(&h_counts[q], d_count[q], 4, hipMemcpyDeviceToHost, s));
     BF_HIP(hipMemcpyAsync(&h_counts[8], d_mem_total, 4, hipMemcpyDeviceToHost, s));
+    unsigned long long h_mem_total64 = 0;
+    BF_HIP(hipMemcpyAsync(&h_mem_total64, d_mem_total64, 8, hipMemcpyDeviceToHost, s));
     c.sync();
+    if (h_mem_total64 > (1ull << 28)) throw HipError("the Memory table would have more than 2^28 rows (2^32 domain rows): not a provable trace");
 
     auto make_cols = [&](int comp, u32 ncols, u32 rows) {
         cols_out[comp].resize(ncols);

@@ -217,6 +217,18 @@ def test_trace_from_registers_equals_trace_from_source(pkg, oracle, ctx):
     bad = rows.copy(); bad[1, 4] = (1 << 31) - 1          # not a canonical M31
     with pytest.raises(pkg.BfhipError, match="canonical"):
         pkg.Trace.from_registers(ctx, bad, oracle.compile(code))
+    # register rows that are not a VM trace: clk gaps whose dummy-row total overflows 32 bits — refused by both table builders, not wrapped
+    import numpy as np
+    wild = np.repeat(rows[:1], 8, axis=0).copy()
+    wild[:, 0] = [0, 2_000_000_000, 5, 2_100_000_000, 7, 2_147_000_000, 9, 2_147_483_000]
+    wild[:, 4] = [1, 1, 2, 2, 3, 3, 4, 4]
+    for on_gpu in (True, False):
+        ctx.set_table_builder(on_gpu)
+        try:
+            with pytest.raises(pkg.BfhipError, match="2\\^28 rows"):
+                pkg.Trace.from_registers(ctx, wild, oracle.compile(code))
+        finally:
+            ctx.set_table_builder(True)
 
 
 def test_ram_size_option(pkg, ctx):
