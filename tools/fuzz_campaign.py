@@ -75,7 +75,9 @@ def persistent(budget, seed):
         count = rng.choice((1, 1, 2, 4, 8))
         reuse = rng.random() < 0.4
         slack = rng.choice((0, 0, 1, 2))
-        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack}
+        gpu_tables = rng.random() < 0.7
+        via_trace = rng.random() < 0.5
+        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack, "gpu_tables": gpu_tables, "via_trace": via_trace}
         try:
             code, inp, steps = program(seed, cls, bound)
             orc.set_conventions(*conv)
@@ -95,8 +97,16 @@ def persistent(budget, seed):
                     pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 1 if reuse else 0)
                     if group is not None:
                         c.join_local_group(group, r)
+                    c.set_table_builder(gpu_tables)
                     a = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
-                    b = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)      # second proof: the cached tree (if on), a warm arena
+                    if via_trace:                                                    # second proof: the cached tree (if on), a warm arena,
+                        tr = pkg.Trace(c, code, inp)                                 # and the resident-trace entry instead of the one-call entry
+                        try:
+                            b = tr.prove(lmr)[0]
+                        finally:
+                            tr.close()
+                    else:
+                        b = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
                     proofs[r] = (a, b)
                 except Exception as e:
                     errors.append(repr(e))
