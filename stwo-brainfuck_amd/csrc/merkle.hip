@@ -178,17 +178,27 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
 // With chan != nullptr the workgroup's first lane then performs the channel step on the fresh root (FRI commit phase): one launch less
 // per layer on the latency-bound path root -> alpha -> next fold.
 __global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
+    // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
+    // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
+    __shared__ uint4 s_lv[2][1024];
     for (int lg = (int)top_log - 1; lg >= 0; lg--) {
         const uint4* prev = layers[lg + 1];
         uint4* out = layers[lg];
+        const bool from_lds = lg + 1 < (int)top_log && lg + 1 <= 9;      // level lg + 1 was produced by this kernel and fits a buffer (<= 512 nodes)
+        const uint4* src = s_lv[(lg + 1) & 1];
+        uint4* dst = s_lv[lg & 1];
         for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
             u32 h[8], m[16];
             node_init(h, rfc);
-            uint4 a = prev[4 * i], b = prev[4 * i + 1], c = prev[4 * i + 2], d = prev[4 * i + 3];
+            uint4 a, b, c, d;
+            if (from_lds) { a = src[4 * i]; b = src[4 * i + 1]; c = src[4 * i + 2]; d = src[4 * i + 3]; }
+            else { a = prev[4 * i]; b = prev[4 * i + 1]; c = prev[4 * i + 2]; d = prev[4 * i + 3]; }
             m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
             m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
             blake2s_compress(h, m, 64u & rfc, rfc);
-            out[2 * i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * i + 1] = make_uint4(h[4], h[5], h[6], h[7]);
+            const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
+            out[2 * i] = lo; out[2 * i + 1] = hi;
+            if (lg <= 9) { dst[2 * i] = lo; dst[2 * i + 1] = hi; }
         }
         __threadfence_block();
         __syncthreads();
