@@ -3,7 +3,7 @@
 seeded random Brainfuck programs of four size classes, every convention set (Poseidon252 on the smaller classes — its CPU oracle is slow),
 proved (a) by the CPU oracle, (b) by one context, (c) by a local shard group of 2/4/8 contexts. All proofs of one case must be the
 same bytes and both verifiers must accept them. Prints one JSON summary; exit code 1 on any mismatch.
-Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000] [fresh|persistent]
+Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000] [fresh|persistent] [xl case every n-th = 11]
 persistent: ONE set of 8 long-lived contexts instead of fresh ones per case — between cases they join and leave groups of changing size,
 switch conventions, toggle the preprocessed-tree cache and prove with LOG_MAX_ROWS above the trace's need (state carried across proofs:
 arena, caches, staging ring, group membership)."""
@@ -155,11 +155,12 @@ def main():
     orc = Oracle()
     orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
     convs = list(CONVENTIONS.items())
+    xl_every = int(sys.argv[4]) if len(sys.argv) > 4 else 11
     t_end = time.time() + budget
     summary = {"seconds": budget, "first_seed": seed, "cases": 0, "by_class": {}, "by_conventions": {}, "by_shard_count": {}, "failures": []}
     k = 0
     while time.time() < t_end:
-        cls, bound = CLASSES[(k // 3) % 3 if k % 11 else 3]           # mostly small..large, an xl case every 11th
+        cls, bound = CLASSES[(k // 3) % 3 if k % xl_every else 3]     # mostly small..large, an xl case every 11th (argv[4]: every n-th)
         cname, conv = convs[k % len(convs)]
         if cname == "poseidon" and cls in ("large", "xl"):
             cname, conv = convs[0]
