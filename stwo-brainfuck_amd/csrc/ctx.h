@@ -1,5 +1,7 @@
 // Device context: stream, twiddle tree, arena allocator, small staging helpers. Internal to the library.
 #pragma once
+#include <cstdlib>
+#include <thread>
 #include "kernels.h"
 #include "comm.h"
 #include <memory>
@@ -64,7 +66,21 @@ struct Ctx {
     // HIP's current device is per host thread: every C-ABI entry binds the calling thread to this context's GPU first, so that
     // allocations (arena chunks, hipMalloc) land on the device the stream belongs to whichever thread drives the context.
     void bind() { BF_HIP(hipSetDevice(device)); }
-    void sync() { BF_HIP(hipStreamSynchronize(stream)); }
+    // Host waits for the stream. A proof has ~10 of these on its critical path (roots, samples, nonce: the Fiat-Shamir points), each followed
+    // by a few microseconds of host work and the next launches, so the wake-up latency of a blocking wait is paid ~10 times per proof:
+    // poll an event instead (BFHIP_SYNC=block restores hipStreamSynchronize).
+    hipEvent_t sync_ev = nullptr;
+    void sync() {
+        static const bool block = [] { const char* v = getenv("BFHIP_SYNC"); return v && v[0] == 'b'; }();
+        if (block || !sync_ev) { BF_HIP(hipStreamSynchronize(stream)); return; }
+        BF_HIP(hipEventRecord(sync_ev, stream));
+        for (u32 polls = 0;; polls++) {
+            hipError_t e = hipEventQuery(sync_ev);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) BF_HIP(e);
+            if (polls > 64) std::this_thread::yield();      // several contexts may be waiting on as many host threads
+        }
+    }
     // Copy a small host block to device scratch (valid until the ring is recycled by stage_checkpoint()). Stream-ordered.
     // Between stage_begin() and stage_end() the blocks are only written to the pinned ring and ONE copy moves them all at
     // stage_end(): every separate copy is a ~5 us blit on the GPU timeline, and a proof stages ~150 blocks.
