@@ -49,7 +49,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase
     bool side_busy = false;         // work enqueued on stream2 may still read parameter blocks from the staging ring
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
     u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
     u32* d_tw = nullptr; u32* d_itw = nullptr;
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
