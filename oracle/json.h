@@ -109,6 +109,8 @@ struct JsonParser {
     }
 };
 
+// a `u32` field of the reference structs holding a log2 size (serde refuses what does not fit the type; a size above 31 cannot be meant)
+static inline u32 j_log_size(const JVal& v) { if (v.kind != JVal::NUM || v.num > 31) throw std::runtime_error("bad log_size"); return (u32)v.num; }
 static inline u32 j_m31(const JVal& v) { if (v.kind != JVal::NUM || v.num >= P) throw std::runtime_error("bad M31"); return (u32)v.num; }
 static inline QM31 j_qm31(const JVal& v) {
     if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
@@ -128,7 +130,7 @@ static inline Hash32 j_hash(const JVal& v) {
         return h;
     }
     if (v.kind != JVal::ARR || v.arr.size() != 32) throw std::runtime_error("bad hash");
-    Hash32 h; for (int i = 0; i < 32; i++) { if (v.arr[i].num > 255) throw std::runtime_error("bad hash byte"); h.b[i] = (u8)v.arr[i].num; } return h;
+    Hash32 h; for (int i = 0; i < 32; i++) { if (v.arr[i].kind != JVal::NUM || v.arr[i].num > 255) throw std::runtime_error("bad hash byte"); h.b[i] = (u8)v.arr[i].num; } return h;
 }
 static inline MerkleDecommitment j_decommitment(const JVal& v) {
     MerkleDecommitment d;
@@ -150,7 +152,7 @@ static inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     if (jp.p != jp.end) throw std::runtime_error("json: bytes after the proof object");   // serde_json::from_slice refuses trailing characters
     BrainfuckProof bp;
     for (int c = 0; c < N_COMPONENTS; c++) {
-        bp.log_sizes[c] = (u32)root.get("claim").get(CLAIM_KEYS[c]).get("log_size").num;
+        bp.log_sizes[c] = j_log_size(root.get("claim").get(CLAIM_KEYS[c]).get("log_size"));
         bp.claimed_sums[c] = j_qm31(root.get("interaction_claim").get(CLAIM_KEYS[c]).get("claimed_sum"));
     }
     const JVal& p = root.get("proof");
@@ -163,12 +165,13 @@ static inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     }
     for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(j_decommitment(d));
     for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(j_m31(x)); sp.queried_values.push_back(v); }
+    if (p.get("proof_of_work").kind != JVal::NUM) throw std::runtime_error("bad proof_of_work");
     sp.proof_of_work = p.get("proof_of_work").num;
     const JVal& f = p.get("fri_proof");
     sp.fri_proof.first_layer = j_fri_layer(f.get("first_layer"));
     for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(j_fri_layer(l));
     for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(j_qm31(q));
-    sp.fri_proof.last_layer_log_size = (u32)f.get("last_layer_poly").get("log_size").num;
+    sp.fri_proof.last_layer_log_size = j_log_size(f.get("last_layer_poly").get("log_size"));
     return bp;
 }
 
