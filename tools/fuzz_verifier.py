@@ -52,7 +52,15 @@ def mutate(proof, rng):
     nums = [p for p, k in ps if k == "num"]
     lists = [p for p, k in ps if k == "list" and len(get(m, p)) > 0]
     strs = [p for p, k in ps if k == "str"]
-    kind = rng.choice(["bump", "random", "zero", "pminus1", "swap", "drop", "dup", "move", "big", "str"] if strs else ["bump", "random", "zero", "pminus1", "swap", "drop", "dup", "move", "big"])
+    kind = rng.choice(["bump", "random", "zero", "pminus1", "swap", "drop", "dup", "move", "big", "type", "str"] if strs else ["bump", "random", "zero", "pminus1", "swap", "drop", "dup", "move", "big", "type"])
+    if kind == "type":           # a value of another JSON type where a number, a list or an object is expected
+        p = rng.choice([q for q, _ in ps if q])
+        new = rng.choice([None, "1", [], {}, True, 1.5, [[]], {"a": 1}, 0])
+        old = get(m, p)
+        if type(old) is type(new) and old == new:
+            return None
+        set_(m, p, new)
+        return m, f"type {'/'.join(map(str, p))}: {type(old).__name__} -> {json.dumps(new)}"
     if kind in ("bump", "random", "zero", "pminus1", "big"):
         p = rng.choice(nums); old = get(m, p)
         new = {"bump": old + 1, "random": rng.randrange(P), "zero": 0, "pminus1": P - 1, "big": rng.choice([P, P + 1, 1 << 32, (1 << 64) - 1, 1 << 64])}[kind]
