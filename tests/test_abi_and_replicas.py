@@ -123,3 +123,39 @@ def test_hip_backend_covers_the_trait_surface():
     integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for entry in used:
         assert entry in integration, f"{entry} is used by hip_backend.rs but not mapped in INTEGRATION.md"
+
+
+def test_host_entries_survive_null_and_invalid_arguments():
+    """Every host-only entry point called with null pointers, zero sizes or an unknown component in a child process each (a crash would be a
+    signal exit code): all return, with -1 / 1 where the reference would panic."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = textwrap.dedent("""
+        import ctypes, sys
+        sys.path.insert(0, %r)
+        from conftest import load_package
+        L = load_package().lib()
+        n, m = ctypes.c_size_t(), ctypes.c_size_t()
+        z = ctypes.c_size_t(0)
+        calls = {
+            "compile_null": lambda: L.bfhip_host_compile(None, None, z, ctypes.byref(n)),
+            "run_null_code": lambda: L.bfhip_host_run(None, None, z, None, z, ctypes.byref(n), None, z, ctypes.byref(m)),
+            "run_null_counts": lambda: L.bfhip_host_run(b"+", None, z, None, z, None, None, z, None),
+            "table_null": lambda: L.bfhip_host_table(None, z, None, z, 0, None, z, ctypes.byref(n), ctypes.byref(m)),
+            "table_bad_component": lambda: L.bfhip_host_table((ctypes.c_uint32 * 7)(), ctypes.c_size_t(1), (ctypes.c_uint32 * 1)(43), ctypes.c_size_t(1), 99, None, z, ctypes.byref(n), ctypes.byref(m)),
+            "verify_null": lambda: L.bfhip_verify_brainfuck(None, z, 20, None, z),
+            "verify_no_error_buffer": lambda: L.bfhip_verify_brainfuck(b"{}", ctypes.c_size_t(2), 20, None, z),
+            "ctx_destroy_null": lambda: L.bfhip_ctx_destroy(None),
+            "trace_destroy_null": lambda: L.bfhip_trace_destroy(None, None),
+            "free_host_null": lambda: L.bfhip_free_host(None),
+            "component_shape_null": lambda: L.bfhip_component_shape(0, None, None, None),
+        }
+        print(calls[sys.argv[1]]())
+    """) % os.path.join(root, "tests")
+    expect = {"compile_null": -1, "run_null_code": -1, "table_bad_component": -1, "verify_null": 1, "verify_no_error_buffer": 1}
+    for name in ["compile_null", "run_null_code", "run_null_counts", "table_null", "table_bad_component", "verify_null", "verify_no_error_buffer",
+                 "ctx_destroy_null", "trace_destroy_null", "free_host_null", "component_shape_null"]:
+        r = subprocess.run([sys.executable, "-c", prog, name], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (name, r.returncode, r.stderr[-300:])
+        if name in expect:
+            assert int(r.stdout.strip().splitlines()[-1]) == expect[name], (name, r.stdout)
