@@ -1089,6 +1089,7 @@ extern "C" int32_t bfhip_ctx_set_table_builder(bfhip_ctx* ctx, int32_t on_gpu) {
 // Downloads one row-granular column of a resident trace (tests: GPU tables == host tables).
 extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows) {
     try {
+        if (!ctx || !t || !n_rows) { bfhip_set_error("null argument"); return -1; }
         if (component >= N_COMPONENTS || column >= t->in.rows[component].size()) { bfhip_set_error("bad component/column"); return -1; }
         const DCol& col = t->in.rows[component][column];
         *n_rows = col.stored();
@@ -1133,9 +1134,10 @@ extern "C" int32_t bfhip_trace_create_ram(bfhip_ctx* ctx, const char* code, cons
                                            uint32_t log_sizes[13], uint64_t* n_steps, uint64_t* main_cells, uint64_t* interaction_cells) {
     try {
         if (!ctx) throw HipError("null context");
+        if (!code || !out || (!input && n_input)) throw HipError("null argument");
         ctx->c.bind();
         std::vector<u32> ins = compile(code);
-        Machine m(ins, std::vector<u8>(input, input + n_input), ram_size ? ram_size : Machine::DEFAULT_RAM_SIZE);
+        Machine m(ins, input ? std::vector<u8>(input, input + n_input) : std::vector<u8>(), ram_size ? ram_size : Machine::DEFAULT_RAM_SIZE);
         m.execute();
         return trace_create_common(ctx, m.trace, ins, out, log_sizes, n_steps, main_cells, interaction_cells);
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
@@ -1150,6 +1152,7 @@ extern "C" int32_t bfhip_trace_create_from_registers(bfhip_ctx* ctx, const uint3
     try {
         if (!ctx) throw HipError("null context");
         ctx->c.bind();
+        if (!out) throw HipError("null argument");
         if (!trace7 || n_rows == 0) throw HipError("EmptyTrace");
         if (!code_words || n_code == 0) throw HipError("empty program");
         std::vector<Registers> tr(n_rows);
@@ -1168,6 +1171,8 @@ extern "C" int32_t bfhip_trace_destroy(bfhip_ctx* ctx, bfhip_trace* t) { (void)c
 extern "C" int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                                       char** transcript, double* phase_seconds) {
     try {
+        if (!ctx) throw HipError("null context");
+        if (!trace) throw HipError("null trace");
         ctx->c.bind();
         HipProver pv(ctx->c, log_max_rows);
         pv.want_transcript = transcript != nullptr;
@@ -1181,6 +1186,8 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
                                           char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
     TraceInput in;
     try {
+        if (!ctx) throw HipError("null context");
+        if (!code) throw HipError("null program text");
         ctx->c.bind();
         HipProver pv(ctx->c, log_max_rows);
         pv.want_transcript = transcript != nullptr;

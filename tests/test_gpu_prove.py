@@ -356,3 +356,18 @@ def test_bench_line_contract(tmp_path):
     assert d["poseidon252"]["verified"] is True and d["poseidon252"]["conventions"] == [0, 0, 0, 1] and d["poseidon252"]["log_domain_rows"] == 20
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+def test_prove_entries_reject_null_arguments(pkg, ctx):
+    """Null context / trace / program text: -1 and a message, not a crash."""
+    import ctypes
+    L = pkg.lib()
+    js, n = ctypes.c_void_p(), ctypes.c_size_t()
+    assert L.bfhip_prove_trace(ctx._h, None, 20, ctypes.byref(js), ctypes.byref(n), None, None) == -1 and b"null trace" in L.bfhip_last_error()
+    assert L.bfhip_prove_trace(None, None, 20, ctypes.byref(js), ctypes.byref(n), None, None) == -1 and b"null context" in L.bfhip_last_error()
+    assert L.bfhip_prove_brainfuck(ctx._h, None, None, ctypes.c_size_t(0), 20, ctypes.byref(js), ctypes.byref(n), None, None) == -1
+    assert L.bfhip_prove_brainfuck(None, b"+", None, ctypes.c_size_t(0), 20, ctypes.byref(js), ctypes.byref(n), None, None) == -1
+    t = ctypes.c_void_p()
+    assert L.bfhip_trace_create(ctx._h, None, None, ctypes.c_size_t(0), ctypes.byref(t), None, None, None, None) == -1
+    assert L.bfhip_trace_create(ctx._h, b"+", None, ctypes.c_size_t(0), None, None, None, None, None) == -1
+    assert L.bfhip_trace_column(ctx._h, None, 0, 0, None, ctypes.c_size_t(0), ctypes.byref(n)) == -1
