@@ -109,11 +109,13 @@ struct JsonParser {
     }
 };
 
+// a Vec field: serde_json takes a JSON array there and nothing else (an empty list written as null or {} must not pass)
+static inline const std::vector<JVal>& j_seq(const JVal& v) { if (v.kind != JVal::ARR) throw std::runtime_error("expected a sequence"); return v.arr; }
 // a `u32` field of the reference structs holding a log2 size (serde refuses what does not fit the type; a size above 31 cannot be meant)
 static inline u32 j_log_size(const JVal& v) { if (v.kind != JVal::NUM || v.num > 31) throw std::runtime_error("bad log_size"); return (u32)v.num; }
 static inline u32 j_m31(const JVal& v) { if (v.kind != JVal::NUM || v.num >= P) throw std::runtime_error("bad M31"); return (u32)v.num; }
 static inline QM31 j_qm31(const JVal& v) {
-    if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
+    if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].kind != JVal::ARR || v.arr[1].kind != JVal::ARR || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
     return QM31::from_u32(j_m31(v.arr[0].arr[0]), j_m31(v.arr[0].arr[1]), j_m31(v.arr[1].arr[0]), j_m31(v.arr[1].arr[1]));
 }
 static inline Hash32 j_hash(const JVal& v) {
@@ -134,13 +136,13 @@ static inline Hash32 j_hash(const JVal& v) {
 }
 static inline MerkleDecommitment j_decommitment(const JVal& v) {
     MerkleDecommitment d;
-    for (auto& h : v.get("hash_witness").arr) d.hash_witness.push_back(j_hash(h));
-    for (auto& x : v.get("column_witness").arr) d.column_witness.push_back(j_m31(x));
+    for (auto& h : j_seq(v.get("hash_witness"))) d.hash_witness.push_back(j_hash(h));
+    for (auto& x : j_seq(v.get("column_witness"))) d.column_witness.push_back(j_m31(x));
     return d;
 }
 static inline FriLayerProof j_fri_layer(const JVal& v) {
     FriLayerProof l;
-    for (auto& q : v.get("fri_witness").arr) l.fri_witness.push_back(j_qm31(q));
+    for (auto& q : j_seq(v.get("fri_witness"))) l.fri_witness.push_back(j_qm31(q));
     l.decommitment = j_decommitment(v.get("decommitment"));
     l.commitment = j_hash(v.get("commitment"));
     return l;
@@ -157,20 +159,20 @@ static inline BrainfuckProof proof_from_json(const char* s, size_t len) {
     }
     const JVal& p = root.get("proof");
     StarkProof& sp = bp.proof;
-    for (auto& h : p.get("commitments").arr) sp.commitments.push_back(j_hash(h));
-    for (auto& t : p.get("sampled_values").arr) {
+    for (auto& h : j_seq(p.get("commitments"))) sp.commitments.push_back(j_hash(h));
+    for (auto& t : j_seq(p.get("sampled_values"))) {
         std::vector<std::vector<QM31>> tv;
-        for (auto& c : t.arr) { std::vector<QM31> cv; for (auto& q : c.arr) cv.push_back(j_qm31(q)); tv.push_back(cv); }
+        for (auto& c : j_seq(t)) { std::vector<QM31> cv; for (auto& q : j_seq(c)) cv.push_back(j_qm31(q)); tv.push_back(cv); }
         sp.sampled_values.push_back(tv);
     }
-    for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(j_decommitment(d));
-    for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(j_m31(x)); sp.queried_values.push_back(v); }
+    for (auto& d : j_seq(p.get("decommitments"))) sp.decommitments.push_back(j_decommitment(d));
+    for (auto& t : j_seq(p.get("queried_values"))) { std::vector<u32> v; for (auto& x : j_seq(t)) v.push_back(j_m31(x)); sp.queried_values.push_back(v); }
     if (p.get("proof_of_work").kind != JVal::NUM) throw std::runtime_error("bad proof_of_work");
     sp.proof_of_work = p.get("proof_of_work").num;
     const JVal& f = p.get("fri_proof");
     sp.fri_proof.first_layer = j_fri_layer(f.get("first_layer"));
-    for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(j_fri_layer(l));
-    for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(j_qm31(q));
+    for (auto& l : j_seq(f.get("inner_layers"))) sp.fri_proof.inner_layers.push_back(j_fri_layer(l));
+    for (auto& q : j_seq(f.get("last_layer_poly").get("coeffs"))) sp.fri_proof.last_layer_coeffs.push_back(j_qm31(q));
     sp.fri_proof.last_layer_log_size = j_log_size(f.get("last_layer_poly").get("log_size"));
     return bp;
 }

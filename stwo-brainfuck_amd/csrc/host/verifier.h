@@ -66,9 +66,11 @@ struct JsonReader {
         return v;
     }
 };
+// a sequence field: serde_json refuses any other JSON type (null, object, number) where a Vec is expected
+inline const std::vector<JVal>& jv_list(const JVal& v) { if (v.kind != JVal::ARR) throw std::runtime_error("expected a sequence"); return v.arr; }
 inline u32 jv_m31(const JVal& v) { if (v.kind != JVal::NUM || v.num >= P31) throw std::runtime_error("bad M31"); return (u32)v.num; }
 inline Q31 jv_qm31(const JVal& v) {
-    if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
+    if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[0].kind != JVal::ARR || v.arr[1].kind != JVal::ARR || v.arr[0].arr.size() != 2 || v.arr[1].arr.size() != 2) throw std::runtime_error("bad QM31");
     return q_make(jv_m31(v.arr[0].arr[0]), jv_m31(v.arr[0].arr[1]), jv_m31(v.arr[1].arr[0]), jv_m31(v.arr[1].arr[1]));
 }
 inline Hash32 jv_hash(const JVal& v, bool felt) {
@@ -91,13 +93,13 @@ inline Hash32 jv_hash(const JVal& v, bool felt) {
 }
 inline MerkleDecommitment jv_decommitment(const JVal& v, bool felt) {
     MerkleDecommitment d;
-    for (auto& h : v.get("hash_witness").arr) d.hash_witness.push_back(jv_hash(h, felt));
-    for (auto& x : v.get("column_witness").arr) d.column_witness.push_back(jv_m31(x));
+    for (auto& h : jv_list(v.get("hash_witness"))) d.hash_witness.push_back(jv_hash(h, felt));
+    for (auto& x : jv_list(v.get("column_witness"))) d.column_witness.push_back(jv_m31(x));
     return d;
 }
 inline FriLayerProof jv_fri_layer(const JVal& v, bool felt) {
     FriLayerProof l;
-    for (auto& q : v.get("fri_witness").arr) l.fri_witness.push_back(jv_qm31(q));
+    for (auto& q : jv_list(v.get("fri_witness"))) l.fri_witness.push_back(jv_qm31(q));
     l.decommitment = jv_decommitment(v.get("decommitment"), felt);
     l.commitment = jv_hash(v.get("commitment"), felt);
     return l;
@@ -116,20 +118,20 @@ inline BrainfuckProof proof_from_json(const char* s, size_t len, bool felt = fal
     }
     const JVal& p = root.get("proof");
     StarkProof& sp = bp.proof;
-    for (auto& h : p.get("commitments").arr) sp.commitments.push_back(jv_hash(h, felt));
-    for (auto& t : p.get("sampled_values").arr) {
+    for (auto& h : jv_list(p.get("commitments"))) sp.commitments.push_back(jv_hash(h, felt));
+    for (auto& t : jv_list(p.get("sampled_values"))) {
         std::vector<std::vector<Q31>> tv;
-        for (auto& c : t.arr) { std::vector<Q31> cv; for (auto& q : c.arr) cv.push_back(jv_qm31(q)); tv.push_back(cv); }
+        for (auto& c : jv_list(t)) { std::vector<Q31> cv; for (auto& q : jv_list(c)) cv.push_back(jv_qm31(q)); tv.push_back(cv); }
         sp.sampled_values.push_back(tv);
     }
-    for (auto& d : p.get("decommitments").arr) sp.decommitments.push_back(jv_decommitment(d, felt));
-    for (auto& t : p.get("queried_values").arr) { std::vector<u32> v; for (auto& x : t.arr) v.push_back(jv_m31(x)); sp.queried_values.push_back(v); }
+    for (auto& d : jv_list(p.get("decommitments"))) sp.decommitments.push_back(jv_decommitment(d, felt));
+    for (auto& t : jv_list(p.get("queried_values"))) { std::vector<u32> v; for (auto& x : jv_list(t)) v.push_back(jv_m31(x)); sp.queried_values.push_back(v); }
     if (p.get("proof_of_work").kind != JVal::NUM) throw std::runtime_error("bad proof_of_work");
     sp.proof_of_work = p.get("proof_of_work").num;
     const JVal& f = p.get("fri_proof");
     sp.fri_proof.first_layer = jv_fri_layer(f.get("first_layer"), felt);
-    for (auto& l : f.get("inner_layers").arr) sp.fri_proof.inner_layers.push_back(jv_fri_layer(l, felt));
-    for (auto& q : f.get("last_layer_poly").get("coeffs").arr) sp.fri_proof.last_layer_coeffs.push_back(jv_qm31(q));
+    for (auto& l : jv_list(f.get("inner_layers"))) sp.fri_proof.inner_layers.push_back(jv_fri_layer(l, felt));
+    for (auto& q : jv_list(f.get("last_layer_poly").get("coeffs"))) sp.fri_proof.last_layer_coeffs.push_back(jv_qm31(q));
     { const JVal& ll = f.get("last_layer_poly").get("log_size"); if (ll.kind != JVal::NUM || ll.num > 31) throw std::runtime_error("bad last layer log_size"); sp.fri_proof.last_layer_log_size = (u32)ll.num; }
     return bp;
 }
