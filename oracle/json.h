@@ -86,6 +86,7 @@ struct JsonParser {
                 ws(); if (p >= end || *p != '"') throw std::runtime_error("json: key");
                 p++; const char* s = p; while (p < end && *p != '"') p++; std::string k(s, p); p++;
                 ws(); if (p >= end || *p != ':') throw std::runtime_error("json: colon"); p++;
+                for (auto& kv : v.obj) if (kv.first == k) throw std::runtime_error("json: duplicate key");   // serde: "duplicate field"
                 v.obj.push_back({k, parse()}); ws();
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }

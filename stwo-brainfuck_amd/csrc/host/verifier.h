@@ -42,6 +42,7 @@ struct JsonReader {
                 ws(); if (p >= end || *p != '"') throw std::runtime_error("json: key");
                 p++; const char* s = p; while (p < end && *p != '"') p++; if (p >= end) throw std::runtime_error("json: key"); std::string k(s, p); p++;
                 ws(); if (p >= end || *p != ':') throw std::runtime_error("json: colon"); p++;
+                for (auto& kv : v.obj) if (kv.first == k) throw std::runtime_error("json: duplicate key");   // serde_json: "duplicate field"
                 v.obj.push_back({k, parse(depth + 1)}); ws();
                 if (p < end && *p == ',') { p++; continue; } if (p < end && *p == '}') { p++; break; } throw std::runtime_error("json: object");
             }

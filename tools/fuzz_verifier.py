@@ -108,6 +108,10 @@ def text_mutations(js, rng):
     import re
     out = []
     nums = list(re.finditer(rb"(?<![0-9.eE\"x])\d+(?![0-9])", js))
+    keys = list(re.finditer(rb'"(log_size|commitment|proof_of_work|coeffs|hash_witness|claimed_sum)":', js))
+    if keys:                                  # a second occurrence of a key in its object, in front of the real one
+        m = rng.choice(keys)
+        out.append((js[:m.start()] + m.group() + rng.choice([b"0", b"[]", b"null"]) + b"," + js[m.start():], f"duplicate key {m.group(1).decode()} at byte {m.start()}"))
     for kind in ("leading_zero", "fraction", "exponent", "negative", "plus2p64", "trailing", "space_inside", "null"):
         m = rng.choice(nums)
         t = m.group()
