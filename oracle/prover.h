@@ -672,6 +672,8 @@ struct Verifier {
         }
         if (layer_bound != cfg.log_last_layer_degree_bound) return "InvalidNumFriLayers";
         if (fp.last_layer_coeffs.size() > (size_t(1) << cfg.log_last_layer_degree_bound)) return "LastLayerDegreeInvalid";
+        // the reference evaluates the last-layer polynomial by folding 2^log_size coefficients (it panics on any other count)
+        if (fp.last_layer_log_size > 31 || (size_t(1) << fp.last_layer_log_size) != fp.last_layer_coeffs.size()) return "LastLayerDegreeInvalid";
         ch.mix_felts(fp.last_layer_coeffs.data(), fp.last_layer_coeffs.size());
         // proof of work
         ch.mix_u64(pf.proof_of_work);

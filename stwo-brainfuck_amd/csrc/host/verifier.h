@@ -329,6 +329,9 @@ inline std::string verify_brainfuck(const BrainfuckProof& bp, u32 log_max_rows, 
         for (auto& lp : fp.inner_layers) { ch.mix_root(lp.commitment); alphas.push_back(ch.draw_felt()); if (layer_bound == 0) return "InvalidNumFriLayers"; layer_bound--; }
         if (layer_bound != cfg.log_last_layer_degree_bound) return "InvalidNumFriLayers";
         if (fp.last_layer_coeffs.size() > (size_t(1) << cfg.log_last_layer_degree_bound)) return "LastLayerDegreeInvalid";
+        // LinePoly::eval_at_point folds the coefficients over log_size doublings and asserts len == 2^log_size (stwo utils::fold): a proof
+        // whose log_size does not match its coefficient count makes the reference's verifier panic
+        if (fp.last_layer_log_size > 31 || fp.last_layer_coeffs.size() != (size_t(1) << fp.last_layer_log_size)) return "LastLayerDegreeInvalid";
         ch.mix_felts(fp.last_layer_coeffs.data(), fp.last_layer_coeffs.size());
         ch.mix_u64(pf.proof_of_work);
         if (ch.trailing_zeros() < cfg.pow_bits) return "ProofOfWork";

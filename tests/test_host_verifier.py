@@ -94,3 +94,12 @@ def test_verifiers_agree_on_mutated_proofs(pkg, oracle, proof, conv):
         b = oracle.verify(js, 12)[0]
         assert a == b, what
         assert not a, f"both verifiers accept the proof after: {what}"
+
+
+def test_last_layer_log_size_must_match_its_coefficients(pkg, oracle, proof, conv):
+    """last_layer_poly.log_size is not bound by the transcript; the reference's LinePoly::eval_at_point folds 2^log_size coefficients and panics on
+    any other count. Both verifiers refuse a log_size that does not match (found by tools/fuzz_verifier.py: 0 -> 1 was accepted by both)."""
+    bad = proof.replace(b'"log_size":0}}}}', b'"log_size":1}}}}')
+    assert bad != proof
+    assert not pkg.verify_brainfuck(bad, 12, conv)[0]
+    assert not oracle.verify(bad, 12)[0]
