@@ -91,6 +91,11 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
  * CanonicCoset(log_eval).circle_domain(), log_eval >= log_size. replicated as above (output is row-granular, 2^(log_eval-4) cells). */
 int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* const* dst_cols_h, uint32_t n_cols, uint32_t log_size, uint32_t log_eval, int32_t replicated);
 
+/* gen_is_first::<B>(log_size) followed by interpolate (mod.rs:497 `tree_builder.extend_evals(gen_is_first(..))`, one call per
+ * log_size in log_min..=log_max): the coefficients of the indicator of cell 0, written in closed form by ONE launch (no transform).
+ * dst_cols_h[n - log_min] = device pointer to 2^n words, or NULL to skip that size. 4 <= log_min <= log_max < log_min + 28. */
+int32_t bfhip_is_first_coeffs(bfhip_ctx* ctx, uint32_t log_min, uint32_t log_max, uint32_t* const* dst_cols_h);
+
 /* ---- single backend operations (each is what one stwo trait method would call; all reached from mod.rs:732 prover::prove unless noted) ----
  * A secure (QM31) column is passed as 4 coordinate pointers. Values/points passed from the host are u32[4] per QM31. */
 

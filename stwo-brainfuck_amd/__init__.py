@@ -185,6 +185,11 @@ class Context:
     def evaluate(self, coeff_ptrs, dst_ptrs, log_size, log_eval, replicated=False):
         _check(lib().bfhip_evaluate(self._h, self._ptr_array(coeff_ptrs), self._ptr_array(dst_ptrs), len(coeff_ptrs), log_size, log_eval, int(replicated)))
 
+    def is_first_coeffs(self, log_min, log_max, dst_ptrs):
+        """interpolate(gen_is_first(n)) for n = log_min..log_max in closed form (mod.rs:497); dst_ptrs[n - log_min] may be None."""
+        arr = (ctypes.c_void_p * len(dst_ptrs))(*[p or None for p in dst_ptrs])
+        _check(lib().bfhip_is_first_coeffs(self._h, log_min, log_max, arr))
+
     def eval_at_point(self, coeff_ptr, log_size, point8, replicated=False):
         pt = (ctypes.c_uint32 * 8)(*[int(v) for v in point8])
         out = (ctypes.c_uint32 * 4)()

@@ -13,6 +13,7 @@
 #include "kernels.h"
 #include "air.h"
 #include <cstdlib>
+#include <stdexcept>
 
 namespace bf {
 
@@ -148,11 +149,9 @@ struct GroupEval {
 // row >> 1 and the bit below them; even rows step back in the first half-coset, odd rows forward in the conjugate one), so the four rows of a
 // quad read elements 0, 2 of the quad at prev(r0) and elements 1, 3 of the quad at prev(r0 + 1) - 1 — except next to the wrap-around.
 template <int COMP>
-__global__ void __launch_bounds__(256) k_constraints_block(const ConstraintArgs* __restrict__ ap) {
-    __shared__ uint4 s_abk[256 * 3];
-    const ConstraintArgs& a = *ap;
+__device__ __forceinline__ void constraints_block_body(const ConstraintArgs& a, uint4* __restrict__ s_abk, u32 block) {
     const u32 n = a.n_rows ? a.n_rows : 2u << a.log_size, row_first = a.n_rows ? a.row0 : 0u;
-    const u32 base = blockIdx.x * 4096u;
+    const u32 base = block * 4096u;
     {
         const u32 rel = base + threadIdx.x * 16u;
         if (rel < n) {
@@ -216,6 +215,88 @@ __global__ void __launch_bounds__(256) k_constraints_block(const ConstraintArgs*
         }
     }
 }
+template <int COMP>
+__global__ void __launch_bounds__(256) k_constraints_block(const ConstraintArgs* __restrict__ ap) {
+    __shared__ uint4 s_abk[256 * 3];
+    constraints_block_body<COMP>(*ap, s_abk, blockIdx.x);
+}
+
+// ---- all components of a proof in ONE launch ----------------------------------------------------------------------------------------
+// The components are grouped into CLASSES by evaluation-domain size (= one accumulator each). A workgroup belongs to one class and
+// evaluates every component of it for its rows: per-row mode sums them in registers and writes the accumulator once (no read-modify-write,
+// no ordering between components needed); row-group mode runs the components one after the other on the workgroup's 4096 rows (the same
+// lane owns the same rows each time, so its accumulator updates are ordered by program order).
+template <int COMP>
+__device__ __forceinline__ Q31 constraints_row_value(const ConstraintArgs& a, u32 row) {
+    DomainEval e(a, row);
+    air_eval<COMP>(e, a.el);
+    return q_mulm(e.result(), a.denom_inv[row >> a.log_size]);
+}
+#define BF_FOR_EACH_COMPONENT(X) X(C_MEMORY) X(C_INSTRUCTION) X(C_PROGRAM) X(C_PROCESSOR) X(C_JNZ) X(C_JZ) X(C_INPUT) X(C_LEFT) X(C_MINUS) X(C_OUTPUT) X(C_PLUS) X(C_RIGHT) X(C_EOE)
+__global__ void __launch_bounds__(256) k_constraints_batch(const ConstraintBatch* __restrict__ bp, const ConstraintArgs* __restrict__ args) {
+    __shared__ uint4 s_abk[256 * 3];
+    const ConstraintBatch& b = *bp;
+    u32 ci = 0;
+    while (ci + 1 < b.n_classes && b.cls[ci + 1].block0 <= blockIdx.x) ci++;      // uniform: scalar loads
+    const ConstraintClass& cl = b.cls[ci];
+    const u32 block = blockIdx.x - cl.block0;
+    if (cl.group_rows) {
+        for (u32 q = 0; q < cl.n_comps; q++) {
+            const ConstraintArgs& a = args[cl.comp[q]];
+            switch (cl.comp[q]) {
+#define X(C) case C: constraints_block_body<C>(a, s_abk, block); break;
+                BF_FOR_EACH_COMPONENT(X)
+#undef X
+            }
+            __syncthreads();      // s_abk is reused by the next component
+        }
+        return;
+    }
+    const ConstraintArgs& a0 = args[cl.comp[0]];
+    u32 row = block * blockDim.x + threadIdx.x;
+    if (a0.n_rows) { if (row >= a0.n_rows) return; row += a0.row0; }
+    else if (row >= (2u << a0.log_size)) return;
+    Q31 sum = q_zero();
+    for (u32 q = 0; q < cl.n_comps; q++) {
+        const ConstraintArgs& a = args[cl.comp[q]];
+        Q31 v = q_zero();
+        switch (cl.comp[q]) {
+#define X(C) case C: v = constraints_row_value<C>(a, row); break;
+            BF_FOR_EACH_COMPONENT(X)
+#undef X
+        }
+        sum = q_add(sum, v);
+    }
+    as_global(a0.acc[0])[row] = sum.a.a; as_global(a0.acc[1])[row] = sum.a.b; as_global(a0.acc[2])[row] = sum.b.a; as_global(a0.acc[3])[row] = sum.b.b;
+}
+// launches[k] = the parameter block of component k (all 13 present, staged at d_args); components with equal log_size form a class.
+void constraint_batch_init(ConstraintBatch& b, const ConstraintLaunch* launches, u32 n) {
+    b = ConstraintBatch{};
+    u32 blocks = 0;
+    for (u32 k = 0; k < n; k++) {
+        u32 ci = 0;
+        while (ci < b.n_classes && launches[b.cls[ci].comp[0]].log_size != launches[k].log_size) ci++;
+        if (ci == b.n_classes) { b.n_classes++; b.cls[ci].group_rows = constraint_group_rows(launches[k], (int)k); b.cls[ci].comp[0] = k; }
+        ConstraintClass& cl = b.cls[ci];
+        if (constraint_group_rows(launches[k], (int)k) != cl.group_rows || launches[k].n_rows != launches[cl.comp[0]].n_rows || launches[k].row0 != launches[cl.comp[0]].row0 ||
+            launches[k].acc[0] != launches[cl.comp[0]].acc[0])
+            throw std::runtime_error("constraint batch: components of one size disagree on mode, row range or accumulator");
+        cl.comp[cl.n_comps++] = k;
+    }
+    for (u32 ci = 0; ci < b.n_classes; ci++) {
+        ConstraintClass& cl = b.cls[ci];
+        const ConstraintLaunch& L = launches[cl.comp[0]];
+        const u32 rows = L.n_rows ? L.n_rows : 2u << L.log_size;
+        cl.block0 = blocks;
+        blocks += cl.group_rows ? (rows + 4095) / 4096 : (rows + 255) / 256;
+    }
+    b.total_blocks = blocks;
+}
+void eval_constraints_batch(hipStream_t stream, const ConstraintBatch* d_batch, const ConstraintBatch& h_batch, const ConstraintLaunch* d_args) {
+    if (!h_batch.total_blocks) return;
+    ProfScope ps(stream, "k_constraints", 0);
+    hipLaunchKernelGGL(k_constraints_batch, dim3(h_batch.total_blocks), dim3(256), 0, stream, d_batch, d_args);
+}
 
 template <int COMP>
 static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size, u32 n_rows, u32 group_rows) {
@@ -262,29 +343,31 @@ void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u
 // ------------------------------------------------------------------------------------------------------------------------------
 // logUp interaction trace
 // ------------------------------------------------------------------------------------------------------------------------------
+// All components of a proof go through the SAME four launches (LogupBatch in HBM: per-component pointers and, per stage, the first
+// workgroup of each component): the reference's 13 interaction_trace_evaluation calls (mod.rs:596-687) cost 4 launches, not 52.
 // Stage 1 — one lane per table row: fractions num/denom of every logUp column, running sum over columns.
 // Columns before the last are written row-granular (they are 16x-replicated like the main trace); the last column's
 // per-row value goes to `vrow` for the coset-order prefix sum.
-struct LogupArgs {
-    const u32* cols[13];        // row-granular main columns of the component
-    u32* out[8];                // row-granular coordinate columns of the non-last logUp columns (4 each)
-    uint4* vrow;                // per-row value of the last logUp column
-    Lookups el;
-    u32 n_rows;
-    int comp;
-};
+__device__ __forceinline__ u32 logup_item_of_block(const u32* __restrict__ blk0, u32 n) {
+    u32 k = 0;
+    while (k + 1 < n && blk0[k + 1] <= blockIdx.x) k++;      // uniform: scalar loads
+    return k;
+}
 
-__device__ __forceinline__ Q31 logup_denominator(const LogupArgs& a, int rel, const u32* v) {
-    const Lookup& l = rel == 0 ? a.el.memory : rel == 1 ? a.el.instruction : a.el.processor;
+__device__ __forceinline__ Q31 logup_denominator(const Lookups& el, int rel, const u32* v) {
+    const Lookup& l = rel == 0 ? el.memory : rel == 1 ? el.instruction : el.processor;
     int n = rel == 2 ? 7 : 3;
     Q31 acc = q_zero();
     for (int i = 0; i < n; i++) acc = q_add(acc, q_mulm(l.alpha_pow[i], v[i]));
     return q_sub(acc, l.z);
 }
 
-__global__ void __launch_bounds__(256) k_logup_rows(LogupArgs a) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_rows) return;
+__global__ void __launch_bounds__(256) k_logup_rows(const LogupBatch* __restrict__ bp) {
+    const LogupBatch& b = *bp;
+    const u32 k = logup_item_of_block(b.rows_blk0, b.n);
+    const LogupItem& a = b.item[k];
+    u32 r = (blockIdx.x - b.rows_blk0[k]) * blockDim.x + threadIdx.x;
+    if (r >= (1u << a.log_rows)) return;
     const int comp = a.comp;
     u32 v[7];
     Q31 cur = q_zero();
@@ -293,19 +376,19 @@ __global__ void __launch_bounds__(256) k_logup_rows(LogupArgs a) {
         u32 reg[8];
         for (int i = 0; i < 8; i++) reg[i] = a.cols[i][r];
         Q31 num = q_subm(q_one(), reg[7]);
-        Q31 d0 = logup_denominator(a, 2, reg);
+        Q31 d0 = logup_denominator(b.el, 2, reg);
         v[0] = reg[1]; v[1] = reg[2]; v[2] = reg[3];
-        Q31 d1 = logup_denominator(a, 1, v);
+        Q31 d1 = logup_denominator(b.el, 1, v);
         v[0] = reg[0]; v[1] = reg[4]; v[2] = reg[5];
-        Q31 d2 = logup_denominator(a, 0, v);
+        Q31 d2 = logup_denominator(b.el, 0, v);
         // one shared inversion (Montgomery trick) — results equal the three separate inverses
         Q31 d01 = q_mul(d0, d1), inv_all = q_inv(q_mul(d01, d2));
         Q31 i2 = q_mul(inv_all, d01), i01 = q_mul(inv_all, d2);
         Q31 i0 = q_mul(i01, d1), i1 = q_mul(i01, d0);
         cur = q_mul(num, i0);
-        a.out[0][r] = cur.a.a; a.out[1][r] = cur.a.b; a.out[2][r] = cur.b.a; a.out[3][r] = cur.b.b;
+        a.out_rep[0][r] = cur.a.a; a.out_rep[1][r] = cur.a.b; a.out_rep[2][r] = cur.b.a; a.out_rep[3][r] = cur.b.b;
         cur = q_add(cur, q_mul(num, i1));
-        a.out[4][r] = cur.a.a; a.out[5][r] = cur.a.b; a.out[6][r] = cur.b.a; a.out[7][r] = cur.b.b;
+        a.out_rep[4][r] = cur.a.a; a.out_rep[5][r] = cur.a.b; a.out_rep[6][r] = cur.b.a; a.out_rep[7][r] = cur.b.b;
         cur = q_add(cur, q_mul(num, i2));
     } else {
         int rel, dcol, mode;   // mode 0: d - 1, 1: 1 - d, 2: -1
@@ -317,7 +400,7 @@ __global__ void __launch_bounds__(256) k_logup_rows(LogupArgs a) {
         else { rel = 2; dcol = 7; mode = 0; }
         int n = rel == 2 ? 7 : 3;
         for (int i = 0; i < n; i++) v[i] = a.cols[i][r];
-        Q31 den = logup_denominator(a, rel, v);
+        Q31 den = logup_denominator(b.el, rel, v);
         Q31 num;
         if (mode == 2) num = q_neg(q_one());
         else { u32 d = a.cols[dcol][r]; num = mode == 0 ? q_subm(q_from_m(d), 1) : q_subm(q_one(), d); }
@@ -332,10 +415,15 @@ __device__ __forceinline__ void q_st(uint4* p, u32 i, Q31 q) { p[i] = make_uint4
 // Stage 2 — inclusive scan over R = bit_reverse(row) of w[R] = v[R] + v[M-1-R]  (M rows; see DESIGN.md "coset-order prefix sum").
 // Block-local scan of SCAN_TILE entries; block totals are scanned by k_scan_totals.
 static constexpr u32 SCAN_TILE = 1024;
-__global__ void __launch_bounds__(256) k_logup_scan_local(const uint4* __restrict__ vrow, uint4* __restrict__ wloc, uint4* __restrict__ totals, u32 log_rows) {
+__global__ void __launch_bounds__(256) k_logup_scan_local(const LogupBatch* __restrict__ bp) {
     __shared__ uint4 s[SCAN_TILE];
+    const LogupBatch& b = *bp;
+    const u32 k = logup_item_of_block(b.scan_blk0, b.n);
+    const LogupItem& a = b.item[k];
+    const uint4* __restrict__ vrow = a.vrow; uint4* __restrict__ wloc = a.wloc; uint4* __restrict__ totals = a.totals;
+    const u32 log_rows = a.log_rows, blk = blockIdx.x - b.scan_blk0[k];
     u32 M = 1u << log_rows;
-    u32 base = blockIdx.x * SCAN_TILE;
+    u32 base = blk * SCAN_TILE;
     for (u32 i = threadIdx.x; i < SCAN_TILE; i += blockDim.x) {
         u32 R = base + i;
         Q31 w = q_zero();
@@ -346,17 +434,20 @@ __global__ void __launch_bounds__(256) k_logup_scan_local(const uint4* __restric
     // Hillis-Steele over 1024 entries, 4 per thread
     for (u32 off = 1; off < SCAN_TILE; off <<= 1) {
         Q31 t[4];
-        for (u32 k = 0; k < 4; k++) { u32 i = threadIdx.x + k * 256; t[k] = i >= off ? q_add(q_ld(s, i), q_ld(s, i - off)) : q_ld(s, i); }
+        for (u32 q = 0; q < 4; q++) { u32 i = threadIdx.x + q * 256; t[q] = i >= off ? q_add(q_ld(s, i), q_ld(s, i - off)) : q_ld(s, i); }
         __syncthreads();
-        for (u32 k = 0; k < 4; k++) q_st(s, threadIdx.x + k * 256, t[k]);
+        for (u32 q = 0; q < 4; q++) q_st(s, threadIdx.x + q * 256, t[q]);
         __syncthreads();
     }
     for (u32 i = threadIdx.x; i < SCAN_TILE; i += blockDim.x) if (base + i < M) wloc[base + i] = s[i];
-    if (threadIdx.x == 0) totals[blockIdx.x] = s[SCAN_TILE - 1];
+    if (threadIdx.x == 0) totals[blk] = s[SCAN_TILE - 1];
 }
-// Exclusive scan of the block totals (single workgroup, serial over chunks of 256); totals[nb] receives the grand total.
-__global__ void __launch_bounds__(256) k_scan_totals(uint4* __restrict__ totals, u32 nb) {
+// Exclusive scan of the block totals (one workgroup per component, serial over chunks of 256); totals[nb] receives the grand total.
+__global__ void __launch_bounds__(256) k_scan_totals(const LogupBatch* __restrict__ bp) {
     __shared__ uint4 s[256];
+    const LogupItem& a = bp->item[blockIdx.x];
+    uint4* __restrict__ totals = a.totals;
+    const u32 nb = a.nb;
     Q31 carry = q_zero();
     for (u32 base = 0; base < nb; base += 256) {
         u32 i = base + threadIdx.x;
@@ -382,9 +473,13 @@ __global__ void __launch_bounds__(256) k_scan_totals(uint4* __restrict__ totals,
 // cell s = 16 r + l, R = bit_reverse(r), L = bit_reverse4(l):
 //   L <  8: S = L*Wtot + W[R] - v[M-1-R]     (even coset position 2q, q = L*M + R)
 //   L >= 8: S = (15-L)*Wtot + W[M-1-R]       (odd coset position)
-__global__ void __launch_bounds__(256) k_logup_last(const uint4* __restrict__ vrow, const uint4* __restrict__ wloc, const uint4* __restrict__ totals, u32 nb,
-                                                    u32 log_rows, u32* __restrict__ o0, u32* __restrict__ o1, u32* __restrict__ o2, u32* __restrict__ o3, uint4* __restrict__ claimed) {
-    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_logup_last(const LogupBatch* __restrict__ bp) {
+    const LogupBatch& b = *bp;
+    const u32 k = logup_item_of_block(b.last_blk0, b.n);
+    const LogupItem& a = b.item[k];
+    const uint4* __restrict__ vrow = a.vrow; const uint4* __restrict__ wloc = a.wloc; const uint4* __restrict__ totals = a.totals;
+    const u32 log_rows = a.log_rows, nb = a.nb;
+    u32 s = (blockIdx.x - b.last_blk0[k]) * blockDim.x + threadIdx.x;
     u32 M = 1u << log_rows;
     if (s >= 16 * M) return;
     u32 r = s >> 4, l = s & 15;
@@ -399,22 +494,36 @@ __global__ void __launch_bounds__(256) k_logup_last(const uint4* __restrict__ vr
         Q31 W = q_add(q_ld(wloc, X), q_ld(totals, X / SCAN_TILE));
         res = q_add(q_mulm(wtot, 15 - L), W);
     }
-    o0[s] = res.a.a; o1[s] = res.a.b; o2[s] = res.b.a; o3[s] = res.b.b;
-    if (s == 0) q_st(claimed, 0, q_mulm(wtot, 8));
+    a.out_last[0][s] = res.a.a; a.out_last[1][s] = res.a.b; a.out_last[2][s] = res.b.a; a.out_last[3][s] = res.b.b;
+    if (s == 0) q_st(a.claimed, 0, q_mulm(wtot, 8));
 }
 
-void logup_generate(hipStream_t stream, const LogupLaunch& L) {
-    LogupArgs a;
-    for (int i = 0; i < 13; i++) a.cols[i] = L.cols[i];
-    for (int i = 0; i < 8; i++) a.out[i] = L.out_rep[i];
-    a.vrow = (uint4*)L.vrow; a.el = L.el; a.n_rows = 1u << L.log_rows; a.comp = L.comp;
-    u32 M = a.n_rows;
-    hipLaunchKernelGGL(k_logup_rows, dim3((M + 255) / 256), dim3(256), 0, stream, a);
-    u32 nb = (M + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_logup_scan_local, dim3(nb), dim3(256), 0, stream, (const uint4*)L.vrow, (uint4*)L.wloc, (uint4*)L.totals, L.log_rows);
-    hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(256), 0, stream, (uint4*)L.totals, nb);
-    hipLaunchKernelGGL(k_logup_last, dim3((16 * M + 255) / 256), dim3(256), 0, stream, (const uint4*)L.vrow, (const uint4*)L.wloc, (const uint4*)L.totals, nb, L.log_rows,
-                       L.out_last[0], L.out_last[1], L.out_last[2], L.out_last[3], (uint4*)L.claimed);
+void logup_batch_init(LogupBatch& b, const Lookups& el, const LogupLaunch* L, u32 n) {
+    if (n > N_COMPONENTS) throw std::runtime_error("logup batch: too many components");
+    b = LogupBatch{};
+    b.el = el; b.n = n;
+    u32 rows = 0, scan = 0, last = 0;
+    for (u32 k = 0; k < n; k++) {
+        LogupItem& it = b.item[k];
+        for (int i = 0; i < 13; i++) it.cols[i] = L[k].cols[i];
+        for (int i = 0; i < 8; i++) it.out_rep[i] = L[k].out_rep[i];
+        for (int i = 0; i < 4; i++) it.out_last[i] = L[k].out_last[i];
+        it.vrow = (uint4*)L[k].vrow; it.wloc = (uint4*)L[k].wloc; it.totals = (uint4*)L[k].totals; it.claimed = (uint4*)L[k].claimed;
+        it.log_rows = L[k].log_rows; it.comp = L[k].comp;
+        const u32 M = 1u << it.log_rows;
+        it.nb = (M + SCAN_TILE - 1) / SCAN_TILE;
+        b.rows_blk0[k] = rows; rows += (M + 255) / 256;
+        b.scan_blk0[k] = scan; scan += it.nb;
+        b.last_blk0[k] = last; last += (16 * M + 255) / 256;
+    }
+    b.rows_blk0[n] = rows; b.scan_blk0[n] = scan; b.last_blk0[n] = last;
+}
+void logup_batch_run(hipStream_t stream, const LogupBatch* d_b, const LogupBatch& h) {
+    if (!h.n) return;
+    hipLaunchKernelGGL(k_logup_rows, dim3(h.rows_blk0[h.n]), dim3(256), 0, stream, d_b);
+    hipLaunchKernelGGL(k_logup_scan_local, dim3(h.scan_blk0[h.n]), dim3(256), 0, stream, d_b);
+    hipLaunchKernelGGL(k_scan_totals, dim3(h.n), dim3(256), 0, stream, d_b);
+    hipLaunchKernelGGL(k_logup_last, dim3(h.last_blk0[h.n]), dim3(256), 0, stream, d_b);
 }
 
 // Broadcast upload helper (a14): rows -> 16 consecutive cells. Only used by the C-ABI when a caller wants the full-size column.

@@ -182,7 +182,9 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
         cv.merkle_node_hash = conv->merkle_node_hash; cv.mix_u64 = conv->mix_u64; cv.logup_mask_order = conv->logup_mask_order; cv.merkle_channel = conv->merkle_channel;
     }
     ctx->c.sync();
-    ctx->c.conv = cv;   // a kept preprocessed tree is keyed on the conventions it was hashed under (prover.hip: PreprocessedCache)
+    // a kept preprocessed tree is keyed on the hasher it was built with (prover.hip: PreprocessedCache::matches) and dropped here as well
+    if (cv.merkle_node_hash != ctx->c.conv.merkle_node_hash || cv.merkle_channel != ctx->c.conv.merkle_channel) preprocessed_cache_invalidate(&ctx->c);
+    ctx->c.conv = cv;
     return 0;
     API_CATCH
 }
@@ -218,9 +220,15 @@ int32_t bfhip_interpolate(bfhip_ctx* ctx, uint32_t* const* src_cols_h, uint32_t*
     if (log_size > c.tw_root_log + 1) throw HipError("log_size exceeds the context's twiddle tree");
     u32 log = replicated ? log_size - 4 : log_size;
     c.stage_checkpoint();
+    StageBatch sb(c);
     auto* s = c.stage(src_cols_h, n_cols);
     auto* d = c.stage(dst_cols_h, n_cols);
-    fft_batch(c.stream, true, (const u32* const*)s, (u32* const*)d, n_cols, log, log, !replicated, c.d_tw, c.d_itw, c.tw_root_log);
+    const FftJob job{(const u32* const*)s, (u32* const*)d, n_cols, log, log, !replicated};
+    FftPlan plan;
+    fft_plan(plan, true, &job, 1, c.d_tw, c.d_itw, c.tw_root_log);
+    plan.d_groups = c.stage(plan.groups.data(), plan.groups.size());
+    sb.end();
+    fft_run(c.stream, plan);
     BF_HIP(hipGetLastError());
     return 0;
     API_CATCH
@@ -235,15 +243,33 @@ int32_t bfhip_evaluate(bfhip_ctx* ctx, uint32_t* const* coeff_cols_h, uint32_t* 
     if (log_eval > c.tw_root_log + 1) throw HipError("log_eval exceeds the context's twiddle tree");
     u32 sh = replicated ? 4 : 0;
     c.stage_checkpoint();
+    StageBatch sb(c);
     auto* s = c.stage(coeff_cols_h, n_cols);
     auto* d = c.stage(dst_cols_h, n_cols);
-    fft_batch(c.stream, false, (const u32* const*)s, (u32* const*)d, n_cols, log_eval - sh, log_size - sh, !replicated, c.d_tw, c.d_itw, c.tw_root_log);
+    const FftJob job{(const u32* const*)s, (u32* const*)d, n_cols, log_eval - sh, log_size - sh, !replicated};
+    FftPlan plan;
+    fft_plan(plan, false, &job, 1, c.d_tw, c.d_itw, c.tw_root_log);
+    plan.d_groups = c.stage(plan.groups.data(), plan.groups.size());
+    sb.end();
+    fft_run(c.stream, plan);
     BF_HIP(hipGetLastError());
     return 0;
     API_CATCH
 }
 
 
+int32_t bfhip_is_first_coeffs(bfhip_ctx* ctx, uint32_t log_min, uint32_t log_max, uint32_t* const* dst_cols_h) {
+    API_CTX(ctx)
+    if (!dst_cols_h) throw HipError("null argument");
+    if (log_min < 4 || log_max < log_min || log_max - log_min >= 28) throw HipError("is_first_coeffs: need 4 <= log_min <= log_max < log_min + 28");
+    if (log_max > ctx->c.tw_root_log + 1) throw HipError("log_max exceeds the context's twiddle tree");
+    IsFirstCols a{}; a.log_min = log_min; a.log_max = log_max;
+    for (u32 n = log_min; n <= log_max; n++) a.ptr[n - log_min] = dst_cols_h[n - log_min];
+    is_first_coeffs(ctx->c.stream, a, ctx->c.d_itw, ctx->c.tw_root_log);
+    BF_HIP(hipGetLastError());
+    return 0;
+    API_CATCH
+}
 int32_t bfhip_broadcast16(bfhip_ctx* ctx, const uint32_t* rows_d, uint32_t* dst_d, size_t n_rows) {
     API_CTX(ctx) broadcast16(ctx->c.stream, rows_d, dst_d, (u32)(n_rows * 16)); BF_HIP(hipGetLastError()); return 0; API_CATCH
 }
@@ -415,7 +441,12 @@ int32_t bfhip_logup_generate(bfhip_ctx* ctx, int32_t component, uint32_t log_siz
     BF_HIP(hipMalloc((void**)&scratch, sizeof(uint4) * (2 * M + n_tot + 1)));
     L.vrow = scratch; L.wloc = scratch + M; L.totals = scratch + 2 * M; L.claimed = scratch + 2 * M + n_tot;
     L.el = lookups_from_h(lookup_h); L.log_rows = log_rows; L.comp = component;
-    logup_generate(c.stream, L);
+    {
+        LogupBatch lb;
+        logup_batch_init(lb, L.el, &L, 1);
+        c.stage_checkpoint();
+        logup_batch_run(c.stream, c.stage(&lb, 1), lb);
+    }
     uint4 r;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&r, L.claimed, sizeof(uint4), hipMemcpyDeviceToHost, c.stream);

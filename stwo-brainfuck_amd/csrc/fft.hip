@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <algorithm>
+#include <vector>
 
 namespace bf {
 
@@ -55,22 +57,54 @@ __global__ void k_gen_twiddles(u32* __restrict__ tw, u32* __restrict__ itw, u32 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// One pass = layers [lo, lo+k) of a size-2^log transform, for the columns cols[blockIdx.y * cpb .. +cpb).
+// Preprocessed columns in closed form: interpolate(gen_is_first(n)) for every n in one launch (mod.rs:495-499: gen_is_first::<SimdBackend>
+// then tree_builder.extend_evals = interpolate). IsFirst(n) is the indicator of cell 0; under the inverse butterflies
+// (v0, v1) -> (v0 + v1, (v0 - v1) t) a one-hot vector stays a tensor product: after layer i cell (1 << i) | l holds cell l times t_i,
+// t_i = the layer's inverse twiddle of butterfly block 0. Hence coefficient j = 2^-n * prod over the set bits i of j of t_i — the values the
+// transform of the one-hot column produces, with no column traffic and no 19 x (1 + 3) launches.
+// t_0 = the circle layer's twiddle of pair 0 (y of the first entry pair of the first line table), t_i = entry 0 of line layer i.
 // ---------------------------------------------------------------------------------------------------------------------
-struct PassArgs {
-    u32* const* dst;          // device array of column pointers (output / in-place)
-    const u32* const* src;    // device array of column pointers (input of this pass)
-    u32 ncols, cols_per_block;
-    u32 log;                  // transform size
-    u32 lo, k;                // layers [lo, lo + k)
-    u32 tile_log;             // contiguous pass (lo == 0): tile = 2^tile_log >= 2^k cells; strided: tile = 2^(k + CHUNK_LOG)
-    u32 src_mask;             // input index mask (2^src_log - 1): forward zero-extension = wrap-around load
-    u32 circle;               // 1: layer 0 is the circle layer; 0: line mode
-    u32 scale;                // inverse: multiply outputs by this (1 = none)
-    const u32* tw;            // twiddle (forward) or inverse-twiddle (inverse) layered buffer
-    u32 tw_total;             // 2^R
-};
+__global__ void __launch_bounds__(256) k_is_first_coeffs(IsFirstCols a, const u32* __restrict__ itw, u32 tw_total) {
+    // one lane writes 16 consecutive coefficients; lanes are flattened over the columns in ascending size
+    const u32 u = blockIdx.x * blockDim.x + threadIdx.x + (1u << (a.log_min - 4));
+    if (u >= (1u << (a.log_max - 3))) return;
+    const u32 n = 35u - __clz(u);                     // column IsFirst(n): u in [2^(n-4), 2^(n-3))
+    u32* __restrict__ dst = a.ptr[n - a.log_min];
+    if (!dst) return;                                 // another rank of the shard group owns this column
+    const u32 jhi = u - (1u << (n - 4));              // coefficient index >> 4
+    auto t = [&](u32 i) -> u32 { return i == 0 ? itw[tw_total - (1u << (n - 1)) + 1] : itw[tw_total - (1u << (n - i))]; };
+    u32 v[16];
+    v[0] = m_inv_pow2(n);
+    for (u32 i = 4; i < n; i++) if ((jhi >> (i - 4)) & 1) v[0] = m_mul(v[0], t(i));
+#pragma unroll
+    for (u32 b = 0; b < 4; b++) {
+        const u32 tb = t(b);
+#pragma unroll
+        for (u32 e = 0; e < (1u << b); e++) v[e + (1u << b)] = m_mul(v[e], tb);
+    }
+    uint4* o = reinterpret_cast<uint4*>(dst + 16 * (size_t)jhi);
+#pragma unroll
+    for (int q = 0; q < 4; q++) o[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+void is_first_coeffs(hipStream_t stream, const IsFirstCols& a, const u32* itw, u32 tw_root_log) {
+    if (a.log_min < 4 || a.log_max < a.log_min || a.log_max - a.log_min >= 28 || a.log_max > tw_root_log + 1) throw std::runtime_error("is_first_coeffs: unsupported sizes");
+    const u32 lanes = (1u << (a.log_max - 3)) - (1u << (a.log_min - 4));
+    hipLaunchKernelGGL(k_is_first_coeffs, dim3((lanes + 255) / 256), dim3(256), 0, stream, a, itw, 1u << tw_root_log);
+}
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One pass = layers [lo, lo+k) of a size-2^log transform, for the columns cols[by * cpb .. +cpb) of one GROUP (columns of one size and
+// storage). A launch covers several groups (PassArgs table in HBM, kernels.h): workgroup b belongs to the group g with
+// groups[g].block0 <= b < groups[g + 1].block0 and is its (tile, column block) = ((b - block0) % grid_x, (b - block0) / grid_x). The 13
+// components of a proof have ~10 distinct sizes: one launch per pass and kernel kind instead of one per size.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BlockOfGroup { u32 g, tile, by; };
+__device__ __forceinline__ BlockOfGroup find_group(const PassArgs* __restrict__ groups, u32 ngroups) {
+    u32 g = 0;
+    while (g + 1 < ngroups && groups[g + 1].block0 <= blockIdx.x) g++;      // uniform: scalar loads
+    const u32 local = blockIdx.x - groups[g].block0, gx = groups[g].grid_x;
+    return {g, local % gx, local / gx};
+}
 __device__ __forceinline__ const u32* layer_table(const PassArgs& a, u32 layer) {
     // line layer `layer` (>= 1 in circle mode, >= 0 in line mode): len = 2^(log-1-layer), table at tw_total - 2*len.
     // In line mode local layer j plays the role of circle-mode layer j+1 of a transform twice the size.
@@ -81,7 +115,9 @@ __device__ __forceinline__ const u32* layer_table(const PassArgs& a, u32 layer) 
 }
 
 template <bool INV>
-__global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
+__global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
     __shared__ u32 s_val[TILE];
     __shared__ u32 s_tw[TILE];  // per-layer twiddle segments of this tile, packed
     const u32 t = threadIdx.x;
@@ -90,7 +126,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
     const u32 tile_log = lo == 0 ? a.tile_log : k + c;
     const u32 tile_n = 1u << tile_log;
     const u32 kt = tile_log - c;   // twiddle span: local layer j needs 2^(kt-1-j) entries, staged at offset 2^kt - 2^(kt-j)
-    const u32 tile = blockIdx.x;
+    const u32 tile = bg.tile;
     // element (m, l) of the tile -> global index
     // contiguous: idx = tile * tile_n + m
     // strided   : idx = (H << (lo+k)) | (m << lo) | (Lhi << c) | l   with tile = H * 2^(lo-c) + Lhi
@@ -121,7 +157,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(PassArgs a) {
         s_tw[e] = v;
     }
 
-    const u32 col0 = blockIdx.y * a.cols_per_block;
+    const u32 col0 = bg.by * a.cols_per_block;
     const u32 col1 = min(a.ncols, col0 + a.cols_per_block);
     for (u32 col = col0; col < col1; col++) {
         g_cu32p src = as_global(a.src[col]);
@@ -202,12 +238,14 @@ template <bool INV, class TW> __device__ __forceinline__ void radix16(u32 (&v)[1
 __device__ __forceinline__ u32 lds_pad(u32 i) { return i + 4 * (i >> 6); }
 
 template <bool INV>
-__global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
+__global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
     __shared__ __attribute__((aligned(16))) u32 s_val[4096 + 4 * 64];
     __shared__ u32 s_tw[4096];
-    const u32 t = threadIdx.x, k = a.k, tile = blockIdx.x;
+    const u32 t = threadIdx.x, k = a.k, tile = bg.tile;
     const u32 base = tile << 12;
-    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     // The tile of the next column is fetched while the current one is transformed (16 more registers, same occupancy): without it
     // every column starts with an exposed HBM round trip, which costs ~25 % when a block has only a few columns.
     uint4 nxt[4];
@@ -334,11 +372,13 @@ __global__ void __launch_bounds__(256) k_fft_tile12(PassArgs a) {
 // CL = log2 of the cells per row: 5 (128-byte rows, 128 lanes) or 6 (256-byte rows, 256 lanes: longer contiguous bursts per DRAM page at
 // the same per-lane work; needs lo >= 6). Per lane always 32 cells: 8 rows x 4 cells in the 16-byte phase, 2 x 16 in the 4-byte phase.
 template <bool INV, int CL>
-__global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(PassArgs a) {
+__global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
     constexpr u32 C = 1u << CL, NT = 4u << CL;
     __shared__ __attribute__((aligned(16))) u32 s_val[128 * C];
     __shared__ u32 s_tw[128];
-    const u32 t = threadIdx.x, lo = a.lo, tile = blockIdx.x;
+    const u32 t = threadIdx.x, lo = a.lo, tile = bg.tile;
     const u32 n_lhi_log = lo - CL;
     const u32 H = tile >> n_lhi_log, Lhi = tile & ((1u << n_lhi_log) - 1);
     const u32 base = (H << (lo + 7)) | (Lhi << CL);
@@ -349,7 +389,7 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(PassArgs a) {
         s_tw[t] = layer_table(a, lo + j)[(H << (6 - j)) + q];
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[128u - (128u >> layer) + idx]; };
-    const u32 col0 = blockIdx.y * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     const u32 l4 = 4 * (t & (C / 4 - 1)), r4 = t >> (CL - 2);      // 16-byte phase: rows m = 8*r4 + q (q = 0..7), cells l4..l4+3
     for (u32 col = col0; col < col1; col++) {
         g_cu32p src = as_global(a.src[col]);
@@ -411,8 +451,10 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(PassArgs a) {
 // Tiny transforms (log <= 5): one thread per column, straight loops over registers/local memory. Only the handful of
 // 16..32-cell columns of empty sub-component tables take this route.
 template <bool INV>
-__global__ void k_fft_tiny(PassArgs a) {
-    u32 col = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
+    u32 col = bg.tile * blockDim.x + threadIdx.x;
     if (col >= a.ncols) return;
     u32 n = 1u << a.log;
     u32 v[32];
@@ -436,96 +478,152 @@ __global__ void k_fft_tiny(PassArgs a) {
 }
 
 // Host-side pass planner. Inverse: contiguous pass first then strided passes upward; forward: mirror image.
-void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* const* d_dst, u32 ncols, u32 log, u32 src_log, bool circle,
-               const u32* tw, const u32* itw, u32 tw_root_log) {
-    if (ncols == 0) return;
-    PassArgs a{};
-    a.ncols = ncols; a.log = log; a.circle = circle ? 1 : 0; a.tw = inverse ? itw : tw; a.tw_total = 1u << tw_root_log; a.scale = 1;
-    if (log > 5 && src_log < 2) throw std::runtime_error("fft_batch: extending a polynomial with fewer than 4 coefficients to more than 32 cells is not supported");
-    const u32 nl = inverse ? log : src_log;   // forward: the layers >= src_log only duplicate (zero extension) = wrap-around load
-    if (log <= 5) {
-        a.dst = d_dst; a.src = d_src; a.src_mask = (1u << src_log) - 1; a.lo = 0; a.k = nl;
-        a.scale = inverse ? m_inv(1u << log) : 1;
-        if (inverse) hipLaunchKernelGGL(k_fft_tiny<true>, dim3((ncols + 63) / 64), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL(k_fft_tiny<false>, dim3((ncols + 63) / 64), dim3(64), 0, stream, a);
-        return;
-    }
-    // ---- fast path: 2^12-cell contiguous pass with k0 in [6,12] layers + strided passes of exactly 7 layers ----------------
-    if (log >= 12 && nl >= 6) {
-        u32 ns = nl > 12 ? (nl - 12 + 6) / 7 : 0;
-        u32 k0 = nl - 7 * ns;
-        int np = 1 + (int)ns;
-        // profiler accounting: `bytes` = what this pass moves (4 B in + 4 B out per cell), `units` = this pass's share of the transform's
-        // ALGORITHMIC bytes (iFFT 8N, LDE 12N per column = read the input once, write the output once)
+// fft_plan lays out the passes of every job (one job = the columns of one size and storage); the pass a job executes pi-th goes into
+// the launch (pi, kernel kind), so a batch of jobs costs at most (passes of the largest job) x (kinds in use) launches.
+enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_KINDS = 5 };
+
+void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, const u32* tw, const u32* itw, u32 tw_root_log) {
+    plan.inverse = inverse; plan.groups.clear(); plan.launches.clear(); plan.d_groups = nullptr;
+    struct Item { int pi, kind; PassArgs a; double bytes, alg; };
+    std::vector<Item> items;
+    int max_np = 0;
+    for (size_t ji = 0; ji < njobs; ji++) {
+        const FftJob& job = jobs[ji];
+        const u32 ncols = job.ncols, log = job.log, src_log = job.src_log;
+        if (ncols == 0) continue;
+        PassArgs a{};
+        a.ncols = ncols; a.log = log; a.circle = job.circle ? 1 : 0; a.tw = inverse ? itw : tw; a.tw_total = 1u << tw_root_log; a.scale = 1;
+        if (log > 5 && src_log < 2) throw std::runtime_error("fft: extending a polynomial with fewer than 4 coefficients to more than 32 cells is not supported");
+        const u32 nl = inverse ? log : src_log;   // forward: the layers >= src_log only duplicate (zero extension) = wrap-around load
+        if (log <= 5) {
+            a.dst = job.d_dst; a.src = job.d_src; a.src_mask = (1u << src_log) - 1; a.lo = 0; a.k = nl;
+            a.scale = inverse ? m_inv(1u << log) : 1;
+            a.grid_x = (ncols + 63) / 64; a.cols_per_block = 1;
+            items.push_back({0, K_TINY, a, 0.0, 0.0});
+            max_np = std::max(max_np, 1);
+            continue;
+        }
+        // ---- fast path: 2^12-cell contiguous pass with k0 in [6,12] layers + strided passes of exactly 7 layers ----------------
+        if (log >= 12 && nl >= 6) {
+            u32 ns = nl > 12 ? (nl - 12 + 6) / 7 : 0;
+            u32 k0 = nl - 7 * ns;
+            int np = 1 + (int)ns;
+            max_np = std::max(max_np, np);
+            // profiler accounting: `bytes` = what this pass moves (4 B in + 4 B out per cell), `alg` = this pass's share of the transform's
+            // ALGORITHMIC bytes (iFFT 8N, LDE 12N per column = read the input once, write the output once)
+            const double alg = 4.0 * ncols * ((double)(1u << src_log) + (double)(1u << log)) / np;
+            for (int pi = 0; pi < np; pi++) {
+                int p = inverse ? pi : np - 1 - pi;
+                bool first = pi == 0, last = pi == np - 1;
+                a.src = first ? job.d_src : (const u32* const*)job.d_dst;
+                a.dst = job.d_dst;
+                a.src_mask = first ? ((1u << src_log) - 1) : 0xffffffffu;
+                a.scale = (inverse && last) ? m_inv(1u << log) : 1;
+                u32 ntiles = 1u << (log - 12);
+                // one workgroup walks as many columns as possible per tile (twiddles staged once), as long as >= 2048 workgroups remain
+                u32 cpb = ncols;
+                while (cpb > 1 && (u64)ntiles * ((ncols + cpb - 1) / cpb) < 2048) cpb = (cpb + 1) / 2;
+                a.cols_per_block = cpb;
+                const u32 gy = (ncols + cpb - 1) / cpb;
+                const double bytes = 8.0 * ncols * (double)(1u << log);
+                if (p == 0) {
+                    a.lo = 0; a.k = k0; a.tile_log = 12; a.grid_x = ntiles;
+                    PassArgs b = a; b.block0 = gy;      // block0 temporarily holds the group's grid_y
+                    items.push_back({pi, K_TILE12, b, bytes, alg});
+                } else {
+                    a.lo = k0 + 7 * (p - 1); a.k = 7;
+#ifndef BF_STRIDED_WIDE_MIN_LOG
+#define BF_STRIDED_WIDE_MIN_LOG 20
+#endif
+                    // 256-byte rows for big transforms (enough tiles to fill the chip twice over), 128-byte rows otherwise
+                    const bool wide = a.lo >= 6 && log >= BF_STRIDED_WIDE_MIN_LOG;
+                    PassArgs b = a; b.grid_x = wide ? ntiles / 2 : ntiles; b.block0 = gy;
+                    items.push_back({pi, wide ? K_STRIDED6 : K_STRIDED5, b, bytes, alg});
+                }
+            }
+            continue;
+        }
+        // pass boundaries: [0, k0) contiguous, then strided passes [k0, k0 + k1), ...
+        u32 bounds[8]; int np = 0;
+        bounds[0] = 0;
+        a.tile_log = log < (u32)TILE_LOG ? log : (u32)TILE_LOG;
+        u32 k0 = nl < a.tile_log ? nl : a.tile_log;
+        bounds[++np] = k0;
+        while (bounds[np] < nl) {
+            u32 rem = nl - bounds[np];
+            u32 passes_left = (rem + STRIDED_K - 1) / STRIDED_K;
+            u32 kk = (rem + passes_left - 1) / passes_left;  // balance the strided passes
+            bounds[np + 1] = bounds[np] + kk; np++;
+        }
+        max_np = std::max(max_np, np);
         const double alg = 4.0 * ncols * ((double)(1u << src_log) + (double)(1u << log)) / np;
         for (int pi = 0; pi < np; pi++) {
             int p = inverse ? pi : np - 1 - pi;
             bool first = pi == 0, last = pi == np - 1;
-            a.src = first ? d_src : (const u32* const*)d_dst;
-            a.dst = d_dst;
+            a.lo = bounds[p]; a.k = bounds[p + 1] - bounds[p];
+            u32 tl = a.lo == 0 ? a.tile_log : a.k + CHUNK_LOG;
+            u32 ntiles = 1u << (log - tl);
+            a.src = first ? job.d_src : (const u32* const*)job.d_dst;
+            a.dst = job.d_dst;
             a.src_mask = first ? ((1u << src_log) - 1) : 0xffffffffu;
             a.scale = (inverse && last) ? m_inv(1u << log) : 1;
-            u32 ntiles = 1u << (log - 12);
-            // one workgroup walks as many columns as possible per tile (twiddles staged once), as long as >= 2048 workgroups remain
-            u32 cpb = ncols;
-            while (cpb > 1 && (u64)ntiles * ((ncols + cpb - 1) / cpb) < 2048) cpb = (cpb + 1) / 2;
+            // columns per block: enough blocks to fill the chip, as few twiddle re-loads as possible
+            u32 cpb = 1;
+            while ((u64)ntiles * ((ncols + cpb - 1) / cpb) > 8192 && cpb < ncols) cpb *= 2;
             a.cols_per_block = cpb;
-            dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
-            if (p == 0) {
-                a.lo = 0; a.k = k0; a.tile_log = 12;
-                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", 8.0 * ncols * (double)(1u << log), alg);
-                if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, a);
-                else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, a);
-            } else {
-                a.lo = k0 + 7 * (p - 1); a.k = 7;
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", 8.0 * ncols * (double)(1u << log), alg);
-#ifndef BF_STRIDED_WIDE_MIN_LOG
-#define BF_STRIDED_WIDE_MIN_LOG 20
-#endif
-                // 256-byte rows for big transforms (enough tiles to fill the chip twice over), 128-byte rows otherwise
-                if (a.lo >= 6 && log >= BF_STRIDED_WIDE_MIN_LOG) {
-                    dim3 gw(ntiles / 2, grid.y);
-                    if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), gw, dim3(256), 0, stream, a);
-                    else hipLaunchKernelGGL((k_fft_strided7<false, 6>), gw, dim3(256), 0, stream, a);
-                } else {
-                    if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 5>), grid, dim3(128), 0, stream, a);
-                    else hipLaunchKernelGGL((k_fft_strided7<false, 5>), grid, dim3(128), 0, stream, a);
-                }
-            }
+            PassArgs b = a; b.grid_x = ntiles; b.block0 = (ncols + cpb - 1) / cpb;
+            items.push_back({pi, K_PASS, b, 8.0 * ncols * (double)(1u << log), alg});
         }
-        return;
     }
-    // pass boundaries: [0, k0) contiguous, then strided passes [k0, k0 + k1), ...
-    u32 bounds[8]; int np = 0;
-    bounds[0] = 0;
-    a.tile_log = log < (u32)TILE_LOG ? log : (u32)TILE_LOG;
-    u32 k0 = nl < a.tile_log ? nl : a.tile_log;
-    bounds[++np] = k0;
-    while (bounds[np] < nl) {
-        u32 rem = nl - bounds[np];
-        u32 passes_left = (rem + STRIDED_K - 1) / STRIDED_K;
-        u32 kk = (rem + passes_left - 1) / passes_left;  // balance the strided passes
-        bounds[np + 1] = bounds[np] + kk; np++;
-    }
-    const double alg = 4.0 * ncols * ((double)(1u << src_log) + (double)(1u << log)) / np;
-    for (int pi = 0; pi < np; pi++) {
-        int p = inverse ? pi : np - 1 - pi;
-        bool first = pi == 0, last = pi == np - 1;
-        a.lo = bounds[p]; a.k = bounds[p + 1] - bounds[p];
-        u32 tl = a.lo == 0 ? a.tile_log : a.k + CHUNK_LOG;
-        u32 ntiles = 1u << (log - tl);
-        a.src = first ? d_src : (const u32* const*)d_dst;
-        a.dst = d_dst;
-        a.src_mask = first ? ((1u << src_log) - 1) : 0xffffffffu;
-        a.scale = (inverse && last) ? m_inv(1u << log) : 1;
-        // columns per block: enough blocks to fill the chip, as few twiddle re-loads as possible
-        u32 cpb = 1;
-        while ((u64)ntiles * ((ncols + cpb - 1) / cpb) > 8192 && cpb < ncols) cpb *= 2;
-        a.cols_per_block = cpb;
-        dim3 grid(ntiles, (ncols + cpb - 1) / cpb);
-        ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", 8.0 * ncols * (double)(1u << log), alg);
-        if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, a);
-        else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, a);
+    for (int pi = 0; pi < max_np; pi++)
+        for (int kind = 0; kind < K_KINDS; kind++) {
+            FftLaunch L{}; L.kind = kind; L.first_group = (u32)plan.groups.size();
+            u32 blocks = 0;
+            for (auto& it : items) {
+                if (it.pi != pi || it.kind != kind) continue;
+                PassArgs a = it.a;
+                const u32 gy = kind == K_TINY ? 1u : a.block0;
+                a.block0 = blocks; blocks += a.grid_x * gy;
+                plan.groups.push_back(a);
+                L.bytes += it.bytes; L.alg += it.alg;
+            }
+            L.ngroups = (u32)plan.groups.size() - L.first_group; L.total_blocks = blocks;
+            if (L.ngroups) plan.launches.push_back(L);
+        }
+}
+
+void fft_run(hipStream_t stream, const FftPlan& plan) {
+    if (plan.launches.empty()) return;
+    if (!plan.d_groups) throw std::runtime_error("fft_run: the plan's group table has not been staged");
+    const bool inverse = plan.inverse;
+    for (const FftLaunch& L : plan.launches) {
+        const PassArgs* g = plan.d_groups + L.first_group;
+        const dim3 grid(L.total_blocks);
+        switch (L.kind) {
+            case K_TILE12: {
+                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, g, L.ngroups);
+                break; }
+            case K_STRIDED5: {
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL((k_fft_strided7<false, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
+                break; }
+            case K_STRIDED6: {
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL((k_fft_strided7<false, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
+                break; }
+            case K_PASS: {
+                ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
+                break; }
+            default:
+                if (inverse) hipLaunchKernelGGL(k_fft_tiny<true>, grid, dim3(64), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL(k_fft_tiny<false>, grid, dim3(64), 0, stream, g, L.ngroups);
+        }
     }
 }
 

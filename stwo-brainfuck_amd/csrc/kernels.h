@@ -4,6 +4,7 @@
 #include "m31.h"
 #include "air.h"
 #include <string>
+#include <vector>
 
 namespace bf {
 
@@ -57,11 +58,38 @@ __device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
 
 // fft.hip
 void gen_twiddles(hipStream_t stream, u32* d_tw, u32* d_itw, u32 R, const uint2* d_tlo, const uint2* d_thi);
-// Batched transform of `ncols` columns of 2^log cells. inverse: evaluations (bit-reversed) -> coefficients, scaled by 2^-log.
+// Transforms of columns of 2^log cells, batched over JOBS (one job = the columns of one size and storage).
+// inverse: evaluations (bit-reversed) -> coefficients, scaled by 2^-log.
 // forward: coefficients of 2^src_log (zero-extended to 2^log) -> evaluations on the canonic domain of size 2^log.
 // circle = false selects "line mode" (no circle layer) used for 16x-replicated columns stored row-granular.
-void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* const* d_dst, u32 ncols, u32 log, u32 src_log, bool circle,
-               const u32* tw, const u32* itw, u32 tw_root_log);
+// d_src / d_dst: DEVICE arrays of column pointers.
+struct FftJob { const u32* const* d_src; u32* const* d_dst; u32 ncols, log, src_log; bool circle; };
+// One pass of one job (fft.hip). A launch covers several of them: workgroups [block0, block0 + grid_x * grid_y) belong to this one.
+struct PassArgs {
+    u32* const* dst;          // device array of column pointers (output / in-place)
+    const u32* const* src;    // device array of column pointers (input of this pass)
+    u32 ncols, cols_per_block;
+    u32 log;                  // transform size
+    u32 lo, k;                // layers [lo, lo + k)
+    u32 tile_log;             // contiguous pass (lo == 0): tile = 2^tile_log >= 2^k cells; strided: tile = 2^(k + CHUNK_LOG)
+    u32 src_mask;             // input index mask (2^src_log - 1): forward zero-extension = wrap-around load
+    u32 circle;               // 1: layer 0 is the circle layer; 0: line mode
+    u32 scale;                // inverse: multiply outputs by this (1 = none)
+    u32 tw_total;             // 2^R
+    const u32* tw;            // twiddle (forward) or inverse-twiddle (inverse) layered buffer
+    u32 block0, grid_x;       // first workgroup of this group within its launch; tiles per column block
+};
+struct FftLaunch { int kind; u32 first_group, ngroups, total_blocks; double bytes, alg; };
+// fft_plan: host-side layout of every pass of every job; the caller copies plan.groups to device memory the stream can read (the
+// staging ring: one copy together with the pointer arrays) and sets d_groups; fft_run issues the launches.
+struct FftPlan { bool inverse = false; std::vector<PassArgs> groups; std::vector<FftLaunch> launches; const PassArgs* d_groups = nullptr; };
+void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, const u32* tw, const u32* itw, u32 tw_root_log);
+void fft_run(hipStream_t stream, const FftPlan& plan);
+
+// Coefficients of IsFirst(n) (indicator of cell 0 of the 2^n-cell canonic domain), n = log_min..log_max, written in closed form by one
+// launch: ptr[n - log_min] receives 2^n words (nullptr: skipped).
+struct IsFirstCols { u32* ptr[28]; u32 log_min, log_max; };
+void is_first_coeffs(hipStream_t stream, const IsFirstCols& a, const u32* itw, u32 tw_root_log);
 
 // merkle.hip
 // out_shift / prev_shift: replication of this layer / of the child layer (nodes are stored at index node >> shift)
@@ -69,8 +97,32 @@ void fft_batch(hipStream_t stream, bool inverse, const u32* const* d_src, u32* c
 // node_conv = Conventions::merkle_node_hash
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
                   u32 node_conv, u32 first = 0, u32 count = 0);
+// A tree's layout in HBM for the kernels that walk several levels (merkle_subtree, merkle_top): layer pointers and replication shifts by
+// level, the column descriptors of all levels in one array (level `lg` owns cols[col_off[lg] .. col_off[lg - 1]), levels descending,
+// col_off[-1] := n_cols).
+struct MerkleTreeDesc { uint4* layers[32]; u32 shifts[32]; u32 col_off[32]; const ColDesc* cols; u32 n_cols, max_log; };
+// levels [hi .. 10] in one launch, 11 <= hi <= 17, all of them un-replicated; bytes / compressions: profiler accounting
+void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions);
+// levels [top_hi .. 0] by one workgroup, top_hi <= 9 (children of level top_hi from level top_hi + 1 in HBM unless top_hi == max_log);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32 node_conv, u32* d_chan = nullptr, u32* d_alpha8 = nullptr, u32* d_root_copy = nullptr);
+void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions);
+// The FRI commit phase below 2^10 rows as ONE single-workgroup launch (merkle.hip: k_fri_tail): per layer the Merkle tree of its 4 coordinate
+// columns, the channel step (mix_root, draw alpha), the fold into the next layer (+ fold-in of the quotient of that size), all through LDS;
+// evaluations, hashes, roots and alphas also go to HBM for the decommitment and the host's channel replay.
+struct FriTailLayer {
+    u32* ev[4];             // this layer's evaluations (2^log rows), already in HBM for the first layer, written by the kernel for the others
+    const u32* quot[4];     // circle evaluation of 2^log rows folded into the NEXT layer, or nullptr
+    uint4* tree[11];        // tree[lg] = level lg of this layer's Merkle tree, lg <= log
+};
+struct FriTailArgs {
+    u32 n_layers, top_log;  // layers of 2^top_log, 2^(top_log - 1), ... rows are committed; top_log <= 10
+    u32 alpha_idx, root_idx;// layer k draws alpha[8 * (alpha_idx + k)] and copies its root to roots[8 * (root_idx + k)]
+    u32* ev_last[4];        // the layer after the last committed one (2^(top_log - n_layers) rows)
+    u32* chan; u32* alpha; u32* roots;
+    const u32* itw; u32 tw_total, rfc;
+    FriTailLayer layer[10];
+};
+void fri_tail(hipStream_t stream, const FriTailArgs* d_args);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.
@@ -98,6 +150,12 @@ struct ConstraintLaunch {
 // replicated columns share a stored cell)
 void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size, u32 n_rows = 0, u32 group_rows = 0);
 u32 constraint_group_rows(const ConstraintLaunch& L, int comp);
+// All components of a proof in one launch: classes = components of equal log_size (one accumulator each). The first component of a class
+// must carry overwrite = 1 and the others 0 (row-group mode updates the accumulator per component; per-row mode writes the class sum once).
+struct ConstraintClass { u32 n_comps, block0, group_rows, pad_; u32 comp[13]; u32 pad2_[3]; };
+struct ConstraintBatch { u32 n_classes, total_blocks, pad_[2]; ConstraintClass cls[13]; };
+void constraint_batch_init(ConstraintBatch& b, const ConstraintLaunch* launches, u32 n);
+void eval_constraints_batch(hipStream_t stream, const ConstraintBatch* d_batch, const ConstraintBatch& h_batch, const ConstraintLaunch* d_args);
 struct LogupLaunch {
     const u32* cols[13];   // row-granular main columns
     u32* out_rep[8];       // row-granular coordinate columns of the non-last logUp columns
@@ -105,7 +163,12 @@ struct LogupLaunch {
     void* vrow; void* wloc; void* totals; void* claimed;   // scratch: uint4[M], uint4[M], uint4[M/1024 + 2], uint4[1]
     Lookups el; u32 log_rows; int comp;
 };
-void logup_generate(hipStream_t stream, const LogupLaunch& L);
+// The logUp generation of up to 13 components as ONE batch of four launches. LogupBatch is the device-side table (the caller copies it to
+// memory the stream can read — the staging ring — and passes both the device address and the host copy).
+struct LogupItem { const u32* cols[13]; u32* out_rep[8]; u32* out_last[4]; uint4* vrow; uint4* wloc; uint4* totals; uint4* claimed; u32 log_rows; int comp; u32 nb; u32 pad_; };
+struct LogupBatch { Lookups el; u32 n; u32 rows_blk0[14], scan_blk0[14], last_blk0[14]; u32 pad_; LogupItem item[13]; };
+void logup_batch_init(LogupBatch& b, const Lookups& el, const LogupLaunch* L, u32 n);
+void logup_batch_run(hipStream_t stream, const LogupBatch* d_batch, const LogupBatch& h_batch);
 void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells);
 
 // quotient.hip
@@ -122,6 +185,9 @@ void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
 void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh = false,
                            u32 first = 0, u32 count = 0);
 void fold_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, u32 first = 0, u32 count = 0);
+// dst = fold_line(src of 2^log rows, alpha) and, when quot != nullptr (a circle evaluation of 2^log rows), dst = dst * alpha^2 + fold_circle(quot, alpha)
+void fold_line_circle(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* const quot[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log,
+                      u32 first = 0, u32 count = 0);
 // dst[i] = src[index of the row at trace-coset offset -1 of LDE row i] over a whole column of 2^(log_size+1) cells (blowup 2) — the
 // "previous-row copy" a column owner materialises before the column is cut into row ranges
 void prev_row_copy(hipStream_t stream, u32* dst, const u32* src, u32 log_size);

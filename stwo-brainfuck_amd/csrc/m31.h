@@ -44,6 +44,7 @@ BF_HD u32 m_reduce64(u64 x) {  // x < P^2 -> [0, P)
 }
 BF_HD u32 m_mul(u32 a, u32 b) { return m_reduce64((u64)a * b); }
 BF_HD u32 m_sqr(u32 a) { return m_mul(a, a); }
+BF_HD u32 m_inv_pow2(u32 n) { return 1u << ((31u - n % 31u) % 31u); }   // 2^-n: 2^31 = 1 (mod P)
 BF_HD u32 m_pow(u32 b, u32 e) { u32 r = 1; while (e) { if (e & 1) r = m_mul(r, b); b = m_mul(b, b); e >>= 1; } return r; }
 // x^(P-2) with the 2^31-3 addition chain (37 multiplications)
 BF_HD u32 m_sqn(u32 x, int n) { for (int i = 0; i < n; i++) x = m_sqr(x); return x; }

@@ -63,24 +63,20 @@ __device__ __forceinline__ void node_init(u32 (&h)[8], u32 rfc) {
     for (int k = 0; k < 8; k++) h[k] = B2S_IV[k] & rfc;
     h[0] ^= 0x01010020u & rfc;
 }
-__device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
-                                            u32 out_shift, u32 prev_shift, u32 rfc) {
-    const u32 i = st << out_shift;          // representative node of this stored slot
-    u32 h[8];
+// Hash of node i: the two child hashes (a, b = left, c, d = right) when has_children, then the LE-u32 values of the ncols columns at row i.
+__device__ __forceinline__ void merkle_node_hash(u32 (&h)[8], bool has_children, uint4 a, uint4 b, uint4 c, uint4 d, const ColDesc* __restrict__ cols, u32 ncols, u32 i, u32 rfc) {
     node_init(h, rfc);
-    const u32 total_bytes = (prev ? 64u : 0u) + 4u * ncols;
+    const u32 total_bytes = (has_children ? 64u : 0u) + 4u * ncols;
     u32 m[16];
     u32 done = 0;   // bytes compressed so far
     u32 c0 = 0;     // next column to absorb
-    if (prev) {
-        const size_t cl = ((size_t)2 * i) >> prev_shift, cr = ((size_t)2 * i + 1) >> prev_shift;   // stored slots of the two children
-        uint4 a = prev[2 * cl], b = prev[2 * cl + 1], c = prev[2 * cr], d = prev[2 * cr + 1];
+    if (has_children) {
         m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
         m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
         done = 64;
         bool last = total_bytes == 64;
         blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
-        if (last) { store_hash(out, st, h); return; }
+        if (last) return;
     }
     // remaining message: column values, 16 words per block (zero padded)
     for (;;) {
@@ -104,6 +100,17 @@ __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, con
         blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
         if (last) break;
     }
+}
+__device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
+                                            u32 out_shift, u32 prev_shift, u32 rfc) {
+    const u32 i = st << out_shift;          // representative node of this stored slot
+    u32 h[8];
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
+    if (prev) {
+        const size_t cl = ((size_t)2 * i) >> prev_shift, cr = ((size_t)2 * i + 1) >> prev_shift;   // stored slots of the two children
+        a = prev[2 * cl]; b = prev[2 * cl + 1]; c = prev[2 * cr]; d = prev[2 * cr + 1];
+    }
+    merkle_node_hash(h, prev != nullptr, a, b, c, d, cols, ncols, i, rfc);
     store_hash(out, st, h);
 }
 // Grid-stride over the stored nodes: large layers give every lane several nodes, which amortises wave launch and the kernel prologue.
@@ -144,7 +151,7 @@ __global__ void __launch_bounds__(256) k_merkle_layer(uint4* __restrict__ out, c
 // removes the device -> host -> device round trip between consecutive layers. One lane; two compressions plus rare redraws.
 // chan = digest[8] || n_sent. alpha_out = alpha[4] || alpha^2[4]. root_out receives a copy of the root (the roots of all layers are
 // collected in one array and read back once).
-__device__ void channel_step(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out) {
+__device__ void channel_step(u32* __restrict__ chan, const u32* __restrict__ root, u32* __restrict__ alpha_out, u32* __restrict__ root_out, u32* alpha_lds = nullptr) {
     u32 h[8], m[16], digest[8];
     // mix_root: digest = Blake2s(digest || root), n_sent = 0
     for (int k = 0; k < 8; k++) { m[k] = chan[k]; m[8 + k] = root[k]; root_out[k] = root[k]; h[k] = B2S_IV[k]; }   // root_out: contiguous copy for one read-back
@@ -166,6 +173,7 @@ __device__ void channel_step(u32* __restrict__ chan, const u32* __restrict__ roo
     Q31 sq = q_mul(alpha, alpha);
     alpha_out[0] = alpha.a.a; alpha_out[1] = alpha.a.b; alpha_out[2] = alpha.b.a; alpha_out[3] = alpha.b.b;
     alpha_out[4] = sq.a.a; alpha_out[5] = sq.a.b; alpha_out[6] = sq.b.a; alpha_out[7] = sq.b.b;
+    if (alpha_lds) { for (int k = 0; k < 8; k++) alpha_lds[k] = alpha_out[k]; }
     for (int k = 0; k < 8; k++) chan[k] = digest[k];
     chan[8] = n_sent;
 }
@@ -174,36 +182,148 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
     channel_step(chan, root, alpha_out, root_out);
 }
 
-// Fused top of the tree: levels [top_log-1 .. 0] (no columns enter there) by a single workgroup; saves one launch per level.
-// With chan != nullptr the workgroup's first lane then performs the channel step on the fresh root (FRI commit phase): one launch less
-// per layer on the latency-bound path root -> alpha -> next fold.
-__global__ void __launch_bounds__(256) k_merkle_top(uint4* const* __restrict__ layers, u32 top_log, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
-    // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
-    // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
-    __shared__ uint4 s_lv[2][1024];
-    for (int lg = (int)top_log - 1; lg >= 0; lg--) {
-        const uint4* prev = layers[lg + 1];
-        uint4* out = layers[lg];
-        const bool from_lds = lg + 1 < (int)top_log && lg + 1 <= 9;      // level lg + 1 was produced by this kernel and fits a buffer (<= 512 nodes)
-        const uint4* src = s_lv[(lg + 1) & 1];
-        uint4* dst = s_lv[lg & 1];
-        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
-            u32 h[8], m[16];
-            node_init(h, rfc);
-            uint4 a, b, c, d;
-            if (from_lds) { a = src[4 * i]; b = src[4 * i + 1]; c = src[4 * i + 2]; d = src[4 * i + 3]; }
-            else { a = prev[4 * i]; b = prev[4 * i + 1]; c = prev[4 * i + 2]; d = prev[4 * i + 3]; }
-            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
-            m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
-            blake2s_compress(h, m, 64u & rfc, rfc);
-            const uint4 lo = make_uint4(h[0], h[1], h[2], h[3]), hi = make_uint4(h[4], h[5], h[6], h[7]);
-            out[2 * i] = lo; out[2 * i + 1] = hi;
-            if (lg <= 9) { dst[2 * i] = lo; dst[2 * i + 1] = hi; }
+// ---- the small end of a tree in two launches ---------------------------------------------------------------------------------------
+// Below 2^18 nodes a layer launch is pure latency (~5 us for < 2 us of work) and the layers form a dependent chain. With the tree's layout
+// in HBM (MerkleTreeDesc: layer pointers, per-level column lists) two kernels cover it:
+//   k_merkle_subtree: levels [hi .. 10], hi <= 17 — one workgroup per node of level 10 hashes that node's subtree: its 2^(hi-10) nodes of
+//                     level hi (children from level hi + 1 in HBM, or none: leaves), then level by level through LDS;
+//   k_merkle_top:     levels [min(max_log, 9) .. 0] by a single workgroup (children of its first level from HBM), columns included, then
+//                     (FRI commit phase) the channel step on the root.
+// Every level is also written to HBM: the decommitment reads hashes from there. Un-replicated levels only (node i stored at i).
+__device__ __forceinline__ void hash_to_lds(uint4* __restrict__ s, u32 j, const u32 (&h)[8]) { s[2 * j] = make_uint4(h[0], h[1], h[2], h[3]); s[2 * j + 1] = make_uint4(h[4], h[5], h[6], h[7]); }
+__device__ __forceinline__ void hash_to_hbm(uint4* __restrict__ out, u32 i, const u32 (&h)[8]) { out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]); }
+
+__global__ void __launch_bounds__(128) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
+    __shared__ uint4 s_lv[2][2 * 128];
+    const MerkleTreeDesc& td = *tdp;
+    const u32 lo = 10, b = blockIdx.x, j = threadIdx.x;
+    for (u32 lg = hi; lg >= lo; lg--) {
+        const u32 n = 1u << (lg - lo);
+        if (j < n) {
+            const u32 i = (b << (lg - lo)) + j;
+            const ColDesc* cols = td.cols + td.col_off[lg];
+            const u32 ncols = td.col_off[lg - 1] - td.col_off[lg];      // col_off is indexed by level, descending levels are laid out ascending
+            u32 h[8];
+            uint4 a = make_uint4(0, 0, 0, 0), bb = a, c = a, d = a;
+            bool has = true;
+            if (lg == hi) {
+                has = hi < td.max_log;
+                if (has) {
+                    const uint4* prev = td.layers[hi + 1];
+                    const u32 ps = td.shifts[hi + 1];
+                    const size_t cl = ((size_t)2 * i) >> ps, cr = ((size_t)2 * i + 1) >> ps;
+                    a = prev[2 * cl]; bb = prev[2 * cl + 1]; c = prev[2 * cr]; d = prev[2 * cr + 1];
+                }
+            } else {
+                const uint4* src = s_lv[(lg + 1) & 1];
+                a = src[4 * j]; bb = src[4 * j + 1]; c = src[4 * j + 2]; d = src[4 * j + 3];
+            }
+            merkle_node_hash(h, has, a, bb, c, d, cols, ncols, i, rfc);
+            hash_to_hbm(td.layers[lg], i, h);
+            hash_to_lds(s_lv[lg & 1], j, h);
         }
-        __threadfence_block();
         __syncthreads();
     }
-    if (chan && threadIdx.x == 0) channel_step(chan, reinterpret_cast<const u32*>(layers[0]), alpha_out, root_out);
+}
+
+__global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __restrict__ tdp, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
+    // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
+    // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
+    __shared__ uint4 s_lv[2][2 * 512];
+    const MerkleTreeDesc& td = *tdp;
+    for (int lg = (int)top_hi; lg >= 0; lg--) {
+        const ColDesc* cols = td.cols + td.col_off[lg];
+        const u32 ncols = (lg > 0 ? td.col_off[lg - 1] : td.n_cols) - td.col_off[lg];
+        const bool first = lg == (int)top_hi;
+        const bool has = !first || top_hi < td.max_log;
+        const uint4* prev = first && has ? td.layers[lg + 1] : nullptr;
+        const uint4* src = s_lv[(lg + 1) & 1];
+        uint4* dst = s_lv[lg & 1];
+        uint4* out = td.layers[lg];
+        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
+            u32 h[8];
+            uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
+            if (has) {
+                if (first) { a = prev[4 * i]; b = prev[4 * i + 1]; c = prev[4 * i + 2]; d = prev[4 * i + 3]; }
+                else { a = src[4 * i]; b = src[4 * i + 1]; c = src[4 * i + 2]; d = src[4 * i + 3]; }
+            }
+            merkle_node_hash(h, has, a, b, c, d, cols, ncols, i, rfc);
+            hash_to_hbm(out, i, h);
+            hash_to_lds(dst, i, h);
+        }
+        __syncthreads();
+    }
+    if (chan && threadIdx.x == 0) {
+        __threadfence_block();
+        channel_step(chan, reinterpret_cast<const u32*>(td.layers[0]), alpha_out, root_out);
+    }
+}
+
+// ---- FRI commit phase below 2^10 rows: one launch ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict__ ap) {
+    __shared__ u32 s_ev[2][4][1024];
+    __shared__ uint4 s_h[2][2 * 1024];
+    __shared__ u32 s_alpha[8];
+    const FriTailArgs& a = *ap;
+    const u32 t = threadIdx.x, rfc = a.rfc;
+    for (u32 i = t; i < (1u << a.top_log); i += 256)
+        for (int w = 0; w < 4; w++) s_ev[0][w][i] = a.layer[0].ev[w][i];
+    __syncthreads();
+    for (u32 k = 0; k < a.n_layers; k++) {
+        const u32 log = a.top_log - k;
+        const FriTailLayer& L = a.layer[k];
+        u32 (*ev)[1024] = s_ev[k & 1];
+        // leaves: node i = hash of the 4 coordinate values of row i (16 bytes, one compression)
+        for (u32 i = t; i < (1u << log); i += 256) {
+            u32 h[8], m[16];
+            node_init(h, rfc);
+#pragma unroll
+            for (int w = 4; w < 16; w++) m[w] = 0;
+            m[0] = ev[0][i]; m[1] = ev[1][i]; m[2] = ev[2][i]; m[3] = ev[3][i];
+            blake2s_compress(h, m, 16u & rfc, rfc);
+            hash_to_hbm(L.tree[log], i, h);
+            hash_to_lds(s_h[log & 1], i, h);
+        }
+        __syncthreads();
+        for (int lg = (int)log - 1; lg >= 0; lg--) {
+            const uint4* src = s_h[(lg + 1) & 1];
+            for (u32 i = t; i < (1u << lg); i += 256) {
+                u32 h[8];
+                merkle_node_hash(h, true, src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3], nullptr, 0, i, rfc);
+                hash_to_hbm(L.tree[lg], i, h);
+                hash_to_lds(s_h[lg & 1], i, h);
+            }
+            __syncthreads();
+        }
+        // Blake2sChannel: mix_root(root), draw alpha (one lane); the root is node 0 of level 0, still in LDS
+        if (t == 0) channel_step(a.chan, reinterpret_cast<const u32*>(s_h[0]), a.alpha + 8 * (a.alpha_idx + k), a.roots + 8 * (a.root_idx + k), s_alpha);
+        __syncthreads();
+        // fold into the next layer
+        const Q31 alpha = q_make(s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]), alpha_sq = q_make(s_alpha[4], s_alpha[5], s_alpha[6], s_alpha[7]);
+        u32 (*nx)[1024] = s_ev[(k + 1) & 1];
+        u32* const* out = k + 1 < a.n_layers ? a.layer[k + 1].ev : a.ev_last;
+        for (u32 i = t; i < (1u << (log - 1)); i += 256) {
+            const u32 xinv = a.itw[a.tw_total - (1u << log) + i];
+            const Q31 fx = q_make(ev[0][2 * i], ev[1][2 * i], ev[2][2 * i], ev[3][2 * i]), fn = q_make(ev[0][2 * i + 1], ev[1][2 * i + 1], ev[2][2 * i + 1], ev[3][2 * i + 1]);
+            Q31 r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+            if (L.quot[0]) {
+                const u32* t1 = a.itw + (a.tw_total - (1u << (log - 1)));
+                const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
+                const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
+                const Q31 fp = q_make(L.quot[0][2 * i], L.quot[1][2 * i], L.quot[2][2 * i], L.quot[3][2 * i]);
+                const Q31 fq = q_make(L.quot[0][2 * i + 1], L.quot[1][2 * i + 1], L.quot[2][2 * i + 1], L.quot[3][2 * i + 1]);
+                const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fq), yinv)), q_add(fp, fq));
+                r = q_add(q_mul(r, alpha_sq), fprime);
+            }
+            nx[0][i] = r.a.a; nx[1][i] = r.a.b; nx[2][i] = r.b.a; nx[3][i] = r.b.b;
+            out[0][i] = r.a.a; out[1][i] = r.a.b; out[2][i] = r.b.a; out[3][i] = r.b.b;
+        }
+        __syncthreads();
+    }
+}
+void fri_tail(hipStream_t stream, const FriTailArgs* d_args) {
+    ProfScope ps(stream, "k_fri_tail", 0);
+    hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(256), 0, stream, d_args);
 }
 
 #ifndef MERKLE_NODES_PER_LANE
@@ -223,9 +343,14 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
     if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
     hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u, node_conv ? 0xFFFFFFFFu : 0u);
 }
-void merkle_top(hipStream_t stream, void* const* d_layers, u32 top_log, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy) {
-    ProfScope ps(stream, "k_merkle_top", 96.0 * (1u << top_log), (double)((1u << top_log) - 1));
-    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, (uint4* const*)d_layers, top_log, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
+void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions) {
+    ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
+    const u32 threads = hi - 10 < 6 ? 64u : 1u << (hi - 10);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(1024), dim3(threads), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
+}
+void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
+    ProfScope ps(stream, "k_merkle_top", bytes, compressions);
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, d_tree, top_hi, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
 }
 
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {

@@ -88,9 +88,11 @@ struct TraceInput {
 // The kept tree is only valid for the configuration it was built under: LOG_MAX_ROWS, the node-hash convention and the shard group
 // (share-wise layers hold one rank's share only) — any change rebuilds it.
 struct PreprocessedCache {
-    bool enabled = false, valid = false; u32 lmr = 0, node_conv = 0, shard_rank = 0, shard_count = 1; DTree tree; Arena keep;
+    bool enabled = false, valid = false; u32 lmr = 0, node_conv = 0, channel = 0, shard_rank = 0, shard_count = 1; DTree tree; Arena keep;
     bool matches(const Ctx& c, u32 log_max_rows) const {
-        return enabled && valid && lmr == log_max_rows && node_conv == c.conv.merkle_node_hash && shard_rank == c.shard.rank && shard_count == c.shard.count;
+        // the hasher is (merkle_channel, merkle_node_hash): a Blake2s tree must never serve a Poseidon252 proof or the reverse
+        return enabled && valid && lmr == log_max_rows && node_conv == c.conv.merkle_node_hash && channel == c.conv.merkle_channel &&
+               shard_rank == c.shard.rank && shard_count == c.shard.count;
     }
 };
 static std::mutex g_cache_mutex;   // contexts may be driven from different host threads (bench.py --inflight)
@@ -127,8 +129,9 @@ struct HipProver {
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     // ---- batched FFT over heterogeneous columns: group by (size, storage) --------------------------------------------------
-    void fft_cols(bool inverse, const std::vector<DCol>& src, const std::vector<DCol>& dst) {
-        c.stage_checkpoint();
+    // Two steps so that a caller can put the plan's staging into a batch shared with what follows (fft_prepare inside a StageBatch,
+    // fft_launch after its end()): pointer arrays and the pass table of every size group reach the device in one copy.
+    FftPlan fft_prepare(bool inverse, const std::vector<DCol>& src, const std::vector<DCol>& dst) {
         std::map<std::pair<u32, u32>, std::vector<size_t>> groups;   // (dst log_size, shift) -> indices
         for (size_t i = 0; i < dst.size(); i++) groups[{dst[i].log_size, dst[i].shift}].push_back(i);
         struct Job { size_t off, n; u32 log, src_log, sh; };
@@ -145,10 +148,22 @@ struct HipProver {
                 for (size_t i : kv.second) ptrs.push_back(dst[i].ptr);
             }
         }
+        FftPlan plan;
+        if (jobs.empty()) return plan;
+        StageBatch sb(c);
         const u32* const* d_ptrs = c.stage(ptrs.data(), ptrs.size());
-        for (auto& j : jobs)
-            fft_batch(c.stream, inverse, d_ptrs + j.off, (u32* const*)(d_ptrs + j.off + j.n), (u32)j.n, j.log - j.sh, j.src_log - j.sh, j.sh == 0, c.d_tw, c.d_itw, c.tw_root_log);
-        BF_HIP(hipGetLastError());
+        std::vector<FftJob> fj;
+        for (auto& j : jobs) fj.push_back({d_ptrs + j.off, (u32* const*)(d_ptrs + j.off + j.n), (u32)j.n, j.log - j.sh, j.src_log - j.sh, j.sh == 0});
+        fft_plan(plan, inverse, fj.data(), fj.size(), c.d_tw, c.d_itw, c.tw_root_log);
+        plan.d_groups = c.stage(plan.groups.data(), plan.groups.size());
+        sb.end();
+        return plan;
+    }
+    void fft_launch(const FftPlan& plan) { fft_run(c.stream, plan); BF_HIP(hipGetLastError()); }
+    // ---- batched FFT over heterogeneous columns: one launch per pass and kernel kind, whatever the number of sizes ---------------
+    void fft_cols(bool inverse, const std::vector<DCol>& src, const std::vector<DCol>& dst) {
+        c.stage_checkpoint();
+        fft_launch(fft_prepare(inverse, src, dst));
     }
 
     // ---- Merkle (a4) -----------------------------------------------------------------------------------------------------------
@@ -161,7 +176,11 @@ struct HipProver {
     // arena storage, column descriptors written to the staging ring — inside the caller's StageBatch), merkle_run = the launches.
     struct MerklePlan {
         DevMerkle mk; std::vector<DCol> cols; std::vector<size_t> off; std::vector<double> bytes; size_t n_all = 0;
-        const ColDesc* d_all = nullptr; void* const* dl = nullptr; u32 fused_top = 0; bool poseidon = false;
+        const ColDesc* d_all = nullptr; const MerkleTreeDesc* d_tree = nullptr; bool poseidon = false;
+        // launches: levels [max_log .. sub_hi + 1] one each (k_merkle_layer), [sub_hi .. 10] one (k_merkle_subtree; sub_hi == 0: none and the
+        // single-level launches go down to fused_top), [fused_top - 1 .. 0] one (k_merkle_top; fused_top == 0: none)
+        u32 fused_top = 0, sub_hi = 0;
+        double top_bytes = 0, top_comp = 0, sub_bytes = 0, sub_comp = 0;
     };
     MerklePlan merkle_plan(const std::vector<DCol>& cols_in) {
         if (cols_in.empty()) throw HipError("merkle_commit: no columns");
@@ -188,12 +207,37 @@ struct HipProver {
         }
         p.n_all = all.size();
         p.poseidon = c.conv.merkle_channel == 1;   // Poseidon252MerkleHasher: layer kernel of poseidon.hip, no fused top, host channel
-        u32 fused_top = std::min<u32>(min_col_log, 10);   // levels below this have no columns and <= 1024 nodes: one fused launch
-        while (fused_top > 0 && mk.shifts[fused_top] != 0) fused_top--;   // the fused kernel expects un-replicated layers
-        if (mk.shifts[fused_top] != 0 || p.poseidon) fused_top = 0;
+        (void)min_col_log;
+        // The top kernel takes levels [fused_top - 1 .. 0] (<= 512 nodes in its first level, columns included), all un-replicated, and reads
+        // the children of its first level from level fused_top (also un-replicated) unless it starts at the leaves.
+        u32 fused_top = std::min<u32>(mk.max_log + 1, 10);
+        while (fused_top > 0 && mk.shifts[std::min(fused_top, mk.max_log)] != 0) fused_top--;
+        if (p.poseidon) fused_top = 0;
         p.fused_top = fused_top;
+        // levels [sub_hi .. 10]: one launch, a workgroup per node of level 10 (one process per proof only: a shard group hashes big layers
+        // share-wise with single-level launches)
+        if (fused_top == 10 && mk.max_log >= 11 && c.shard.count == 1) {
+            u32 hi = std::min<u32>(mk.max_log, 17);
+            while (hi > 10 && mk.shifts[hi] != 0) hi--;
+            if (hi > 10) p.sub_hi = hi;
+        }
+        auto level_cols = [&](int log) { return (log > 0 ? p.off[log - 1] : all.size()) - p.off[log]; };
+        auto level_cost = [&](int log, double& bytes, double& comp) {
+            const double nodes = (double)(1u << log), nc = (double)level_cols(log);
+            const bool has = log < (int)mk.max_log;
+            bytes += nodes * ((has ? 64.0 : 0.0) + 32.0) + p.bytes[log];
+            comp += nodes * ((has ? 1.0 : 0.0) + (double)(((u32)nc + 15) / 16) + ((!has && nc == 0) ? 1.0 : 0.0));
+        };
+        for (int log = (int)fused_top - 1; log >= 0; log--) level_cost(log, p.top_bytes, p.top_comp);
+        if (p.sub_hi) for (int log = (int)p.sub_hi; log >= 10; log--) level_cost(log, p.sub_bytes, p.sub_comp);
         p.d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
-        p.dl = fused_top > 0 ? (void* const*)c.stage(mk.layers.data(), mk.layers.size()) : nullptr;
+        if (fused_top > 0) {
+            MerkleTreeDesc td{};
+            if (mk.max_log >= 32) throw HipError("merkle: tree too deep");
+            for (u32 lg = 0; lg <= mk.max_log; lg++) { td.layers[lg] = (uint4*)mk.layers[lg]; td.shifts[lg] = mk.shifts[lg]; td.col_off[lg] = (u32)p.off[lg]; }
+            td.cols = p.d_all; td.n_cols = (u32)all.size(); td.max_log = mk.max_log;
+            p.d_tree = c.stage(&td, 1);
+        }
         // Shard group: the un-replicated layers with at least 256 nodes per rank are hashed share-wise; the smallest of them is
         // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
         const ShardGroup& sg = c.shard;
@@ -220,7 +264,8 @@ struct HipProver {
         if (poseidon && step) throw HipError("the device-side channel step is a Blake2s path");
         const char* layer_kernel = poseidon ? "k_merkle_layer_poseidon" : "k_merkle_layer";
         prof_run_begin(c.stream, layer_kernel);
-        for (int log = (int)mk.max_log; log >= (int)fused_top; log--) {
+        const int single_lo = p.sub_hi ? (int)p.sub_hi + 1 : (int)fused_top;
+        for (int log = (int)mk.max_log; log >= single_lo; log--) {
             size_t n = (log > 0 ? p.off[log - 1] : p.n_all) - p.off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? ((1u << (log - mk.shifts[log])) >> sg.log_count) : 0u;   // in stored slots
@@ -239,7 +284,8 @@ struct HipProver {
             }
         }
         prof_run_end(c.stream);
-        if (fused_top > 0) merkle_top(c.stream, p.dl, fused_top, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr);
+        if (p.sub_hi) merkle_subtree(c.stream, p.d_tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
+        if (fused_top > 0) merkle_top(c.stream, p.d_tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr, p.top_bytes, p.top_comp);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
@@ -472,15 +518,16 @@ struct HipProver {
                 // shard group: the big IsFirst columns are column-sharded like the interaction tree's (owner interpolates and extends,
                 // every rank receives its row range of the LDE)
                 trees[0].owner = assign_owners(trees[0].polys, cfg.log_blowup);
-                std::vector<DCol> mine_cols;
+                // interpolate(gen_is_first(log)) for every size in closed form, one launch (fft.hip: k_is_first_coeffs)
+                IsFirstCols ifc{}; ifc.log_min = LOG_N_LANES; ifc.log_max = log_max_rows;
+                if (log_max_rows - LOG_N_LANES >= 28) throw HipError("log_max_rows too large");
                 for (size_t i = 0; i < trees[0].polys.size(); i++) {
                     if (trees[0].owner[i] != OWNER_ALL && trees[0].owner[i] != c.shard.rank) continue;
                     DCol& p = trees[0].polys[i];
                     p.ptr = c.alloc_u32(p.stored());
-                    one_hot(c.stream, p.ptr, 1u << p.log_size);
-                    mine_cols.push_back(p);
+                    ifc.ptr[p.log_size - LOG_N_LANES] = p.ptr;
                 }
-                fft_cols(true, mine_cols, mine_cols);
+                is_first_coeffs(c.stream, ifc, c.d_itw, c.tw_root_log);
                 commit_tree(trees[0], pinned_root0);
                 if (cache.enabled) std::swap(c.arena, cache.keep);
                 BF_HIP(hipEventRecord(c.ev[1], c.stream));
@@ -521,7 +568,7 @@ struct HipProver {
         if (!reuse) {
             trees[0].mk.root = *pinned_root0;
             if (cache.enabled) {
-                cache.tree = trees[0]; cache.lmr = log_max_rows; cache.node_conv = c.conv.merkle_node_hash;
+                cache.tree = trees[0]; cache.lmr = log_max_rows; cache.node_conv = c.conv.merkle_node_hash; cache.channel = c.conv.merkle_channel;
                 cache.shard_rank = c.shard.rank; cache.shard_count = c.shard.count; cache.valid = true;
             }
         }
@@ -548,6 +595,7 @@ struct HipProver {
         { Q31 z, a; ch.draw_two_felts(z, a); el.processor = make_lookup(z, a); }      // ProcessorElements::draw
         uint4* d_claimed = (uint4*)c.arena.alloc(sizeof(uint4) * N_COMPONENTS);
         std::vector<DCol> inter_vals;
+        std::vector<LogupLaunch> logups(N_COMPONENTS);
         for (int k = 0; k < N_COMPONENTS; k++) {
             u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
             size_t M = size_t(1) << log_rows;
@@ -568,7 +616,13 @@ struct HipProver {
             L.totals = c.arena.alloc(sizeof(uint4) * (M / 1024 + 2));
             L.claimed = d_claimed + k;
             L.el = el; L.log_rows = log_rows; L.comp = k;
-            logup_generate(c.stream, L);
+            logups[k] = L;
+        }
+        {   // the 13 interaction_trace_evaluation calls (mod.rs:596-687) as one batch: four launches
+            LogupBatch lb;
+            logup_batch_init(lb, el, logups.data(), N_COMPONENTS);
+            c.stage_checkpoint();
+            logup_batch_run(c.stream, c.stage(&lb, 1), lb);
         }
         BF_HIP(hipGetLastError());
         {
@@ -702,8 +756,15 @@ struct HipProver {
             launches[k] = L;
         }
         c.stage_checkpoint();
-        const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());   // one copy for the 13 parameter blocks
-        for (int k = 0; k < N_COMPONENTS; k++) eval_constraints(c.stream, k, d_launches + k, bp.log_sizes[k], launches[k].n_rows, constraint_group_rows(launches[k], k));
+        {   // the 13 evaluate_constraint_quotients_on_domain calls as ONE launch (air.hip: k_constraints_batch), one staging copy
+            ConstraintBatch cb;
+            constraint_batch_init(cb, launches.data(), N_COMPONENTS);
+            StageBatch sb(c);
+            const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());
+            const ConstraintBatch* d_cb = c.stage(&cb, 1);
+            sb.end();
+            eval_constraints_batch(c.stream, d_cb, cb, d_launches);
+        }
         BF_HIP(hipGetLastError());
         // finalize (DomainEvaluationAccumulator::finalize): ascending sizes; the reference evaluates the running polynomial on the next
         // populated size, adds the evaluations and interpolates the sum. Interpolation is linear and evaluating a polynomial on a larger

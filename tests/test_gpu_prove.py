@@ -276,6 +276,14 @@ def test_reuse_preprocessed_survives_a_convention_change(pkg, oracle):
         assert pkg.verify_brainfuck(b, 20, conventions=other) == (True, "")
         c.set_conventions(*cur)
         assert pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20) == a == oracle.prove(code, inp, log_max_rows=20)[0]
+        # the MerkleChannel is part of the key too — a Blake2s tree must not serve a Poseidon252 proof, nor the reverse
+        pos = (cur[0], cur[1], cur[2], 1 - cur[3])
+        c.set_conventions(*pos)
+        p1 = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20)
+        assert pkg.verify_brainfuck(p1, 20, conventions=pos) == (True, "")
+        assert pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20) == p1      # second proof under the same hasher: cache hit, same bytes
+        c.set_conventions(*cur)
+        assert pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=20) == a
         pkg.lib().bfhip_ctx_reuse_preprocessed(c._h, 0)
     finally:
         c.close()

@@ -13,8 +13,8 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bf::", "")))
     rows.sort()
-    # a proof starts with the k_one_hot burst of the preprocessed phase: take the last such burst as the start of the last proof
-    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_one_hot") and (i == 0 or not rows[i - 1][2].startswith("k_one_hot"))]
+    # a proof starts with the k_is_first_coeffs burst of the preprocessed phase: take the last such burst as the start of the last proof
+    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_is_first_coeffs") and (i == 0 or not rows[i - 1][2].startswith("k_is_first_coeffs"))]
     first = starts[-1] if starts else 0
     rows = rows[first:]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
