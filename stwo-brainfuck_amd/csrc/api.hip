@@ -505,7 +505,8 @@ int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint
     a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
     a.n_batches = (u32)batches.size(); a.log = log_size; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;
     for (int w = 0; w < 4; w++) a.out[w] = out_d[w];
-    accumulate_quotients(c.stream, a);
+    const u32 blocks = quotient_groups_layout(&a, 1);
+    accumulate_quotients(c.stream, c.stage(&a, 1), 1, blocks);
     BF_HIP(hipGetLastError());
     return 0;
     API_CATCH

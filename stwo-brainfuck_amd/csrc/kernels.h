@@ -122,7 +122,7 @@ struct FriTailArgs {
     const u32* itw; u32 tw_total, rfc;
     FriTailLayer layer[10];
 };
-void fri_tail(hipStream_t stream, const FriTailArgs* d_args);
+void fri_tail(hipStream_t stream, const FriTailArgs* d_args, double bytes, double compressions);   // bytes / compressions: profiler accounting (tree nodes only)
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.
@@ -177,8 +177,12 @@ void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 t
 struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; C31 kden; u32 pad_; };   // kden = prx * piy - pry * pix
 struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
 // row0 / n_rows: range of rows to compute (n_rows == 0: all 2^log rows; both multiples of 4); out pointers may be virtual bases
-struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; u32 row0, n_rows; };
-void accumulate_quotients(hipStream_t stream, const QuotientArgs& a);
+// block0: first workgroup of this size group within the one launch that covers all of them (set by quotient_groups_layout)
+struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; u32 row0, n_rows; u32 block0, pad_; };
+// every size group of a proof in one launch: fill h_groups, call quotient_groups_layout (sets block0, returns the grid size), copy the table
+// to device memory the stream can read, launch
+u32 quotient_groups_layout(QuotientArgs* h_groups, u32 n_groups);
+void accumulate_quotients(hipStream_t stream, const QuotientArgs* d_groups, u32 n_groups, u32 total_blocks);
 // d_alpha8: device pointer to alpha[4] || alpha^2[4]
 // fresh: dst holds nothing yet (treated as zero, not read)
 // first / count: range of DESTINATION cells to compute (count == 0: all 2^(log-1)); pointers may be virtual bases
@@ -195,6 +199,8 @@ void prev_row_copy(hipStream_t stream, u32* dst, const u32* src, u32 log_size);
 struct GatherReq { const u32* base; u64 index; u32 out_off; u32 n_words; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);
+struct AccumulateSizes { u32* dst[4]; const u32* src[8][4]; u32 log[8]; u32 n; };   // sources sorted by descending size, all <= 2^log of dst
+void accumulate_sizes(hipStream_t stream, const AccumulateSizes& a);
 void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n);
 void batch_inverse_qm31(hipStream_t stream, const u32* const src[4], u32* const dst[4], u32 n);
 void bit_reverse(hipStream_t stream, const u32* src, u32* dst, u32 log);

@@ -190,116 +190,298 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
 //   k_merkle_top:     levels [min(max_log, 9) .. 0] by a single workgroup (children of its first level from HBM), columns included, then
 //                     (FRI commit phase) the channel step on the root.
 // Every level is also written to HBM: the decommitment reads hashes from there. Un-replicated levels only (node i stored at i).
+//
+// These kernels are latency chains: one compression per tree level, ~1.7 us each when one lane runs the 977 dependent instructions. Narrow
+// levels (and the channel's two hashes) are therefore hashed by a QUAD of lanes per compression: lane i of the quad owns column i of the
+// 4 x 4 Blake2s state (a, b, c, d = v[i], v[4+i], v[8+i], v[12+i]), the diagonal step rotates b, c, d across the quad with DPP quad_perm
+// (no LDS, no extra instruction when the compiler folds the DPP modifier into the consumer), every lane holds the whole message and picks
+// its two words per half-round by lane parity (3 v_cndmask each). ~490 instructions instead of 977 on the dependent chain.
+// Each kernel keeps ONE single-lane and ONE quad compression site (a compression is ~8 KiB / ~4 KiB of code; the instruction cache is cold
+// at every launch of a short kernel).
 __device__ __forceinline__ void hash_to_lds(uint4* __restrict__ s, u32 j, const u32 (&h)[8]) { s[2 * j] = make_uint4(h[0], h[1], h[2], h[3]); s[2 * j + 1] = make_uint4(h[4], h[5], h[6], h[7]); }
 __device__ __forceinline__ void hash_to_hbm(uint4* __restrict__ out, u32 i, const u32 (&h)[8]) { out[2 * (size_t)i] = make_uint4(h[0], h[1], h[2], h[3]); out[2 * (size_t)i + 1] = make_uint4(h[4], h[5], h[6], h[7]); }
+#define BF_QDPP(x, ctrl) ((u32)__builtin_amdgcn_mov_dpp((int)(x), (ctrl), 0xf, 0xf, true))
+#define BF_QG(mx, my) \
+    a = a + b + (mx); d = rotr(d ^ a, 16); c = c + d; b = rotr(b ^ c, 12); \
+    a = a + b + (my); d = rotr(d ^ a, 8);  c = c + d; b = rotr(b ^ c, 7);
+#define BF_QROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) { \
+    u32 mx = qsel(m[s0], m[s2], m[s4], m[s6]), my = qsel(m[s1], m[s3], m[s5], m[s7]); \
+    BF_QG(mx, my) \
+    b = BF_QDPP(b, 0x39); c = BF_QDPP(c, 0x4E); d = BF_QDPP(d, 0x93);      /* lane i takes b of lane i+1, c of i+2, d of i+3: the diagonals */ \
+    mx = qsel(m[s8], m[s10], m[s12], m[s14]); my = qsel(m[s9], m[s11], m[s13], m[s15]); \
+    BF_QG(mx, my) \
+    b = BF_QDPP(b, 0x93); c = BF_QDPP(c, 0x4E); d = BF_QDPP(d, 0x39); }
+// ha = h[qi], hb = h[4 + qi] on entry and on return (qi = lane & 3); m, t0, f0 identical in the 4 lanes; all 4 lanes of the quad active.
+__device__ __forceinline__ void blake2s_compress_quad(u32& ha, u32& hb, const u32 (&m)[16], u32 t0, u32 f0, u32 qi) {
+    const bool odd = qi & 1, up = qi & 2;
+    auto qsel = [&](u32 x0, u32 x1, u32 x2, u32 x3) -> u32 { const u32 lo = odd ? x1 : x0, hi = odd ? x3 : x2; return up ? hi : lo; };
+    u32 a = ha, b = hb;
+    u32 c = qsel(0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au);
+    u32 d = qsel(0x510E527Fu ^ t0, 0x9B05688Cu, 0x1F83D9ABu ^ f0, 0x5BE0CD19u);
+    BF_QROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+    BF_QROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+    BF_QROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+    BF_QROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+    BF_QROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+    BF_QROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+    BF_QROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+    BF_QROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+    BF_QROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+    BF_QROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+    ha ^= a ^ c; hb ^= b ^ d;
+}
+// initial chaining words of lane qi: (IV ^ parameter block)[qi], [4 + qi]
+__device__ __forceinline__ void quad_iv(u32 qi, u32& lo, u32& hi) {
+    const bool odd = qi & 1, up = qi & 2;
+    const u32 l0 = odd ? 0xBB67AE85u : (0x6A09E667u ^ 0x01010020u), l1 = odd ? 0xA54FF53Au : 0x3C6EF372u;
+    const u32 h0 = odd ? 0x9B05688Cu : 0x510E527Fu, h1 = odd ? 0x5BE0CD19u : 0x1F83D9ABu;
+    lo = up ? l1 : l0; hi = up ? h1 : h0;
+}
+__device__ __forceinline__ void kids_to_m(u32 (&m)[16], uint4 a, uint4 b, uint4 c, uint4 d) {
+    m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = b.x; m[5] = b.y; m[6] = b.z; m[7] = b.w;
+    m[8] = c.x; m[9] = c.y; m[10] = c.z; m[11] = c.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+}
+// Node hash by one lane with ONE compression site: message blocks = [the two child hashes]? then the column words 16 at a time.
+// leaf4 != nullptr: the node's four column values are given (FRI layer leaves from LDS) instead of column descriptors.
+__device__ __forceinline__ void node_hash_lean(u32 (&h)[8], bool has, uint4 ka, uint4 kb, uint4 kc, uint4 kd, const ColDesc* __restrict__ cols, u32 ncols, u32 i, u32 rfc,
+                                               const u32* leaf4 = nullptr) {
+    node_init(h, rfc);
+    const u32 nblk = (has ? 1u : 0u) + (ncols + 15) / 16 + ((!has && ncols == 0) ? 1u : 0u);
+    u32 done = 0;
+#pragma unroll 1
+    for (u32 blk = 0; blk < nblk; blk++) {
+        u32 m[16];
+        if (blk == 0 && has) { kids_to_m(m, ka, kb, kc, kd); done = 64; }
+        else if (leaf4) {
+#pragma unroll
+            for (int w = 0; w < 16; w++) m[w] = w < 4 ? leaf4[w] : 0u;
+            done += 16;
+        } else {
+            const u32 c0 = 16 * (blk - (has ? 1u : 0u));
+#pragma unroll
+            for (u32 w = 0; w < 16; w++) {
+                const u32 cc = c0 + w;
+                u32 v = 0;
+                if (cc < ncols) v = ld_col(cols[cc], i);
+                m[w] = v;
+            }
+            done += min(64u, 4u * (ncols - min(ncols, c0)));
+        }
+        const bool last = blk + 1 == nblk;
+        blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
+    }
+}
 
 __global__ void __launch_bounds__(128) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
     __shared__ uint4 s_lv[2][2 * 128];
     const MerkleTreeDesc& td = *tdp;
-    const u32 lo = 10, b = blockIdx.x, j = threadIdx.x;
+    const u32 lo = 10, b = blockIdx.x, t = threadIdx.x, qi = t & 3, qn = t >> 2;
     for (u32 lg = hi; lg >= lo; lg--) {
         const u32 n = 1u << (lg - lo);
+        const ColDesc* cols = td.cols + td.col_off[lg];
+        const u32 ncols = td.col_off[lg - 1] - td.col_off[lg];      // col_off is indexed by level; levels are laid out descending
+        const bool first = lg == hi, has = !first || hi < td.max_log;
+        const uint4* prev = first && has ? td.layers[hi + 1] : nullptr;
+        const u32 ps = first && has ? td.shifts[hi + 1] : 0u;
+        const uint4* src = s_lv[(lg + 1) & 1];
+        const bool quad = ncols == 0 && has && 4 * n <= blockDim.x;
+        const u32 j = quad ? qn : t;
         if (j < n) {
             const u32 i = (b << (lg - lo)) + j;
-            const ColDesc* cols = td.cols + td.col_off[lg];
-            const u32 ncols = td.col_off[lg - 1] - td.col_off[lg];      // col_off is indexed by level, descending levels are laid out ascending
-            u32 h[8];
-            uint4 a = make_uint4(0, 0, 0, 0), bb = a, c = a, d = a;
-            bool has = true;
-            if (lg == hi) {
-                has = hi < td.max_log;
-                if (has) {
-                    const uint4* prev = td.layers[hi + 1];
-                    const u32 ps = td.shifts[hi + 1];
-                    const size_t cl = ((size_t)2 * i) >> ps, cr = ((size_t)2 * i + 1) >> ps;
-                    a = prev[2 * cl]; bb = prev[2 * cl + 1]; c = prev[2 * cr]; d = prev[2 * cr + 1];
-                }
-            } else {
-                const uint4* src = s_lv[(lg + 1) & 1];
-                a = src[4 * j]; bb = src[4 * j + 1]; c = src[4 * j + 2]; d = src[4 * j + 3];
+            uint4 ka = make_uint4(0, 0, 0, 0), kb = ka, kc = ka, kd = ka;
+            if (has) {
+                if (first) { const size_t cl = ((size_t)2 * i) >> ps, cr = ((size_t)2 * i + 1) >> ps; ka = prev[2 * cl]; kb = prev[2 * cl + 1]; kc = prev[2 * cr]; kd = prev[2 * cr + 1]; }
+                else { ka = src[4 * j]; kb = src[4 * j + 1]; kc = src[4 * j + 2]; kd = src[4 * j + 3]; }
             }
-            merkle_node_hash(h, has, a, bb, c, d, cols, ncols, i, rfc);
-            hash_to_hbm(td.layers[lg], i, h);
-            hash_to_lds(s_lv[lg & 1], j, h);
+            if (quad) {
+                u32 m[16], ha, hb;
+                kids_to_m(m, ka, kb, kc, kd);
+                quad_iv(qi, ha, hb); ha &= rfc; hb &= rfc;
+                blake2s_compress_quad(ha, hb, m, 64u & rfc, rfc, qi);
+                u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * (size_t)i; o[qi] = ha; o[4 + qi] = hb;
+                u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * j; l[qi] = ha; l[4 + qi] = hb;
+            } else {
+                u32 h[8];
+                node_hash_lean(h, has, ka, kb, kc, kd, cols, ncols, i, rfc);
+                hash_to_hbm(td.layers[lg], i, h);
+                hash_to_lds(s_lv[lg & 1], j, h);
+            }
         }
         __syncthreads();
     }
 }
 
+// chan != nullptr: Blake2sChannel::mix_root(root) and draw_felt() follow the root as two more quad steps (levels -1 and -2 of the loop).
 __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __restrict__ tdp, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
     // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
     // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
     __shared__ uint4 s_lv[2][2 * 512];
+    __shared__ u32 s_ch[16];              // [0, 8): channel digest; [8, 16): the draw's output
     const MerkleTreeDesc& td = *tdp;
-    for (int lg = (int)top_hi; lg >= 0; lg--) {
-        const ColDesc* cols = td.cols + td.col_off[lg];
-        const u32 ncols = (lg > 0 ? td.col_off[lg - 1] : td.n_cols) - td.col_off[lg];
-        const bool first = lg == (int)top_hi;
-        const bool has = !first || top_hi < td.max_log;
-        const uint4* prev = first && has ? td.layers[lg + 1] : nullptr;
+    const u32 t = threadIdx.x, qi = t & 3, qn = t >> 2;
+    if (chan && t < 8) s_ch[t] = chan[t];
+    u32 n_sent = 0;
+    for (int lg = (int)top_hi;;) {
+        const bool tree = lg >= 0;
+        const ColDesc* cols = tree ? td.cols + td.col_off[lg] : nullptr;
+        const u32 ncols = tree ? (lg > 0 ? td.col_off[lg - 1] : td.n_cols) - td.col_off[lg] : 0u;
+        const bool first = lg == (int)top_hi, has = !first || top_hi < td.max_log;
+        const uint4* prev = tree && first && has ? td.layers[lg + 1] : nullptr;
         const uint4* src = s_lv[(lg + 1) & 1];
-        uint4* dst = s_lv[lg & 1];
-        uint4* out = td.layers[lg];
-        for (u32 i = threadIdx.x; i < (1u << lg); i += blockDim.x) {
-            u32 h[8];
-            uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
-            if (has) {
-                if (first) { a = prev[4 * i]; b = prev[4 * i + 1]; c = prev[4 * i + 2]; d = prev[4 * i + 3]; }
-                else { a = src[4 * i]; b = src[4 * i + 1]; c = src[4 * i + 2]; d = src[4 * i + 3]; }
+        const u32 n = tree ? 1u << lg : 1u;
+        const bool quad = !tree || (ncols == 0 && has && n <= 64);
+        if (!quad) {
+            for (u32 i = t; i < n; i += blockDim.x) {
+                u32 h[8];
+                uint4 ka = make_uint4(0, 0, 0, 0), kb = ka, kc = ka, kd = ka;
+                if (has) {
+                    if (first) { ka = prev[4 * i]; kb = prev[4 * i + 1]; kc = prev[4 * i + 2]; kd = prev[4 * i + 3]; }
+                    else { ka = src[4 * i]; kb = src[4 * i + 1]; kc = src[4 * i + 2]; kd = src[4 * i + 3]; }
+                }
+                node_hash_lean(h, has, ka, kb, kc, kd, cols, ncols, i, rfc);
+                hash_to_hbm(td.layers[lg], i, h);
+                hash_to_lds(s_lv[lg & 1], i, h);
             }
-            merkle_node_hash(h, has, a, b, c, d, cols, ncols, i, rfc);
-            hash_to_hbm(out, i, h);
-            hash_to_lds(dst, i, h);
+        } else if (qn < n) {
+            u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;
+            quad_iv(qi, ha, hb);
+            if (tree) {
+                if (first) kids_to_m(m, prev[4 * qn], prev[4 * qn + 1], prev[4 * qn + 2], prev[4 * qn + 3]);
+                else kids_to_m(m, src[4 * qn], src[4 * qn + 1], src[4 * qn + 2], src[4 * qn + 3]);
+                ha &= rfc; hb &= rfc; t0 &= rfc; f0 = rfc;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) m[k] = s_ch[k];
+                if (lg == -1) {         // mix_root: Blake2s(digest || root)
+                    const u32* root = reinterpret_cast<const u32*>(s_lv[0]);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) m[8 + k] = root[k];
+                    root_out[qi] = m[8 + qi]; root_out[4 + qi] = m[12 + qi];     // contiguous copy of the roots for one read-back
+                } else {                // draw: Blake2s(digest || n_sent as LE u32 || zero padding to 64 bytes)
+#pragma unroll
+                    for (int k = 9; k < 16; k++) m[k] = 0;
+                    m[8] = n_sent;
+                }
+            }
+            blake2s_compress_quad(ha, hb, m, t0, f0, qi);
+            if (tree) {
+                u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
+                u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
+            } else if (lg == -1) { s_ch[qi] = ha; s_ch[4 + qi] = hb; }
+            else { s_ch[8 + qi] = ha; s_ch[12 + qi] = hb; }
         }
         __syncthreads();
+        if (lg == -2) {
+            bool ok = true;      // redrawn until all 8 words are < 2P
+#pragma unroll
+            for (int k = 0; k < 8; k++) ok = ok && s_ch[8 + k] < 2u * P31;
+            n_sent++;
+            if (ok) break;
+            __syncthreads();     // every lane has read the rejected draw before it is overwritten
+        } else {
+            lg--;
+            if (lg < 0 && !chan) return;
+        }
     }
-    if (chan && threadIdx.x == 0) {
-        __threadfence_block();
-        channel_step(chan, reinterpret_cast<const u32*>(td.layers[0]), alpha_out, root_out);
+    if (t == 0) {
+        u32 w[4];
+        for (int k = 0; k < 4; k++) w[k] = s_ch[8 + k] >= P31 ? s_ch[8 + k] - P31 : s_ch[8 + k];
+        const Q31 alpha = q_make(w[0], w[1], w[2], w[3]), sq = q_mul(alpha, alpha);
+        alpha_out[0] = alpha.a.a; alpha_out[1] = alpha.a.b; alpha_out[2] = alpha.b.a; alpha_out[3] = alpha.b.b;
+        alpha_out[4] = sq.a.a; alpha_out[5] = sq.a.b; alpha_out[6] = sq.b.a; alpha_out[7] = sq.b.b;
+        for (int k = 0; k < 8; k++) chan[k] = s_ch[k];
+        chan[8] = n_sent;
     }
 }
 
 // ---- FRI commit phase below 2^10 rows: one launch ------------------------------------------------------------------------------------
+// Steps of one layer of 2^log rows: leaves (kind 0, level log), inner levels log-1 .. 0 (kind 1), mix_root (kind 2), draw (kind 3), fold.
 __global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict__ ap) {
     __shared__ u32 s_ev[2][4][1024];
     __shared__ uint4 s_h[2][2 * 1024];
-    __shared__ u32 s_alpha[8];
+    __shared__ u32 s_ch[16];
     const FriTailArgs& a = *ap;
-    const u32 t = threadIdx.x, rfc = a.rfc;
+    const u32 t = threadIdx.x, rfc = a.rfc, qi = t & 3, qn = t >> 2;
     for (u32 i = t; i < (1u << a.top_log); i += 256)
         for (int w = 0; w < 4; w++) s_ev[0][w][i] = a.layer[0].ev[w][i];
+    if (t < 8) s_ch[t] = a.chan[t];
     __syncthreads();
     for (u32 k = 0; k < a.n_layers; k++) {
         const u32 log = a.top_log - k;
         const FriTailLayer& L = a.layer[k];
         u32 (*ev)[1024] = s_ev[k & 1];
-        // leaves: node i = hash of the 4 coordinate values of row i (16 bytes, one compression)
-        for (u32 i = t; i < (1u << log); i += 256) {
-            u32 h[8], m[16];
-            node_init(h, rfc);
-#pragma unroll
-            for (int w = 4; w < 16; w++) m[w] = 0;
-            m[0] = ev[0][i]; m[1] = ev[1][i]; m[2] = ev[2][i]; m[3] = ev[3][i];
-            blake2s_compress(h, m, 16u & rfc, rfc);
-            hash_to_hbm(L.tree[log], i, h);
-            hash_to_lds(s_h[log & 1], i, h);
-        }
-        __syncthreads();
-        for (int lg = (int)log - 1; lg >= 0; lg--) {
+        u32 n_sent = 0;
+        for (int lg = (int)log, kind = 0;;) {
+            const u32 n = kind <= 1 ? 1u << lg : 1u;
             const uint4* src = s_h[(lg + 1) & 1];
-            for (u32 i = t; i < (1u << lg); i += 256) {
-                u32 h[8];
-                merkle_node_hash(h, true, src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3], nullptr, 0, i, rfc);
-                hash_to_hbm(L.tree[lg], i, h);
-                hash_to_lds(s_h[lg & 1], i, h);
+            if (n > 64) {
+                for (u32 i = t; i < n; i += 256) {
+                    u32 h[8];
+                    u32 leaf[4] = {0, 0, 0, 0};
+                    uint4 ka = make_uint4(0, 0, 0, 0), kb = ka, kc = ka, kd = ka;
+                    if (kind == 0) { leaf[0] = ev[0][i]; leaf[1] = ev[1][i]; leaf[2] = ev[2][i]; leaf[3] = ev[3][i]; }
+                    else { ka = src[4 * i]; kb = src[4 * i + 1]; kc = src[4 * i + 2]; kd = src[4 * i + 3]; }
+                    node_hash_lean(h, kind == 1, ka, kb, kc, kd, nullptr, kind == 0 ? 4u : 0u, i, rfc, leaf);
+                    hash_to_hbm(L.tree[lg], i, h);
+                    hash_to_lds(s_h[lg & 1], i, h);
+                }
+            } else if (qn < n) {
+                u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;
+                quad_iv(qi, ha, hb);
+                if (kind == 0) {
+#pragma unroll
+                    for (int w = 4; w < 16; w++) m[w] = 0;
+                    m[0] = ev[0][qn]; m[1] = ev[1][qn]; m[2] = ev[2][qn]; m[3] = ev[3][qn];
+                    ha &= rfc; hb &= rfc; t0 = 16u & rfc; f0 = rfc;
+                } else if (kind == 1) {
+                    kids_to_m(m, src[4 * qn], src[4 * qn + 1], src[4 * qn + 2], src[4 * qn + 3]);
+                    ha &= rfc; hb &= rfc; t0 &= rfc; f0 = rfc;
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 8; w++) m[w] = s_ch[w];
+                    if (kind == 2) {
+                        const u32* root = reinterpret_cast<const u32*>(s_h[0]);
+#pragma unroll
+                        for (int w = 0; w < 8; w++) m[8 + w] = root[w];
+                        u32* ro = a.roots + 8 * (a.root_idx + k);
+                        ro[qi] = m[8 + qi]; ro[4 + qi] = m[12 + qi];
+                    } else {
+#pragma unroll
+                        for (int w = 9; w < 16; w++) m[w] = 0;
+                        m[8] = n_sent;
+                    }
+                }
+                blake2s_compress_quad(ha, hb, m, t0, f0, qi);
+                if (kind <= 1) {
+                    u32* o = reinterpret_cast<u32*>(L.tree[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
+                    u32* l = reinterpret_cast<u32*>(s_h[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
+                } else if (kind == 2) { s_ch[qi] = ha; s_ch[4 + qi] = hb; }
+                else { s_ch[8 + qi] = ha; s_ch[12 + qi] = hb; }
             }
             __syncthreads();
+            if (kind == 3) {
+                bool ok = true;
+#pragma unroll
+                for (int w = 0; w < 8; w++) ok = ok && s_ch[8 + w] < 2u * P31;
+                n_sent++;
+                if (ok) break;
+                __syncthreads();
+            } else if (kind == 2) kind = 3;
+            else if (lg == 0) kind = 2;
+            else { lg--; kind = 1; }
         }
-        // Blake2sChannel: mix_root(root), draw alpha (one lane); the root is node 0 of level 0, still in LDS
-        if (t == 0) channel_step(a.chan, reinterpret_cast<const u32*>(s_h[0]), a.alpha + 8 * (a.alpha_idx + k), a.roots + 8 * (a.root_idx + k), s_alpha);
-        __syncthreads();
+        // alpha, alpha^2 (every lane computes them; lane 0 publishes them and the channel state)
+        u32 w4[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) w4[w] = s_ch[8 + w] >= P31 ? s_ch[8 + w] - P31 : s_ch[8 + w];
+        const Q31 alpha = q_make(w4[0], w4[1], w4[2], w4[3]), alpha_sq = q_mul(alpha, alpha);
+        if (t == 0) {
+            u32* ao = a.alpha + 8 * (a.alpha_idx + k);
+            ao[0] = alpha.a.a; ao[1] = alpha.a.b; ao[2] = alpha.b.a; ao[3] = alpha.b.b;
+            ao[4] = alpha_sq.a.a; ao[5] = alpha_sq.a.b; ao[6] = alpha_sq.b.a; ao[7] = alpha_sq.b.b;
+            if (k + 1 == a.n_layers) { for (int w = 0; w < 8; w++) a.chan[w] = s_ch[w]; a.chan[8] = n_sent; }
+        }
         // fold into the next layer
-        const Q31 alpha = q_make(s_alpha[0], s_alpha[1], s_alpha[2], s_alpha[3]), alpha_sq = q_make(s_alpha[4], s_alpha[5], s_alpha[6], s_alpha[7]);
         u32 (*nx)[1024] = s_ev[(k + 1) & 1];
         u32* const* out = k + 1 < a.n_layers ? a.layer[k + 1].ev : a.ev_last;
         for (u32 i = t; i < (1u << (log - 1)); i += 256) {
@@ -321,8 +503,8 @@ __global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict_
         __syncthreads();
     }
 }
-void fri_tail(hipStream_t stream, const FriTailArgs* d_args) {
-    ProfScope ps(stream, "k_fri_tail", 0);
+void fri_tail(hipStream_t stream, const FriTailArgs* d_args, double bytes, double compressions) {
+    ProfScope ps(stream, "k_fri_tail", bytes, compressions);
     hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(256), 0, stream, d_args);
 }
 
@@ -345,8 +527,7 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
 }
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
-    const u32 threads = hi - 10 < 6 ? 64u : 1u << (hi - 10);
-    hipLaunchKernelGGL(k_merkle_subtree, dim3(1024), dim3(threads), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(1024), dim3(128), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
 }
 void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_top", bytes, compressions);

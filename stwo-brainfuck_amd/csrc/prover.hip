@@ -773,6 +773,28 @@ struct HipProver {
         // transform, no full-size accumulate. Exact field arithmetic: the coefficients are the same.
         // Shard group: the 4 coordinate columns of a row-sharded accumulator are gathered whole on their owners (coordinate w on rank
         // w mod count: rows -> columns, one grouped send-receive per size), which interpolate and merge them; ranks without a coordinate idle.
+        if (!sharded()) {
+            // one process: every size's accumulator is interpolated by the SAME batch of launches (the transforms are independent), then one
+            // launch adds the smaller sizes' coefficients onto the largest size's
+            std::vector<DCol> all_vals;
+            std::vector<u32> logs;
+            for (u32 log = max_log; log >= 1; log--) {
+                if (!have[log]) continue;
+                logs.push_back(log);
+                for (int w = 0; w < 4; w++) { DCol v; v.ptr = acc[log].c[w]; v.log_size = log; v.shift = 0; all_vals.push_back(v); }
+            }
+            if (logs.size() > 9) throw HipError("composition: too many distinct sizes");
+            fft_cols(true, all_vals, all_vals);
+            AccumulateSizes as{};
+            for (int w = 0; w < 4; w++) as.dst[w] = acc[logs[0]].c[w];
+            for (size_t k = 1; k < logs.size(); k++) { for (int w = 0; w < 4; w++) as.src[k - 1][w] = acc[logs[k]].c[w]; as.log[k - 1] = logs[k]; }
+            as.n = (u32)logs.size() - 1;
+            accumulate_sizes(c.stream, as);
+            BF_HIP(hipGetLastError());
+            trees[3].polys.assign(all_vals.begin(), all_vals.begin() + 4);
+            trees[3].owner.assign(4, OWNER_ALL);
+            return;
+        }
         bool cur_have = false; std::vector<DCol> cur(4);
         bool cur_owned = false;               // `cur` is complete only on the coordinate's owner
         auto owner_of = [&](int w) { return (u32)w % c.shard.count; };
@@ -899,8 +921,10 @@ struct HipProver {
             out.push_back(q);
             i = j;
         }
+        const u32 q_blocks = quotient_groups_layout(launches.data(), (u32)launches.size());
+        const QuotientArgs* d_groups = launches.empty() ? nullptr : c.stage(launches.data(), launches.size());
         sb.end();                                   // one copy for the parameter blocks of every size group
-        for (auto& a : launches) accumulate_quotients(c.stream, a);
+        accumulate_quotients(c.stream, d_groups, (u32)launches.size(), q_blocks);     // and one launch
         BF_HIP(hipGetLastError());
         return out;
     }
@@ -961,7 +985,6 @@ struct HipProver {
         u32* d_roots = c.alloc_u32(8 * (max_layers + 1));                                        // root copies, read back once
         memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
         BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
-        u32 cur_alpha = 0;
         // Poseidon252Channel is stepped on the host (one root read-back per layer): two serial Hades permutations by a single lane would
         // cost more than the round trip. commit_step = Merkle tree of a layer + mix_root + draw alpha (alpha || alpha^2 -> d_alpha[idx]).
         const bool host_channel = c.conv.merkle_channel == 1;
@@ -1008,35 +1031,63 @@ struct HipProver {
         auto fold_range = [&](u32 src_log, bool src_sliced, u32& first, u32& count) {
             if (src_sliced) { first = (u32)(slice_first(src_log) >> 1); count = (u32)(slice_cells(src_log) >> 1); } else { first = 0; count = 0; }
         };
-        DSecure layer = layers[0];
-        bool layer_fresh = true;                     // nothing folded into `layer` yet: the first circle fold writes it (no zero fill)
-        bool layer_partial = false;                  // a complete (unsharded) buffer of which every rank has filled only its range so far
+        // a complete (unsharded) buffer of which every rank has filled only its range is finished by one all-gather per coordinate
+        auto complete = [&](const DSecure& l) { for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, l.c[w], sizeof(u32) << (l.log_size - lc())); };
+        // circle -> line: the largest quotient opens layer 0 (nothing folded into it yet: no zero fill)
         size_t qi = 0;
-        while (line_log > last_log) {
-            while (qi < quotients.size() && quotients[qi].log_size - 1 == line_log) {
-                const u32* src[4] = {quotients[qi].c[0], quotients[qi].c[1], quotients[qi].c[2], quotients[qi].c[3]};
-                u32 first, count; fold_range(quotients[qi].log_size, quotients[qi].lc != 0, first, count);
-                if (quotients[qi].lc != 0 && layer.lc == 0) layer_partial = true;
-                fold_circle_into_line(c.stream, layer.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, quotients[qi].log_size, layer_fresh, first, count);
-                layer_fresh = false;
-                qi++;
-            }
-            if (layer_partial) {
-                for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, layer.c[w], sizeof(u32) << (line_log - lc()));
-                layer_partial = false;
-            }
-            Inner in; in.ev = layer;
-            cur_alpha++;
-            in.tree = commit_step(1 + inner.size(), secure_cols(layer), cur_alpha, (u32)(1 + inner.size()));
-            DSecure next = layers[inner.size() + 1];
-            const u32* src[4] = {layer.c[0], layer.c[1], layer.c[2], layer.c[3]};
-            u32 first, count; fold_range(line_log, layer.lc != 0, first, count);
-            if (layer.lc != 0 && next.lc == 0) layer_partial = true;
-            fold_line(c.stream, next.c, src, d_alpha + 8 * cur_alpha, c.d_itw, c.tw_root_log, line_log, first, count);
-            inner.push_back(in);
-            layer = next; line_log--;
+        if (quotients[0].log_size - 1 != line_log) throw HipError("FRI: first layer size");
+        {
+            const DSecure& q = quotients[qi++];
+            const u32* src[4] = {q.c[0], q.c[1], q.c[2], q.c[3]};
+            u32 first, count; fold_range(q.log_size, q.lc != 0, first, count);
+            fold_circle_into_line(c.stream, layers[0].c, src, d_alpha, c.d_itw, c.tw_root_log, q.log_size, /*fresh=*/true, first, count);
+            if (q.lc != 0 && layers[0].lc == 0) complete(layers[0]);
         }
-        if (layer_partial) for (int w = 0; w < 4; w++) c.shard.comm->all_gather(c.stream, layer.c[w], sizeof(u32) << (line_log - lc()));
+        // inner layers: commit layer k (-> alpha_{k+1}), then ONE launch folds it into layer k + 1 together with the quotient of layer k's
+        // size (fold_line, then dst * alpha^2 + fold_circle: both with alpha_{k+1}). Below 2^10 rows the rest of the phase is one launch.
+        const u32 TAIL_LOG = 10;
+        u32 li = 0;
+        for (; li < n_inner; li++) {
+            const u32 log = line_log - li;
+            if (!host_channel && log <= TAIL_LOG) break;
+            Inner in; in.ev = layers[li];
+            in.tree = commit_step(1 + li, secure_cols(layers[li]), li + 1, 1 + li);
+            inner.push_back(in);
+            const DSecure* q = (qi < quotients.size() && quotients[qi].log_size == log) ? &quotients[qi++] : nullptr;
+            if (qi < quotients.size() && quotients[qi].log_size == log) throw HipError("FRI: two quotient columns of one size");
+            DSecure& next = layers[li + 1];
+            const u32* src[4] = {layers[li].c[0], layers[li].c[1], layers[li].c[2], layers[li].c[3]};
+            const u32* qs[4] = {q ? q->c[0] : nullptr, q ? q->c[1] : nullptr, q ? q->c[2] : nullptr, q ? q->c[3] : nullptr};
+            if (q && (q->lc != 0) != (layers[li].lc != 0)) throw HipError("FRI: a layer and the quotient of its size are sharded differently");
+            u32 first, count; fold_range(log, layers[li].lc != 0, first, count);
+            fold_line_circle(c.stream, next.c, src, q ? qs : nullptr, d_alpha + 8 * (li + 1), c.d_itw, c.tw_root_log, log, first, count);
+            if (layers[li].lc != 0 && next.lc == 0) complete(next);
+        }
+        if (li < n_inner) {
+            // k_fri_tail: layers li .. n_inner - 1 (2^TAIL_LOG rows and below): trees, channel steps and folds by one workgroup
+            FriTailArgs ta{};
+            ta.n_layers = n_inner - li; ta.top_log = line_log - li; ta.alpha_idx = li + 1; ta.root_idx = 1 + li;
+            ta.chan = d_chan; ta.alpha = d_alpha; ta.roots = d_roots; ta.itw = c.d_itw; ta.tw_total = 1u << c.tw_root_log; ta.rfc = c.conv.merkle_node_hash ? 0xFFFFFFFFu : 0u;
+            if (ta.n_layers > 10 || ta.top_log > TAIL_LOG) throw HipError("FRI tail: too many layers");
+            for (u32 k = 0; k < ta.n_layers; k++) {
+                const u32 log = ta.top_log - k;
+                FriTailLayer& L = ta.layer[k];
+                for (int w = 0; w < 4; w++) L.ev[w] = layers[li + k].c[w];
+                if (qi < quotients.size() && quotients[qi].log_size == log) { for (int w = 0; w < 4; w++) L.quot[w] = quotients[qi].c[w]; qi++; }
+                const DevMerkle& mk = plans[1 + li + k].mk;
+                if (mk.max_log != log) throw HipError("FRI tail: tree layout");
+                for (u32 lg = 0; lg <= log; lg++) { if (mk.shifts[lg] != 0) throw HipError("FRI tail: replicated level"); L.tree[lg] = (uint4*)mk.layers[lg]; }
+                Inner in; in.ev = layers[li + k]; in.tree = mk;
+                inner.push_back(in);
+            }
+            for (int w = 0; w < 4; w++) ta.ev_last[w] = layers[n_inner].c[w];
+            double tail_nodes = 0;
+            for (u32 k = 0; k < ta.n_layers; k++) tail_nodes += (double)((2u << (ta.top_log - k)) - 1);
+            c.stage_checkpoint();
+            fri_tail(c.stream, c.stage(&ta, 1), 48.0 * tail_nodes, tail_nodes);
+        }
+        DSecure layer = layers[n_inner];
+        line_log = last_log;
         if (qi != quotients.size()) throw HipError("FRI: not all columns consumed");
         BF_HIP(hipGetLastError());
         if (!host_channel) {

@@ -3,6 +3,7 @@
 // the column reads of the Merkle/FRI decommitment, all reached from prover::prove at
 // crates/brainfuck_prover/src/brainfuck_air/mod.rs:732 (CommitmentSchemeProver::prove_values).
 #include "kernels.h"
+#include <stdexcept>
 
 namespace bf {
 
@@ -141,8 +142,12 @@ __device__ __forceinline__ void domain_point(const u32* __restrict__ tw, u32 tw_
 // ------------------------------------------------------------------------------------------------------------------------------
 // Each lane owns 4 consecutive rows: full-size columns are read as one 16-byte access, replicated columns as one word, and the 4
 // denominators of a batch share one M31 inversion (Montgomery trick on the CM31 norms) — values identical to 4 separate inverses.
-__global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
-    u32 row0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// One launch covers every size group of a proof: groups[g] describes group g, its workgroups are [block0, next group's block0).
+__global__ void __launch_bounds__(256) k_quotients(const QuotientArgs* __restrict__ groups, u32 n_groups) {
+    u32 g = 0;
+    while (g + 1 < n_groups && groups[g + 1].block0 <= blockIdx.x) g++;      // uniform: scalar loads
+    const QuotientArgs& a = groups[g];
+    u32 row0 = ((blockIdx.x - a.block0) * blockDim.x + threadIdx.x) * 4;
     if (a.n_rows) { if (row0 >= a.n_rows) return; row0 += a.row0; }
     else if (row0 >= (1u << a.log)) return;
     // The lane's 4 rows are the points (x, y), (x, -y), (-x, -y), (-x, y) of the bit-reversed domain (domain_point: rows 4j..4j+3 share
@@ -213,10 +218,20 @@ __global__ void __launch_bounds__(256) k_quotients(QuotientArgs a) {
     *reinterpret_cast<uint4*>(a.out[2] + row0) = make_uint4(acc[0].b.a, acc[1].b.a, acc[2].b.a, acc[3].b.a);
     *reinterpret_cast<uint4*>(a.out[3] + row0) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
 }
-void accumulate_quotients(hipStream_t stream, const QuotientArgs& a) {
-    u32 n = (a.n_rows ? a.n_rows : (1u << a.log)) / 4;   // 4 rows per lane (all quotient domains have >= 2^5 rows)
+// h_groups: host copy of the table (block0 is filled in here BEFORE the caller stages it: call quotient_groups_layout first)
+u32 quotient_groups_layout(QuotientArgs* h_groups, u32 n_groups) {
+    u32 blocks = 0;
+    for (u32 g = 0; g < n_groups; g++) {
+        const u32 lanes = (h_groups[g].n_rows ? h_groups[g].n_rows : (1u << h_groups[g].log)) / 4;   // 4 rows per lane (all quotient domains have >= 2^5 rows)
+        h_groups[g].block0 = blocks;
+        blocks += (lanes + 255) / 256;
+    }
+    return blocks;
+}
+void accumulate_quotients(hipStream_t stream, const QuotientArgs* d_groups, u32 n_groups, u32 total_blocks) {
+    if (!n_groups || !total_blocks) return;
     ProfScope ps(stream, "k_quotients", 0);
-    hipLaunchKernelGGL(k_quotients, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_quotients, dim3(total_blocks), dim3(256), 0, stream, d_groups, n_groups);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -329,6 +344,21 @@ __global__ void k_accumulate(u32* __restrict__ dst, const u32* __restrict__ src,
 }
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n) {
     hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, stream, dst, src, n);
+}
+// dst[w][i] += sum over the sources s with i < 2^log[s] of src[s][w][i], for the 4 coordinate columns w: the composition polynomial's
+// coefficients = the largest size's plus the zero-extended coefficients of every smaller size (DomainEvaluationAccumulator::finalize by
+// linearity), one launch instead of 4 per size.
+__global__ void __launch_bounds__(256) k_accumulate_sizes(AccumulateSizes a) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= (1u << a.log[0])) return;      // sources are sorted by descending size
+    u32 v = a.dst[w][i];
+    for (u32 s = 0; s < a.n; s++) { if (i >= (1u << a.log[s])) break; v = m_add(v, a.src[s][w][i]); }
+    a.dst[w][i] = v;
+}
+void accumulate_sizes(hipStream_t stream, const AccumulateSizes& a) {
+    if (!a.n) return;
+    for (u32 s = 1; s < a.n; s++) if (a.log[s] > a.log[s - 1]) throw std::runtime_error("accumulate_sizes: sources must be sorted by descending size");
+    hipLaunchKernelGGL(k_accumulate_sizes, dim3(((1u << a.log[0]) + 255) / 256, 4), dim3(256), 0, stream, a);
 }
 
 // FieldOps::batch_inverse over M31: 8 elements per lane share one inversion (Montgomery trick) — values equal elementwise inverses.

@@ -356,7 +356,7 @@ def test_bench_line_contract(tmp_path):
     assert d["parity_checked"] is True and d["parity"]["own_verifier_accepts"] is True
     assert abs(d["value"] - d["config"]["cells_per_proof"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-6
     rf = d["roofline"]
-    assert rf["kernel"] == "k_merkle_layer" and rf["bound"] == "valu" and 0.5 < rf["frac"] < 1.0 and rf["compressions_per_proof"] == 674228124
+    assert rf["kernel"] == "k_merkle_layer" and rf["bound"] == "valu" and 0.5 < rf["frac"] < 1.0 and 0.95 * 674228124 < rf["compressions_per_proof"] <= 674228124 and rf["compressions_per_proof_all_merkle_kernels"] == 674246651
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["hbm"]["peak"] == 8000.0
     assert d["fft"]["algorithmic_GBps"] > 0 and any(k.startswith("k_fft_strided7") for k in d["fft"]["kernels"])
     assert [p["log_domain_rows"] for p in d["sweep"]] == [20, 22] and all(p["verified"] for p in d["sweep"])

@@ -103,3 +103,31 @@ def test_last_layer_log_size_must_match_its_coefficients(pkg, oracle, proof, con
     assert bad != proof
     assert not pkg.verify_brainfuck(bad, 12, conv)[0]
     assert not oracle.verify(bad, 12)[0]
+
+
+@pytest.mark.single_conv
+def test_bfprove_verify_try_all_names_the_convention_set(_oracle, tmp_path):
+    """tools/bfprove.py verify --try-all (host only): the one-command pin for whoever holds a proof written by the Rust reference
+    (`brainfuck_prover prove --output`, bin/brainfuck_prover.rs:127-131) — it must name exactly the switch set a proof was made under,
+    for Blake2s and Poseidon252 proofs alike, and list the first failing check per set for a proof nothing accepts."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = [sys.executable, os.path.join(root, "tools", "bfprove.py"), "verify"]
+    try:
+        for conv in ((0, 0, 0, 0), (1, 0, 1, 0), (0, 0, 1, 1)):
+            _oracle.set_conventions(*conv)
+            proof = _oracle.prove("++>,<[>+.<-]", b"\x02", log_max_rows=10)[0]
+            f = tmp_path / ("p%d%d%d%d.json" % conv)
+            f.write_bytes(proof)
+            r = subprocess.run(tool + [str(f), "--log-max-rows", "10", "--try-all"], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            hits = [l for l in r.stdout.splitlines() if l.startswith("Proof verified under")]
+            assert len(hits) == 1 and ("--conventions %d,%d,%d,%d " % conv) in hits[0], r.stdout
+            # the explicit form of the same switch set
+            r = subprocess.run(tool + [str(f), "--log-max-rows", "10", "--conventions", "%d,%d,%d,%d" % conv], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and "Proof verified" in r.stdout
+        f.write_bytes(proof.replace(b'"proof_of_work":', b'"proof_of_work":1', 1))
+        r = subprocess.run(tool + [str(f), "--log-max-rows", "10", "--try-all"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and r.stdout.count("\n  ") == 10, r.stdout        # one reason per set
+    finally:
+        _oracle.set_conventions(0, 0, 0, 0)
