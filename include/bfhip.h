@@ -66,6 +66,15 @@ int32_t bfhip_device_count(void);
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
+/* Intra-proof overlap on the context's partner streams (events only, bytes unchanged). bit 1 (default on): the FRI first-layer tree is
+ * hashed level by level behind the quotient launches (compute_fri_quotients inside mod.rs:732); bit 0 (default off — transforms and Blake2s
+ * are both VALU-limited on gfx950 and slow each other down when they co-run; measured neutral): the Merkle layers of a tree's largest
+ * columns are hashed while its smaller columns are still being transformed (tree_builder.commit, mod.rs:500,583,723). */
+int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask);
+/* Host waits of this context: 0 (default) = poll briefly, then yield / block; 1 = hipStreamSynchronize at once (hosts with more waiting
+ * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s). */
+int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);
+
 /* Conventions used by every operation of this context (prover, bfhip_merkle_commit_layer, bfhip_grind). conv == NULL restores the defaults. */
 int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv);
 int32_t bfhip_ctx_get_conventions(bfhip_ctx* ctx, bfhip_conventions* out);
@@ -202,6 +211,15 @@ int32_t bfhip_ctx_join_rccl_group(bfhip_ctx* ctx, const uint8_t id[128], uint32_
 int32_t bfhip_ctx_leave_group(bfhip_ctx* ctx);
 /* Since the group was joined: out = {all-gathers, max-reduces, grouped send-receives, payload bytes this rank sent to other ranks}. */
 int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]);
+/* GPU-side milliseconds this rank's stream spent inside {all-gathers, max-reduces, grouped send-receives} since the group was joined (one
+ * HIP-event pair per collective): the communication share of a proof over several GPUs. Synchronises the context's stream. */
+int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]);
+/* Test entry: joins an RCCL group (unique id, rank, count), runs ONE grouped send-receive on the given blocks and leaves. With a test double
+ * of librccl (environment BFHIP_RCCL_LIBRARY, tests/mock_rccl.c) the blocks are host memory and no GPU is needed; with the real library they
+ * must be device memory. stats_out (optional) = the counters of bfhip_ctx_group_stats. */
+int32_t bfhip_rccl_exchange_raw(const uint8_t id[128], uint32_t rank, uint32_t count, uint32_t n_sends, const uint32_t* send_peer, void* const* send_ptr,
+                                const size_t* send_bytes, uint32_t n_recvs, const uint32_t* recv_peer, void* const* recv_ptr, const size_t* recv_bytes,
+                                uint64_t stats_out[4]);
 /* Exercises the RCCL transport with a one-rank communicator on this context's GPU (library load, communicator, all-gather, max-reduce,
  * grouped exchange): what a single-GPU box can check of the multi-process path. */
 int32_t bfhip_rccl_selftest(bfhip_ctx* ctx);

@@ -231,6 +231,7 @@ int orc_table_from_registers(const u32* trace7, size_t n_trace, const u32* code,
         case C_RIGHT: t = instruction_sub_table(tr, OP_RIGHT); break;
         default: t = eoe_table(tr); break;
     }
+    if (t.n_rows == 0) throw std::runtime_error("EmptyTrace");      // TraceError::EmptyTrace (e.g. memory/table.rs:83-86): what trace_evaluation answers
     *n_rows = t.n_rows; *n_cols = t.cols.size();
     if (out) {
         if (t.n_rows * t.cols.size() > cap) { g_err = "cap"; return -2; }

@@ -123,6 +123,10 @@ class Context:
         _check(lib().bfhip_ctx_get_conventions(self._h, ctypes.byref(cv)))
         return cv.merkle_node_hash, cv.mix_u64, cv.logup_mask_order, cv.merkle_channel
 
+    def set_overlap(self, mask=1):
+        """bit 0: tree commitment (Merkle beside the transforms of the smaller columns), bit 1: quotients / FRI first-layer tree."""
+        _check(lib().bfhip_ctx_set_overlap(self._h, int(mask)))
+
     def set_table_builder(self, on_gpu=True):
         """Where this context builds the 13 component tables: GPU kernels (default) or the host builders. Identical results."""
         _check(lib().bfhip_ctx_set_table_builder(self._h, int(on_gpu)))
@@ -148,6 +152,12 @@ class Context:
         out = (ctypes.c_uint64 * 4)()
         _check(lib().bfhip_ctx_group_stats(self._h, out))
         return dict(zip(("all_gathers", "max_reduces", "exchanges", "bytes_sent"), [int(v) for v in out]))
+
+    def group_times(self):
+        """{all_gather_ms, max_reduce_ms, exchange_ms}: GPU-side time of this rank's collectives since it joined its shard group."""
+        out = (ctypes.c_double * 3)()
+        _check(lib().bfhip_ctx_group_times(self._h, out))
+        return dict(zip(("all_gather_ms", "max_reduce_ms", "exchange_ms"), [float(v) for v in out]))
 
     def group_info(self):
         r, n, t = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_char_p()

@@ -1,6 +1,7 @@
 // C ABI (include/bfhip.h) over the gfx950 kernels. No torch types, plain pointers and sizes.
 #include "../../include/bfhip.h"
 #include "ctx.h"
+#include <cstdlib>
 #include "host/circle.h"
 #include "host/quotients.h"
 #include <cstdio>
@@ -27,6 +28,11 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipSetDevice(dev));
     BF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    id_main = stream;
+    if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
+    if (const char* v = getenv("BFHIP_OVERLAP")) overlap = (u32)atoi(v) & 3u;
+    for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
     BF_HIP(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
@@ -55,6 +61,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
 void Ctx::destroy() {
     if (stream) (void)hipStreamSynchronize(stream);
     if (stream2) (void)hipStreamSynchronize(stream2);
+    for (auto& a : aux) if (a) { (void)hipStreamSynchronize(a); prof_forget(a); (void)hipStreamDestroy(a); a = nullptr; }
+    for (auto& e : evp) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     shard = ShardGroup();
     if (stream) prof_forget(stream);
     if (stream2) prof_forget(stream2);
@@ -130,6 +138,30 @@ int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]) {
     return 0;
     API_CATCH
 }
+int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]) {
+    API_CTX(ctx)
+    out_ms[0] = out_ms[1] = out_ms[2] = 0.0;
+    if (Comm* m = ctx->c.shard.comm.get()) { ctx->c.sync(); m->times_ms(out_ms); }
+    return 0;
+    API_CATCH
+}
+// Test entry (tests/test_abi_and_replicas.py with tests/mock_rccl.c as BFHIP_RCCL_LIBRARY): joins an RCCL group and runs ONE grouped
+// send-receive whose blocks live in HOST memory — RcclComm's bookkeeping (self blocks, zero-byte blocks, several blocks per peer, matching
+// order) driven through the 10 RCCL entry points without a GPU. With the real librccl the pointers must be device memory.
+int32_t bfhip_rccl_exchange_raw(const uint8_t id[128], uint32_t rank, uint32_t count, uint32_t n_sends, const uint32_t* send_peer, void* const* send_ptr, const size_t* send_bytes,
+                                uint32_t n_recvs, const uint32_t* recv_peer, void* const* recv_ptr, const size_t* recv_bytes, uint64_t stats_out[4]) {
+    API_TRY
+    if (!id || (n_sends && (!send_peer || !send_ptr || !send_bytes)) || (n_recvs && (!recv_peer || !recv_ptr || !recv_bytes))) throw HipError("null argument");
+    check_group_size(rank, count);
+    std::unique_ptr<Comm> comm = rccl_comm_join(id, rank, count);
+    std::vector<Xfer> sends, recvs;
+    for (u32 i = 0; i < n_sends; i++) sends.push_back({send_peer[i], send_ptr[i], send_bytes[i]});
+    for (u32 i = 0; i < n_recvs; i++) recvs.push_back({recv_peer[i], recv_ptr[i], recv_bytes[i]});
+    comm->exchange(nullptr, sends, recvs);
+    if (stats_out) { stats_out[0] = comm->n_all_gather; stats_out[1] = comm->n_all_reduce; stats_out[2] = comm->n_exchange; stats_out[3] = comm->bytes_sent; }
+    return 0;
+    API_CATCH
+}
 // Exercises the RCCL transport with a communicator of ONE rank on this context's GPU: library load, communicator creation, an in-place
 // all-gather, a max-reduce and a grouped exchange (a block to oneself). What a single-GPU box can check of the multi-process path.
 int32_t bfhip_rccl_selftest(bfhip_ctx* ctx) {
@@ -185,6 +217,15 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
     // a kept preprocessed tree is keyed on the hasher it was built with (prover.hip: PreprocessedCache::matches) and dropped here as well
     if (cv.merkle_node_hash != ctx->c.conv.merkle_node_hash || cv.merkle_channel != ctx->c.conv.merkle_channel) preprocessed_cache_invalidate(&ctx->c);
     ctx->c.conv = cv;
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking) { API_CTX(ctx) ctx->c.sync_blocking = blocking != 0; return 0; API_CATCH }
+int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask) {
+    API_CTX(ctx)
+    if (mask > 3) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer");
+    ctx->c.sync();
+    ctx->c.overlap = mask;
     return 0;
     API_CATCH
 }

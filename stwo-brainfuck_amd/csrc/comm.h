@@ -21,7 +21,7 @@ struct Comm {
     u32 rank = 0, count = 1;
     // operation counts and payload bytes this rank sent to OTHER ranks since the group was joined (tests, DESIGN.md numbers)
     u64 n_all_gather = 0, n_all_reduce = 0, n_exchange = 0, bytes_sent = 0;
-    virtual ~Comm() {}
+    virtual ~Comm();
     // In place: rank r's block is buf + r * bytes_per_rank; afterwards every block is filled on every rank.
     virtual void all_gather(hipStream_t s, void* buf, size_t bytes_per_rank) = 0;
     // Element-wise maximum over the ranks (decommitment words / sampled values: each is held by one rank, zero elsewhere).
@@ -29,6 +29,27 @@ struct Comm {
     // Point-to-point blocks. Sends to / receives from one peer are matched in list order. A block to oneself is a plain copy.
     virtual void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) = 0;
     virtual const char* transport() const = 0;
+    // Asynchronous failure of the transport (RCCL: ncclCommGetAsyncError). Called while the host waits for the stream; throws.
+    virtual void check_async() {}
+    // Gives up on the group after a failure or a timeout so that blocked peers and streams are released (RCCL: ncclCommAbort).
+    virtual void abort() {}
+
+    // GPU-side duration of every collective (one event pair each, on the stream that carries it): where the time of a proof over several
+    // GPUs goes — [0] all-gathers, [1] max-reduces, [2] grouped send-receives, in milliseconds since the group was joined. The stream must
+    // have been synchronised. Not recorded for a null stream (host-memory test transport).
+    enum { T_ALL_GATHER = 0, T_ALL_REDUCE = 1, T_EXCHANGE = 2 };
+    void times_ms(double out[3]);
+  protected:
+    struct TimedOp { hipEvent_t e0, e1; int kind; };
+    std::vector<TimedOp> pending_;
+    std::vector<hipEvent_t> pool_;
+    double ms_[3] = {0, 0, 0};
+    hipEvent_t timing_event();
+    struct Timed {      // brackets one collective
+        Comm& c; hipStream_t s; hipEvent_t e1 = nullptr;
+        Timed(Comm& c_, hipStream_t s_, int kind);
+        ~Timed();
+    };
 };
 
 // LocalComm rendezvous object shared by the N contexts of one process (reference counted: it lives until the last member has left).
@@ -39,5 +60,7 @@ std::unique_ptr<Comm> local_comm_join(const std::shared_ptr<LocalGroup>& g, u32 
 // RCCL: rank 0 creates the 128-byte unique id, the host program distributes it (control plane), every rank joins.
 void rccl_unique_id(unsigned char id[128]);
 std::unique_ptr<Comm> rccl_comm_join(const unsigned char id[128], u32 rank, u32 count);
+// Seconds a host wait inside a shard group may last before the group is declared failed (BFHIP_COMM_TIMEOUT_S, default 300).
+double comm_timeout_seconds();
 
 }  // namespace bf

@@ -6,8 +6,37 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <cstdlib>
 
 namespace bf {
+
+double comm_timeout_seconds() {
+    static const double t = [] { const char* v = getenv("BFHIP_COMM_TIMEOUT_S"); double x = v ? atof(v) : 0.0; return x > 0.0 ? x : 300.0; }();
+    return t;
+}
+Comm::~Comm() { for (auto& t : pending_) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); } for (auto e : pool_) (void)hipEventDestroy(e); }
+hipEvent_t Comm::timing_event() {
+    if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    BF_HIP(hipEventCreate(&e));
+    return e;
+}
+Comm::Timed::Timed(Comm& c_, hipStream_t s_, int kind) : c(c_), s(s_) {
+    if (!s) return;
+    hipEvent_t e0 = c.timing_event(); e1 = c.timing_event();
+    BF_HIP(hipEventRecord(e0, s));
+    c.pending_.push_back({e0, e1, kind});
+}
+Comm::Timed::~Timed() { if (e1) (void)hipEventRecord(e1, s); }
+void Comm::times_ms(double out[3]) {
+    for (auto& t : pending_) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) ms_[t.kind] += ms;
+        pool_.push_back(t.e0); pool_.push_back(t.e1);
+    }
+    pending_.clear();
+    for (int k = 0; k < 3; k++) out[k] = ms_[k];
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // LocalComm: the ranks are host threads of one process; their contexts may share a device or own one each. A transfer is a
@@ -18,16 +47,23 @@ namespace bf {
 // ---------------------------------------------------------------------------------------------------------------------------------------
 struct LocalGroup {
     u32 count;
-    std::mutex mu; std::condition_variable cv; u32 arrived = 0; u64 generation = 0; u32 joined = 0;
+    std::mutex mu; std::condition_variable cv; u32 arrived = 0; u64 generation = 0;
+    bool failed = false;                 // a member failed or left mid-collective: every rendezvous throws from then on
+    std::vector<bool> taken;             // ranks currently held by a LocalComm
     struct Slot { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; std::vector<Xfer> sends; int device = -1; };
     std::vector<Slot> slots;
-    explicit LocalGroup(u32 n) : count(n), slots(n) {}
+    explicit LocalGroup(u32 n) : count(n), taken(n, false), slots(n) {}
+    void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) throw HipError("shard group: another rank of the group failed");
         const u64 gen = generation;
         if (++arrived == count) { arrived = 0; generation++; cv.notify_all(); return; }
-        if (!cv.wait_for(lk, std::chrono::seconds(300), [&] { return generation != gen; }))
-            throw HipError("shard group: a rank did not reach the rendezvous (another rank failed or diverged)");
+        const bool ok = cv.wait_for(lk, std::chrono::duration<double>(comm_timeout_seconds()), [&] { return generation != gen || failed; });
+        if (generation != gen) return;                 // released (even if the group failed right afterwards: the next rendezvous reports it)
+        arrived--;                                     // this rank leaves the rendezvous it did not complete
+        if (!ok) { failed = true; cv.notify_all(); throw HipError("shard group: a rank did not reach the rendezvous (another rank failed or diverged)"); }
+        throw HipError("shard group: another rank of the group failed");
     }
 };
 std::shared_ptr<LocalGroup> local_group_create(u32 count) { return std::make_shared<LocalGroup>(count); }
@@ -47,15 +83,22 @@ struct LocalComm : Comm {
     bool peers_checked = false, multi_device = false;
     LocalComm(const std::shared_ptr<LocalGroup>& g_, u32 r) : g(g_) {
         rank = r; count = g_->count;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (g->taken[r]) throw HipError("shard group: this rank of the group is already taken by another context");
+            g->taken[r] = true;
+        }
         BF_HIP(hipGetDevice(&g->slots[r].device));        // the C-ABI entry has bound this thread to the context's GPU
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].done, hipEventDisableTiming));
     }
     ~LocalComm() override {
+        { std::lock_guard<std::mutex> lk(g->mu); g->taken[rank] = false; }
         (void)hipEventDestroy(g->slots[rank].ready); (void)hipEventDestroy(g->slots[rank].done);
         g->slots[rank].ready = g->slots[rank].done = nullptr;
         (void)hipFree(scratch);
     }
+    void abort() override { g->fail(); }
     const char* transport() const override {
         return multi_device ? "local (N contexts of one process on one GPU each, peer copies ordered by HIP events)"
                             : "local (N contexts of one process, device-to-device copies ordered by HIP events)";
@@ -88,6 +131,7 @@ struct LocalComm : Comm {
     }
     void all_gather(hipStream_t s, void* buf, size_t bpr) override {
         n_all_gather++; bytes_sent += bpr * (count - 1);
+        Timed tm(*this, s, T_ALL_GATHER);
         publish(s, buf);
         for (u32 p = 0; p < count; p++) {
             if (p == rank) continue;
@@ -99,6 +143,7 @@ struct LocalComm : Comm {
     void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
         n_all_reduce++; bytes_sent += n * sizeof(u32);
         if (n == 0) { g->barrier(); g->barrier(); return; }
+        Timed tm(*this, s, T_ALL_REDUCE);
         const size_t need = (size_t)(count + 1) * n;
         if (scratch_words < need) { BF_HIP(hipStreamSynchronize(s)); (void)hipFree(scratch); scratch = nullptr; scratch_words = 0; BF_HIP(hipMalloc((void**)&scratch, need * sizeof(u32))); scratch_words = need; }
         publish(s, buf);
@@ -113,6 +158,7 @@ struct LocalComm : Comm {
     }
     void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
         n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
+        Timed tm(*this, s, T_EXCHANGE);
         g->slots[rank].sends = sends;
         publish(s, nullptr);
         std::vector<size_t> next(count, 0);   // per peer: position in that peer's send list of the next block addressed to me
@@ -120,7 +166,7 @@ struct LocalComm : Comm {
             const std::vector<Xfer>& ps = g->slots[r.peer].sends;
             size_t& k = next[r.peer];
             while (k < ps.size() && ps[k].peer != rank) k++;
-            if (k >= ps.size() || ps[k].bytes != r.bytes) throw HipError("shard group: unmatched send/receive");
+            if (k >= ps.size() || ps[k].bytes != r.bytes) { g->fail(); throw HipError("shard group: unmatched send/receive"); }
             if (r.peer != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[r.peer].ready, 0));
             if (r.bytes) copy_from(r.peer, r.ptr, ps[k].ptr, r.bytes, s);
             k++;
@@ -148,13 +194,19 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    // Only a test double exports this (tests/mock_rccl.c, selected with BFHIP_RCCL_LIBRARY): copies between HOST buffers, so that
+    // RcclComm's bookkeeping can be driven on a box without a GPU. The real transport copies a block to oneself with hipMemcpyAsync.
+    int (*MockSelfCopy)(void*, const void*, size_t) = nullptr;
 };
 static RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+        if (const char* over = getenv("BFHIP_RCCL_LIBRARY")) api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);      // a test double of the 10 entry points
+        else for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
         if (!api.lib) return;
         auto sym = [&](const char* n) { return dlsym(api.lib, n); };
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
@@ -167,6 +219,9 @@ static RcclApi& rccl() {
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.CommGetAsyncError = (decltype(api.CommGetAsyncError))sym("ncclCommGetAsyncError");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+        api.MockSelfCopy = (decltype(api.MockSelfCopy))sym("bfhip_mock_self_copy");
     });
     if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
         throw HipError("RCCL is not available (librccl.so.1 could not be loaded): a multi-process shard group needs it");
@@ -188,18 +243,29 @@ struct RcclComm : Comm {
         ncclUniqueId u; memcpy(&u, id, 128);
         BF_NCCL(rccl().CommInitRank(&comm, (int)n, u, (int)r));
     }
-    ~RcclComm() override { if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm); }
+    bool aborted = false;
+    ~RcclComm() override { if (comm && !aborted && rccl().CommDestroy) (void)rccl().CommDestroy(comm); }
+    void check_async() override {
+        if (!comm || !rccl().CommGetAsyncError) return;
+        ncclResult_t st = ncclSuccess;
+        if (rccl().CommGetAsyncError(comm, &st) == ncclSuccess && st != ncclSuccess && st != ncclInProgress)
+            throw HipError(std::string("shard group: RCCL reported an asynchronous error: ") + (rccl().GetErrorString ? rccl().GetErrorString(st) : "?"));
+    }
+    void abort() override { if (comm && !aborted && rccl().CommAbort) { aborted = true; (void)rccl().CommAbort(comm); } }
     const char* transport() const override { return "RCCL (one process per GPU, collectives on the context's stream over xGMI)"; }
     void all_gather(hipStream_t s, void* buf, size_t bpr) override {
         n_all_gather++; bytes_sent += bpr * (count - 1);
+        Timed tm(*this, s, T_ALL_GATHER);
         BF_NCCL(rccl().AllGather((const char*)buf + rank * bpr, buf, bpr, ncclUint8, comm, s));   // in place: send block = my block of the receive buffer
     }
     void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
         n_all_reduce++; bytes_sent += n * sizeof(u32);
+        Timed tm(*this, s, T_ALL_REDUCE);
         if (n) BF_NCCL(rccl().AllReduce(buf, buf, n, ncclUint32, ncclMax, comm, s));
     }
     void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
         n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
+        Timed tm(*this, s, T_EXCHANGE);
         // blocks to oneself are plain copies, matched in order
         std::vector<const Xfer*> self_s, self_r;
         for (auto& x : sends) if (x.peer == rank) self_s.push_back(&x);
@@ -207,7 +273,9 @@ struct RcclComm : Comm {
         if (self_s.size() != self_r.size()) throw HipError("shard group: unmatched self transfer");
         for (size_t i = 0; i < self_s.size(); i++) {
             if (self_s[i]->bytes != self_r[i]->bytes) throw HipError("shard group: unmatched self transfer");
-            if (self_s[i]->bytes) BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
+            if (!self_s[i]->bytes) continue;
+            if (rccl().MockSelfCopy) { if (rccl().MockSelfCopy(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes) != 0) throw HipError("shard group: self copy failed"); }
+            else BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
         }
         BF_NCCL(rccl().GroupStart());
         for (auto& x : sends) if (x.peer != rank && x.bytes) BF_NCCL(rccl().Send(x.ptr, x.bytes, ncclUint8, (int)x.peer, comm, s));

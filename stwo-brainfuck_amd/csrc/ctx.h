@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdlib>
 #include <thread>
+#include <chrono>
 #include "kernels.h"
 #include "comm.h"
 #include <memory>
@@ -49,6 +50,18 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase
     bool side_busy = false;         // work enqueued on stream2 may still read parameter blocks from the staging ring
+    // Partner streams for overlap INSIDE a tree commitment: the VALU-bound Merkle layers of the largest columns run on the partner while the
+    // HBM-bound transforms of the smaller columns continue on the stream itself (aux[0] beside the main stream, aux[1] beside the side stream).
+    // Ordered by events only; both are joined back (event wait) before the commitment returns.
+    // overlap: bit 0 = hash a tree's largest layers beside the transforms of its smaller columns; bit 1 = hash the FRI first-layer tree level by
+    // level behind the quotient launches (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
+    u32 overlap = 2;      // measured on one box (profiles/r03_overlap_ab.txt): bit 1 gains 0.3 ms on fib19, bit 0 nothing (both sides are VALU-limited)
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipStream_t id_main = nullptr;  // the main stream's handle (stream and stream2 are swapped while the preprocessed phase is enqueued)
+    hipStream_t aux_of(hipStream_t s) const { return s == id_main ? aux[0] : aux[1]; }
+    hipEvent_t evp[32] = {};        // ordering events (no timing), handed out round robin: a wait captures the event's state when it is enqueued
+    u32 evp_next = 0;
+    hipEvent_t next_event() { return evp[evp_next++ % 32]; }
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
     u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
     u32* d_tw = nullptr; u32* d_itw = nullptr;
@@ -70,15 +83,33 @@ struct Ctx {
     // by a few microseconds of host work and the next launches, so the wake-up latency of a blocking wait is paid ~10 times per proof:
     // poll an event instead (BFHIP_SYNC=block restores hipStreamSynchronize).
     hipEvent_t sync_ev = nullptr;
+    // Waits: a few tens of microseconds of polling (the Fiat-Shamir round trips are that short: no wake-up latency), then yielding polls;
+    // `sync_blocking` (bfhip_ctx_set_sync_policy, or BFHIP_SYNC=block at context creation) goes to hipStreamSynchronize at once — for hosts
+    // with more waiting contexts than cores. Inside a shard group every wait is BOUNDED: the transport is polled for asynchronous errors and
+    // after comm_timeout_seconds() the group is aborted and the wait fails, instead of a stream that hangs on a peer that diverged.
+    bool sync_blocking = false;
     void sync() {
-        static const bool block = [] { const char* v = getenv("BFHIP_SYNC"); return v && v[0] == 'b'; }();
-        if (block || !sync_ev) { BF_HIP(hipStreamSynchronize(stream)); return; }
+        const bool grouped = shard.count > 1 && shard.comm;
+        if ((sync_blocking && !grouped) || !sync_ev) { BF_HIP(hipStreamSynchronize(stream)); return; }
         BF_HIP(hipEventRecord(sync_ev, stream));
+        const auto t0 = std::chrono::steady_clock::now();
         for (u32 polls = 0;; polls++) {
             hipError_t e = hipEventQuery(sync_ev);
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) BF_HIP(e);
-            if (polls > 64) std::this_thread::yield();      // several contexts may be waiting on as many host threads
+            if (polls < 64) continue;
+            if ((polls & 1023u) == 0) {
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (grouped) {
+                    try { shard.comm->check_async(); } catch (...) { shard.comm->abort(); throw; }
+                    if (waited > comm_timeout_seconds()) { shard.comm->abort(); throw HipError("shard group: the stream did not complete within the communication timeout (a peer failed or diverged)"); }
+                } else if (waited > 200e-6 && !grouped) {
+                    // a long wait (a whole proof, a big trace): stop burning a core
+                    BF_HIP(hipEventSynchronize(sync_ev));
+                    return;
+                }
+            }
+            std::this_thread::yield();      // several contexts may be waiting on as many host threads
         }
     }
     // Copy a small host block to device scratch (valid until the ring is recycled by stage_checkpoint()). Stream-ordered.
@@ -103,7 +134,14 @@ struct Ctx {
     // Called at the start of every high-level operation: recycles the staging ring once it is half full (after a sync, so no
     // in-flight kernel still reads parameter blocks from it).
     void stage_checkpoint() {
-        if (stage_batch_depth == 0 && stage_used > stage_bytes / 2) { sync(); if (side_busy) BF_HIP(hipStreamSynchronize(stream2)); stage_used = 0; }
+        if (stage_batch_depth == 0 && stage_used > stage_bytes / 2) {
+            // every stream of the context may still read parameter blocks from the ring (`stream` may currently be a partner stream)
+            sync();
+            BF_HIP(hipStreamSynchronize(stream2));
+            if (id_main) BF_HIP(hipStreamSynchronize(id_main));
+            for (auto a : aux) if (a) BF_HIP(hipStreamSynchronize(a));
+            stage_used = 0;
+        }
     }
     u32* alloc_u32(size_t n) { return (u32*)arena.alloc(n * sizeof(u32)); }
     // Stream-ordered device -> host read of a small result through the pinned bounce buffer; returns after the data has arrived.

@@ -256,7 +256,10 @@ struct HipProver {
         }
         return p;
     }
-    DevMerkle merkle_run(MerklePlan& p, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr) {
+    // waits: before the level `level` (and everything below it) is hashed the stream waits for `ev` — the columns of that size are produced
+    // on another stream while the larger layers are being hashed. Sorted by descending level.
+    struct LevelWait { int level; hipEvent_t ev; };
+    DevMerkle merkle_run(MerklePlan& p, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr, const std::vector<LevelWait>* waits = nullptr) {
         DevMerkle& mk = p.mk;
         const ShardGroup& sg = c.shard;
         const bool poseidon = p.poseidon;
@@ -265,7 +268,10 @@ struct HipProver {
         const char* layer_kernel = poseidon ? "k_merkle_layer_poseidon" : "k_merkle_layer";
         prof_run_begin(c.stream, layer_kernel);
         const int single_lo = p.sub_hi ? (int)p.sub_hi + 1 : (int)fused_top;
+        size_t wi = 0;
+        auto apply_waits = [&](int log) { while (waits && wi < waits->size() && (*waits)[wi].level >= log) BF_HIP(hipStreamWaitEvent(c.stream, (*waits)[wi++].ev, 0)); };
         for (int log = (int)mk.max_log; log >= single_lo; log--) {
+            apply_waits(log);
             size_t n = (log > 0 ? p.off[log - 1] : p.n_all) - p.off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? ((1u << (log - mk.shifts[log])) >> sg.log_count) : 0u;   // in stored slots
@@ -284,6 +290,7 @@ struct HipProver {
             }
         }
         prof_run_end(c.stream);
+        apply_waits(0);
         if (p.sub_hi) merkle_subtree(c.stream, p.d_tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
         if (fused_top > 0) merkle_top(c.stream, p.d_tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr, p.top_bytes, p.top_comp);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
@@ -436,6 +443,67 @@ struct HipProver {
         if (!pinned_root) ch.mix_root(t.mk.root);
     }
 
+    // One process per proof: the same commitment with its two bounds overlapped. The transforms are HBM-bound, the Blake2s layers
+    // VALU-bound, and layer L of a mixed-degree tree needs only the columns of size L and layer L + 1 — so the largest size class is
+    // transformed first and its layers are hashed on the partner stream while the smaller classes are still being transformed.
+    // interp_src (optional, one entry per polynomial): evaluations still to be interpolated into t.polys (extend_evals), wave by wave.
+    void commit_tree_overlapped(DTree& t, Hash32* pinned_root, const std::vector<DCol>* interp_src = nullptr) {
+        const size_t n = t.polys.size();
+        t.owner.assign(n, OWNER_ALL);
+        t.evals.resize(n); t.prev.assign(n, DCol());
+        u32 max_log = 0;
+        for (size_t i = 0; i < n; i++) {
+            DCol e; e.log_size = t.polys[i].log_size + cfg.log_blowup; e.shift = t.polys[i].shift; e.ptr = c.alloc_u32(e.stored());
+            t.evals[i] = e; max_log = std::max(max_log, e.log_size);
+        }
+        std::vector<DCol> src[2], pol[2], ev[2];
+        u32 next_log = 0;                       // largest size among the second wave
+        for (size_t i = 0; i < n; i++) {
+            const int w = t.evals[i].log_size == max_log ? 0 : 1;
+            if (interp_src) src[w].push_back((*interp_src)[i]);
+            pol[w].push_back(t.polys[i]); ev[w].push_back(t.evals[i]);
+            if (w) next_log = std::max(next_log, t.evals[i].log_size);
+        }
+        // below ~2^18 leaves the whole tree is a latency chain: nothing to hide, one stream
+        const bool overlap = (c.overlap & 1u) && !ev[1].empty() && max_log >= 19;
+        c.stage_checkpoint();
+        FftPlan fi[2], fe[2];
+        MerklePlan mp;
+        {
+            StageBatch sb(c);
+            for (int w = 0; w < 2; w++) {
+                if (interp_src) fi[w] = fft_prepare(true, src[w], pol[w]);
+                fe[w] = fft_prepare(false, pol[w], ev[w]);
+            }
+            mp = merkle_plan(t.evals);
+            sb.end();
+        }
+        hipStream_t main = c.stream, aux = c.aux_of(main);
+        if (interp_src) fft_launch(fi[0]);
+        fft_launch(fe[0]);
+        if (!overlap) {
+            if (interp_src) fft_launch(fi[1]);
+            fft_launch(fe[1]);
+            t.mk = merkle_run(mp, pinned_root);
+        } else {
+            hipEvent_t e1 = c.next_event(), e2 = c.next_event(), e3 = c.next_event();
+            BF_HIP(hipEventRecord(e1, main));
+            if (interp_src) fft_launch(fi[1]);
+            fft_launch(fe[1]);
+            BF_HIP(hipEventRecord(e2, main));
+            BF_HIP(hipStreamWaitEvent(aux, e1, 0));
+            std::vector<LevelWait> waits = {{(int)next_log, e2}};
+            c.stream = aux;
+            try { t.mk = merkle_run(mp, nullptr, /*no_readback=*/true, nullptr, &waits); } catch (...) { c.stream = main; (void)hipStreamSynchronize(aux); throw; }
+            c.stream = main;
+            BF_HIP(hipEventRecord(e3, aux));
+            BF_HIP(hipStreamWaitEvent(main, e3, 0));      // joined: whatever follows on this stream sees the tree
+            if (pinned_root) BF_HIP(hipMemcpyAsync(pinned_root->b, t.mk.layers[0], 32, hipMemcpyDeviceToHost, main));
+            else c.read_back(t.mk.root.b, t.mk.layers[0], 32);
+        }
+        if (!pinned_root) ch.mix_root(t.mk.root);
+    }
+
     // ------------------------------------------------------------------------------------------------------------------------------
     // Host table build + upload (outside the metric's timed region: "inputs already resident in HBM").
     // Prover-input preparation from the VM trace. on_gpu (default): the 13 table builders run on the device (tables.hip);
@@ -528,7 +596,7 @@ struct HipProver {
                     ifc.ptr[p.log_size - LOG_N_LANES] = p.ptr;
                 }
                 is_first_coeffs(c.stream, ifc, c.d_itw, c.tw_root_log);
-                commit_tree(trees[0], pinned_root0);
+                if (sharded()) commit_tree(trees[0], pinned_root0); else commit_tree_overlapped(trees[0], pinned_root0);
                 if (cache.enabled) std::swap(c.arena, cache.keep);
                 BF_HIP(hipEventRecord(c.ev[1], c.stream));
             } catch (...) { if (use_side) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } throw; }
@@ -558,9 +626,9 @@ struct HipProver {
             {
                 std::vector<DCol> src;
                 for (int k = 0; k < N_COMPONENTS; k++) for (auto& r : rows[k]) src.push_back(r);
-                fft_cols(true, src, trees[1].polys);
+                if (sharded()) { fft_cols(true, src, trees[1].polys); commit_tree(trees[1], pinned_root1); }
+                else commit_tree_overlapped(trees[1], pinned_root1, &src);
             }
-            commit_tree(trees[1], pinned_root1);
             BF_HIP(hipEventRecord(c.ev[2], c.stream));
             c.sync();
         } catch (...) { join_side(); throw; }
@@ -633,14 +701,14 @@ struct HipProver {
         trees[2].polys = inter_vals;          // interpolate in place
         // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner
         // interpolates and extends a column; the row-granular ones and the small ones are transformed by every rank.
-        trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
-        {
+        for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
+        if (sharded()) {
+            trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
             std::vector<DCol> mine_cols;
             for (size_t i = 0; i < inter_vals.size(); i++) if (trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank) mine_cols.push_back(inter_vals[i]);
             fft_cols(true, mine_cols, mine_cols);
-        }
-        for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
-        commit_tree(trees[2], nullptr, /*with_prev=*/true);
+            commit_tree(trees[2], nullptr, /*with_prev=*/true);
+        } else commit_tree_overlapped(trees[2], nullptr, &inter_vals);
         tap("root2");
         tm.interaction = now() - t0;
 
@@ -648,7 +716,7 @@ struct HipProver {
         t0 = now();
         Q31 random_coeff = ch.draw_felt();
         compute_composition(trees, bp, main_off, inter_off, el, random_coeff);
-        commit_tree(trees[3]);
+        if (sharded()) commit_tree(trees[3]); else commit_tree_overlapped(trees[3], nullptr);
         tap("root3");
         tm.composition = now() - t0;
 
@@ -693,13 +761,14 @@ struct HipProver {
         t0 = now();
         Q31 q_coeff = ch.draw_felt();
         BF_HIP(hipEventRecord(c.ev[4], c.stream));
-        std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff);
+        std::vector<LevelWait> q_waits;
+        std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff, &q_waits);
         BF_HIP(hipEventRecord(c.ev[5], c.stream));
         // no host wait here: the FRI phase is planned (layer storage, 26 tree layouts, one staging copy) while the quotient kernels run;
         // the phase time comes from the two events
 
         // ---- FRI commit (a10), proof of work (a11), decommitment (a12) -------------------------------------------------------------------
-        fri_and_decommit(trees, quotients, bp.proof);
+        fri_and_decommit(trees, quotients, bp.proof, q_waits);
         {
             float ms_q = 0.f;
             BF_HIP(hipEventElapsedTime(&ms_q, c.ev[4], c.ev[5]));      // both completed: fri_and_decommit ends with host waits
@@ -882,7 +951,7 @@ struct HipProver {
 
     // compute_fri_quotients: one secure column per distinct LDE size, descending.
     std::vector<DSecure> compute_quotients(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points,
-                                           const StarkProof& pf, Q31 random_coeff) {
+                                           const StarkProof& pf, Q31 random_coeff, std::vector<LevelWait>* q_waits = nullptr) {
         struct FlatCol { DCol col; size_t tree, idx; };
         std::vector<FlatCol> flat;
         for (size_t t = 0; t < trees.size(); t++) for (size_t i = 0; i < trees[t].evals.size(); i++) flat.push_back({trees[t].evals[i], t, i});
@@ -921,10 +990,24 @@ struct HipProver {
             out.push_back(q);
             i = j;
         }
-        const u32 q_blocks = quotient_groups_layout(launches.data(), (u32)launches.size());
+        // Launches: one per size group of >= 2^19 rows, largest first, each followed by an event (q_waits) — the FRI first-layer tree hashes
+        // level L as soon as the quotient of size L exists, on the partner stream, while the smaller groups are still being computed — and one
+        // launch for all the smaller groups together. (Shard group / host channel: one launch, no events.)
+        const bool pipelined = (c.overlap & 2u) && q_waits && !sharded() && c.conv.merkle_channel == 0;
+        std::vector<std::pair<u32, u32>> ranges;      // [first group, count)
+        {
+            u32 g = 0;
+            if (pipelined) while (g < launches.size() && launches[g].log >= 19) { ranges.push_back({g, 1u}); g++; }
+            if (g < launches.size()) ranges.push_back({g, (u32)launches.size() - g});
+        }
+        std::vector<u32> blocks;
+        for (auto& r : ranges) blocks.push_back(quotient_groups_layout(launches.data() + r.first, r.second));
         const QuotientArgs* d_groups = launches.empty() ? nullptr : c.stage(launches.data(), launches.size());
         sb.end();                                   // one copy for the parameter blocks of every size group
-        accumulate_quotients(c.stream, d_groups, (u32)launches.size(), q_blocks);     // and one launch
+        for (size_t k = 0; k < ranges.size(); k++) {
+            accumulate_quotients(c.stream, d_groups + ranges[k].first, ranges[k].second, blocks[k]);
+            if (pipelined) { hipEvent_t e = c.next_event(); BF_HIP(hipEventRecord(e, c.stream)); q_waits->push_back({(int)launches[ranges[k].first].log, e}); }
+        }
         BF_HIP(hipGetLastError());
         return out;
     }
@@ -969,7 +1052,7 @@ struct HipProver {
         return v;
     }
 
-    void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf) {
+    void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf, const std::vector<LevelWait>& q_waits) {
         // FriProver::commit — first layer: one Merkle tree over the coordinate columns of every quotient.
         // The channel is stepped on the device through the whole commit phase (k_channel_mix_root_draw): per layer mix_root(root) and
         // draw_felt() run as a one-lane kernel and the folds read alpha from device memory, so the ~25 layers are enqueued back to back
@@ -984,6 +1067,12 @@ struct HipProver {
         u32* d_alpha = c.alloc_u32(8 * (max_layers + 1));
         u32* d_roots = c.alloc_u32(8 * (max_layers + 1));                                        // root copies, read back once
         memcpy(pinned_chan, ch.digest.b, 32); pinned_chan[8] = ch.n_sent;
+        // Pipelined with the quotient launches (q_waits): the channel state, the tree layouts and the first-layer tree go to the PARTNER stream —
+        // on the main stream they would queue up behind every quotient kernel.
+        hipStream_t main_stream = c.stream;
+        const bool first_on_aux = c.conv.merkle_channel == 0 && !q_waits.empty();
+        if (first_on_aux) c.stream = c.aux_of(main_stream);
+        struct StreamRestore { Ctx& c; hipStream_t s; ~StreamRestore() { c.stream = s; } } restore_stream{c, main_stream};
         BF_HIP(hipMemcpyAsync(d_chan, pinned_chan, 36, hipMemcpyHostToDevice, c.stream));
         // Poseidon252Channel is stepped on the host (one root read-back per layer): two serial Hades permutations by a single lane would
         // cost more than the round trip. commit_step = Merkle tree of a layer + mix_root + draw alpha (alpha || alpha^2 -> d_alpha[idx]).
@@ -1024,7 +1113,16 @@ struct HipProver {
             BF_HIP(hipMemcpyAsync(d_alpha + 8 * alpha_idx, st, 32, hipMemcpyDeviceToDevice, c.stream));
             return t;
         };
-        DevMerkle first_tree = commit_step(0, first_cols, 0, 0);
+        DevMerkle first_tree;
+        if (first_on_aux) {
+            // level L of the first-layer tree is hashed as soon as the quotient of size L exists; joined before the first fold
+            ChannelStep st{d_chan, d_alpha, d_roots};
+            first_tree = merkle_run(plans[0], nullptr, /*no_readback=*/true, &st, &q_waits);
+            hipEvent_t e3 = c.next_event();
+            BF_HIP(hipEventRecord(e3, c.stream));
+            c.stream = main_stream;
+            BF_HIP(hipStreamWaitEvent(main_stream, e3, 0));
+        } else first_tree = commit_step(0, first_cols, 0, 0);
         struct Inner { DSecure ev; DevMerkle tree; };
         std::vector<Inner> inner;
         // destination range of a fold whose SOURCE has 2^src_log rows: the image of this rank's source range when the source is sharded
@@ -1215,6 +1313,12 @@ extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 
+// A proof that fails on one rank of a shard group must not leave the others waiting for its next collective: the transport is told to give
+// up (in-process: the rendezvous object is marked failed and every waiting rank throws; RCCL: ncclCommAbort). The group is unusable afterwards.
+static void release_group_after_failure(bfhip_ctx* ctx) {
+    if (ctx && ctx->c.shard.count > 1 && ctx->c.shard.comm) { try { ctx->c.shard.comm->abort(); } catch (...) {} (void)hipStreamSynchronize(ctx->c.stream); }
+}
+
 static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {
     if (proof_json) {
         std::string js = proof_to_json(bp, pv.c.conv.merkle_channel == 1);
@@ -1291,7 +1395,7 @@ extern "C" int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, u
         BrainfuckProof bp = pv.prove(trace->in);
         fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
         return 0;
-    } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; } catch (...) { bfhip_set_error("unknown error"); return -1; }
+    } catch (const std::exception& e) { release_group_after_failure(ctx); bfhip_set_error(e.what()); return -1; } catch (...) { release_group_after_failure(ctx); bfhip_set_error("unknown error"); return -1; }
 }
 
 extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input, size_t n_input, uint32_t log_max_rows,
@@ -1314,7 +1418,8 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
         fill_outputs(pv, bp, proof_json, proof_len, transcript, phase_seconds);
         in.release();
         return 0;
-    } catch (const std::exception& e) { in.release(); bfhip_set_error(e.what()); return -1; } catch (...) { in.release(); bfhip_set_error("unknown error"); return -1; }
+    } catch (const std::exception& e) { release_group_after_failure(ctx); in.release(); bfhip_set_error(e.what()); return -1; }
+    catch (...) { release_group_after_failure(ctx); in.release(); bfhip_set_error("unknown error"); return -1; }
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
 extern "C" int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on) {
@@ -1392,6 +1497,7 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
             case C_EOE: t = eoe_table(tr); break;
             default: bfhip_set_error("bad component"); return -1;
         }
+        if (t.n_rows == 0) throw HipError("EmptyTrace");      // TraceError::EmptyTrace (memory/table.rs:83-86 and the six analogues)
         *n_rows = t.n_rows; *n_cols = t.cols.size();
         if (out_row_major) {
             if (t.n_rows * t.cols.size() > cap) { bfhip_set_error("capacity"); return -2; }
@@ -1401,16 +1507,16 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
     } catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 // Profiler state is per stream, i.e. per context: contexts on other threads are not affected (prof.hip).
-static void sync_both(Ctx& c) { c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); }
+static void sync_both(Ctx& c) { c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a)); }
 extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) {
-    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); return 0; }
+    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); for (auto a : ctx->c.aux) prof_enable(a, mode); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) {
-    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); return 0; }
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); for (auto a : ctx->c.aux) prof_reset(a); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {
-    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); hipStream_t ss[2] = {ctx->c.stream, ctx->c.stream2}; std::string s = prof_report_json(ss, 2); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); hipStream_t ss[4] = {ctx->c.stream, ctx->c.stream2, ctx->c.aux[0], ctx->c.aux[1]}; std::string s = prof_report_json(ss, 4); *json = (char*)malloc(s.size() + 1); memcpy(*json, s.c_str(), s.size() + 1); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }

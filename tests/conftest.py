@@ -266,3 +266,34 @@ def splitmix_column(seed: int, n: int) -> np.ndarray:
     x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
     x ^= x >> np.uint64(31)
     return (x % np.uint64(P)).astype(np.uint32)
+
+
+def logup_expected_dummy_elements(rows, columns):
+    """Pure-Python restatement of LogupTraceGenerator (write_frac / finalize_col / finalize_last) for the reference's
+    interaction-trace tests, which run under LookupElements::dummy() (z = 1, every alpha power 1): combine(values) = sum(values) - 1 is a
+    base-field value, so every fraction lies in M31 and only coordinate 0 of a logUp column is non-zero.
+    rows: table rows (lists of main-column values); columns: [{"denominator_columns": [...], "numerators": [...]}, ...] as the reference test
+    writes them. Returns (one full-size M31 column of 16 * n_rows cells per logUp column, claimed sum). A table row occupies the 16 cells
+    16 r .. 16 r + 15 of the bit-reversed circle-domain order (PackedM31 broadcast, memory/table.rs:95-104); a column before the last holds
+    the running sum over the logUp columns per row; the last one is prefix-summed in COSET order."""
+    M = len(rows)
+    n = 16 * M
+    log = n.bit_length() - 1
+    run = [0] * M
+    out = []
+    for k, col in enumerate(columns):
+        for r in range(M):
+            den = (sum(rows[r][c] for c in col["denominator_columns"]) - 1) % P
+            run[r] = (run[r] + (col["numerators"][r] % P) * pow(den, P - 2, P)) % P
+        if k + 1 < len(columns):
+            out.append([run[s >> 4] for s in range(n)])
+    def bitrev(i, bits):
+        return int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
+    last, acc = [0] * n, 0
+    for i in range(n):                                   # coset position i -> circle-domain index -> bit-reversed storage cell
+        idx = i // 2 if i % 2 == 0 else n - (i + 1) // 2
+        s = bitrev(idx, log)
+        acc = (acc + run[s >> 4]) % P
+        last[s] = acc
+    out.append(last)
+    return out, acc

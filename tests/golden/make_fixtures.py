@@ -34,6 +34,132 @@ def pair_rows(entries):
     return [a + b for a, b in zip(entries, nxt)]
 
 
+
+# ---- round 3: the remaining table-level tests of the reference, as (register rows -> table rows) vectors ---------------------------------
+# A reference test that builds an *intermediate* table from hand-written entries is restated as the register rows that produce exactly
+# those entries (Memory/Processor entries are the registers themselves; sub-component entries are selected by `ci`; Instruction entries are
+# program + trace, here with an empty program), and the pinned intermediate table is carried to table rows by the cited pairing rule.
+def reg(clk=0, ip=0, ci=0, ni=0, mp=0, mv=0, mvi=0):
+    return [clk, ip, ci, ni, mp, mv, mvi]
+
+
+def mem_rows(entries):
+    """MemoryTable::from(intermediate) — memory/table.rs:121-151: row r = entry r || entry r+1, the last one pairs with
+    new_dummy(last.clk + 1, last.mp, last.mv)."""
+    last = entries[-1]
+    nxt = entries[1:] + [[last[0] + 1, last[1], last[2], 1]]
+    return [a + b for a, b in zip(entries, nxt)]
+
+
+LEFT, RIGHT, PLUS, MINUS, PUTC, READC, JZ, JNZ = 60, 62, 43, 45, 46, 44, 91, 93
+
+TABLES_R3 = [
+    # ---------------- memory/table.rs ----------------
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:638-651 (test_sort: sorted by (mp, clk)) + pad :291-303 + pairing :121-151",
+     "component": 0, "code_words": [PLUS],
+     "trace": [reg(clk=0, mp=1), reg(clk=0, mp=0), reg(clk=1, mp=0)],
+     "expected": mem_rows([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0], [1, 1, 0, 1]])},
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:663-686 (test_complete_wih_dummy_entries: clk gaps of one mp filled with d = 1) + pad + pairing",
+     "component": 0, "code_words": [PLUS],
+     "trace": [reg(clk=5, mp=1, mv=1), reg(clk=0, mp=0), reg(clk=0, mp=1)],
+     "expected": mem_rows([[0, 0, 0, 0], [0, 1, 0, 0], [1, 1, 0, 1], [2, 1, 0, 1], [3, 1, 0, 1], [4, 1, 0, 1], [5, 1, 1, 0], [6, 1, 1, 1]])},
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:695-712 (test_pad: dummy (last.clk + 1, last.mp, last.mv)) + pairing",
+     "component": 0, "code_words": [PLUS],
+     "trace": [reg(clk=0, mp=0, mv=0), reg(clk=1, mp=1, mv=0), reg(clk=2, mp=1, mv=1)],
+     "expected": mem_rows([[0, 0, 0, 0], [1, 1, 0, 0], [2, 1, 1, 0], [3, 1, 1, 1]])},
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:757-799 (test_trace_evaluation: columns clk, mp, mv, d of rows 0, 1) + pairing",
+     "component": 0, "code_words": [PLUS],
+     "trace": [reg(clk=0, mp=43, mv=91), reg(clk=1, mp=91, mv=9)],
+     "expected": mem_rows([[0, 43, 91, 0], [1, 91, 9, 0]])},
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:886-929 (test_interaction_trace_evaluation_dummy_entries_effect: the table of the real entries only)",
+     "component": 0, "code_words": [PLUS],
+     "trace": [reg(clk=0, mp=43, mv=91), reg(clk=2, mp=91, mv=9)],
+     "expected": mem_rows([[0, 43, 91, 0], [2, 91, 9, 0]])},
+    # ---------------- instruction/table.rs (entries given directly = trace rows with an empty program) ----------------
+    {"cite": "crates/brainfuck_prover/src/components/instruction/table.rs:816-889 (test_trace_evaluation_single_row: all 8 columns)",
+     "component": 1, "code_words": [],
+     "trace": [reg(ip=1, ci=43, ni=91)],
+     "expected": [[1, 43, 91, 0, 1, 0, 0, 1]]},
+    {"cite": "crates/brainfuck_prover/src/components/instruction/table.rs:892-946 (test_instruction_trace_evaluation: columns ip, ci, ni) + pairing :116-145",
+     "component": 1, "code_words": [],
+     "trace": [reg(clk=0, ip=0, ci=43, ni=91), reg(clk=1, ip=1, ci=91, ni=9)],
+     "expected": [[0, 43, 91, 0, 1, 91, 9, 0], [1, 91, 9, 0, 1, 0, 0, 1]]},
+    # ---------------- processor/table.rs ----------------
+    {"cite": "crates/brainfuck_prover/src/components/processor/table.rs:898-937 (test_trace_evaluation_single_row_processor_table) + pairing :117-145",
+     "component": 3, "code_words": [PLUS],
+     "trace": [reg(1, 2, 3, 4, 5, 6, 7)],
+     "expected": [[1, 2, 3, 4, 5, 6, 7, 0, 2]]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/table.rs:940-1050 (test_trace_evaluation_processor_table_with_multiple_rows: all 9 columns)",
+     "component": 3, "code_words": [PLUS],
+     "trace": [reg(0, 1, 2, 3, 4, 5, 6), reg(1, 2, 3, 4, 5, 6, 7)],
+     "expected": [[0, 1, 2, 3, 4, 5, 6, 0, 1], [1, 2, 3, 4, 5, 6, 7, 0, 2]]},
+    # ---------------- processor/instructions/table.rs (Left) ----------------
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/table.rs:790-922 (test_trace_evaluation_processor_instruction_table_with_multiple_rows)",
+     "component": 7, "code_words": [PLUS],
+     "trace": [reg(0, 0, LEFT, PLUS, 4, 5, 6), reg(1, 1, PLUS, LEFT, 1, 2, 3), reg(2, 2, LEFT, MINUS, 4, 5, 6), reg(3, 3, MINUS, 0, 1, 2, 3)],
+     # (clk, ip, ci, ni, mp, mv, mvi, d, next_ip, next_mp, next_mv)
+     "expected": [[0, 0, LEFT, PLUS, 4, 5, 6, 0, 1, 1, 2], [2, 2, LEFT, MINUS, 4, 5, 6, 0, 3, 1, 2]]},
+    # ---------------- processor/instructions/jump/table.rs ----------------
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/jump/table.rs:759-822 (test_trace_evaluation_single_row_jump_table)",
+     "component": 4, "code_words": [PLUS],
+     "trace": [reg(1, 2, JNZ, 1, 5, 0, 0), reg(2, 3, 0, 0, 5, 0, 0)],
+     # (clk, ip, ci, ni, mp, mv, mvi, next_clk, next_ip, next_mp, next_mv, d, is_mv_zero)
+     "expected": [[1, 2, JNZ, 1, 5, 0, 0, 2, 3, 5, 0, 0, 1]]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/jump/table.rs:825-978 (test_trace_evaluation_jump_table_with_multiple_rows: all 13 columns)",
+     "component": 4, "code_words": [PLUS],
+     "trace": [reg(11, 12, JNZ, 7, 0, 1, 1), reg(12, 7, RIGHT, PLUS, 0, 1, 1), reg(17, 12, JNZ, 7, 0, 0, 0), reg(18, 14, 0, 0, 0, 0, 0)],
+     "expected": [[11, 12, JNZ, 7, 0, 1, 1, 12, 7, 0, 1, 0, 0], [17, 12, JNZ, 7, 0, 0, 0, 18, 14, 0, 0, 0, 1]]},
+    # ---------------- end_of_execution/table.rs ----------------
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/end_of_execution/table.rs:394-427 (test_trace_evaluation_single_row_end_of_execution_table)",
+     "component": 12, "code_words": [PLUS],
+     "trace": [reg(clk=1, ip=2)],
+     "expected": [[1, 2, 0, 0, 0, 0, 0]]},
+]
+
+# Error paths of the table builders (TraceError, crates/brainfuck_prover/src/components/mod.rs): what the builders must refuse.
+TABLE_ERRORS = [
+    {"cite": "memory/table.rs:749-755 (test_empty_trace_evaluation)", "component": 0, "code_words": [PLUS], "trace": [], "error": "EmptyTrace"},
+    {"cite": "instruction/table.rs:596-608,806-812 (empty registers and program -> empty table -> EmptyTrace)", "component": 1, "code_words": [], "trace": [], "error": "EmptyTrace"},
+    {"cite": "program/table.rs:384-390 (test_trace_evaluation_empty_table)", "component": 2, "code_words": [], "trace": [], "error": "EmptyTrace"},
+    {"cite": "processor/table.rs:889-895 (test_trace_evaluation_empty_processor_table)", "component": 3, "code_words": [PLUS], "trace": [], "error": "EmptyTrace"},
+    {"cite": "end_of_execution/table.rs:373-378 (no row with ci = 0)", "component": 12, "code_words": [PLUS], "trace": [reg(0, 0, PLUS, 0, 0, 0, 0)], "error": "InvalidEndOfExecution"},
+    {"cite": "end_of_execution/table.rs:381-391 (two rows with ci = 0)", "component": 12, "code_words": [PLUS], "trace": [reg(0, 0, 0, 0, 0, 0, 0), reg(1, 1, 0, 0, 0, 0, 0)],
+     "error": "InvalidEndOfExecution"},
+    {"cite": "jump/table.rs:191-193 (a jump row pairs a real entry with a dummy one: both entries must share d)", "component": 4, "code_words": [PLUS],
+     "trace": None, "error": None},     # placeholder removed below: not reachable from a register trace (pairs are pushed together)
+]
+TABLE_ERRORS = [e for e in TABLE_ERRORS if e["error"]]
+
+# logUp structure of the 7 interaction-trace tests: per table row the numerator the reference writes (write_frac) and which main columns
+# enter the denominator `combine` (in that order), per logUp column. Evaluated under LookupElements::dummy() (z = 1, all alpha powers 1).
+#   rows: explicit main-table rows, or code/input (the table the component builds from the executed program)
+LOGUP_STRUCTURE = [
+    {"cite": "crates/brainfuck_prover/src/components/memory/table.rs:811-878 (test_interaction_trace_evaluation)",
+     "component": 0, "rows": mem_rows([[0, 0, 0, 0], [1, 1, 0, 1], [2, 1, 0, 0], [3, 1, 0, 1]]),
+     "columns": [{"denominator_columns": [0, 1, 2], "numerators": [-1, 0, -1, 0]}]},
+    {"cite": "crates/brainfuck_prover/src/components/instruction/table.rs:983-1054 (test_interaction_trace_evaluation, program '+->[-]')",
+     "component": 1, "code": "+->[-]", "input": [],
+     "columns": [{"denominator_columns": [0, 1, 2], "numerators": [-1] * 13 + [0] * 3}]},
+    {"cite": "crates/brainfuck_prover/src/components/program/table.rs:587-647 (test_interaction_trace_evaluation, program '+->[-]')",
+     "component": 2, "code": "+->[-]", "input": [],
+     "columns": [{"denominator_columns": [0, 1, 2], "numerators": [1] * 8}]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/table.rs:1070-1178 (test_interaction_trace_evaluation, program '+,.' input 1): three logUp columns in "
+             "the order Processor(clk, ip, ci, ni, mp, mv, mvi), Instruction(ip, ci, ni), Memory(clk, mp, mv)",
+     "component": 3, "code": "+,.", "input": [1],
+     "columns": [{"denominator_columns": [0, 1, 2, 3, 4, 5, 6], "numerators": [1, 1, 1, 1]},
+                 {"denominator_columns": [1, 2, 3], "numerators": [1, 1, 1, 1]},
+                 {"denominator_columns": [0, 4, 5], "numerators": [1, 1, 1, 1]}]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/table.rs:924-1000 (test_interaction_trace_evaluation, Left table of '+>>><,<.<' input 1)",
+     "component": 7, "code": "+>>><,<.<", "input": [1],
+     "columns": [{"denominator_columns": [0, 1, 2, 3, 4, 5, 6], "numerators": [-1, -1, -1, 0]}]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/jump/table.rs:980-1052 (test_interaction_trace_evaluation, JumpIfNotZero table of '++>,<[>+.<-]' input 1)",
+     "component": 4, "code": "++>,<[>+.<-]", "input": [1],
+     "columns": [{"denominator_columns": [0, 1, 2, 3, 4, 5, 6], "numerators": [-1, -1]}]},
+    {"cite": "crates/brainfuck_prover/src/components/processor/instructions/end_of_execution/table.rs:431-502 (test_interaction_trace_evaluation, '+>>><,<.<' input 1)",
+     "component": 12, "code": "+>>><,<.<", "input": [1],
+     "columns": [{"denominator_columns": [0, 1, 2, 3, 4, 5, 6], "numerators": [-1]}]},
+]
+
 vectors = {
     "compile": [  # crates/brainfuck_vm/src/compiler.rs:62-79
         {"code": "++>,<[>+.<-]", "expected": [43, 43, 62, 44, 60, 91, 13, 62, 43, 46, 60, 45, 93, 7]},
@@ -86,7 +212,9 @@ vectors = {
          "component": 12, "code": "+>,<[>+.<-]", "input": [1],
          # (clk, ip, ci, ni, mp, mv, mvi)
          "expected": [[11, 13, 0, 0, 0, 0, 0]]},
-    ],
+    ] + TABLES_R3,
+    "table_errors": TABLE_ERRORS,
+    "logup_structure": LOGUP_STRUCTURE,
     # component log sizes measured for the bundled programs — SURVEY.md Appendix A.3 (derived from the reference's padding rules)
     "log_sizes": [
         {"program": "hello_kakarot.bf", "input": [], "steps": 651, "expected": [17, 14, 12, 14, 8, 4, 4, 10, 10, 9, 13, 11, 4]},

@@ -159,3 +159,69 @@ def test_host_entries_survive_null_and_invalid_arguments():
         assert r.returncode == 0, (name, r.returncode, r.stderr[-300:])
         if name in expect:
             assert int(r.stdout.strip().splitlines()[-1]) == expect[name], (name, r.stdout)
+
+
+def test_rccl_exchange_bookkeeping_through_a_mock_library(tmp_path):
+    """RcclComm::exchange (comm.hip) driven through a test double of the 10 RCCL entry points (tests/mock_rccl.c, ranks = threads, host
+    buffers): real ncclSend/ncclRecv need one GPU per rank, which no test box has. Checks what the transport itself is responsible for —
+    blocks to oneself (copied, matched in order), zero-byte blocks (skipped on both sides), several blocks per peer (order kept), the
+    counters — and that a size mismatch between a send and its receive is an ERROR on the ranks involved, not a hang."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mock = tmp_path / "libmock_rccl.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-o", str(mock), os.path.join(root, "tests", "mock_rccl.c"), "-lpthread"])
+    prog = textwrap.dedent("""
+        import ctypes, sys, threading
+        import numpy as np
+        sys.path.insert(0, %r)
+        from conftest import load_package
+        L = load_package().lib()
+        N = 4
+        uid = (ctypes.c_uint8 * 128)()
+        assert L.bfhip_rccl_unique_id(uid) == 0
+
+        def blocks(src, dst, bad):
+            # what rank src sends to rank dst, in order: (words, fill); a zero-byte block sits in the middle
+            out = [(5 + src, 100 * src + dst), (0, 0), (3, 1000 + 10 * src + dst), (7 + dst, 7)]
+            if bad and (src, dst) == (1, 2):
+                out[2] = (4, out[2][1])            # rank 1 announces 4 words where rank 2 expects 3
+            return out
+
+        def run(rank, bad, res):
+            sends, recvs, keep, want = [], [], [], []
+            for peer in range(N):
+                for words, fill in blocks(rank, peer, bad):
+                    a = np.full(words, fill, dtype=np.uint32); keep.append(a)
+                    sends.append((peer, a))
+                for words, fill in blocks(peer, rank, False):
+                    a = np.zeros(words, dtype=np.uint32); keep.append(a)
+                    recvs.append((peer, a)); want.append(np.full(words, fill, dtype=np.uint32))
+            def pack(lst):
+                n = len(lst)
+                return (n, (ctypes.c_uint32 * n)(*[p for p, _ in lst]), (ctypes.c_void_p * n)(*[a.ctypes.data for _, a in lst]), (ctypes.c_size_t * n)(*[a.nbytes for _, a in lst]))
+            stats = (ctypes.c_uint64 * 4)()
+            rc = L.bfhip_rccl_exchange_raw(uid, rank, N, *pack(sends), *pack(recvs), stats)
+            ok = rc == 0 and all(np.array_equal(a, w) for (_, a), w in zip(recvs, want))
+            sent = sum(a.nbytes for p, a in sends if p != rank)
+            res[rank] = (rc, ok, list(stats), sent, L.bfhip_last_error().decode() if rc else "")
+
+        for bad in (False, True):
+            res = [None] * N
+            th = [threading.Thread(target=run, args=(r, bad, res)) for r in range(N)]
+            [t.start() for t in th]; [t.join(60) for t in th]
+            assert not any(t.is_alive() for t in th), "a rank hangs"
+            if not bad:
+                for r in range(N):
+                    rc, ok, stats, sent, err = res[r]
+                    assert rc == 0 and ok, (r, res[r])
+                    assert stats == [0, 0, 1, sent], (r, stats, sent)
+            else:
+                assert res[2][0] != 0 and "RCCL" in res[2][4] or "invalid usage" in res[2][4], res[2]      # the receiver of the wrong size
+                assert res[0][0] == 0 and res[0][1]                                                          # an uninvolved rank is unaffected
+            if not bad:
+                uid = (ctypes.c_uint8 * 128)(); assert L.bfhip_rccl_unique_id(uid) == 0     # a fresh group for the failing round
+        print("ok")
+    """) % os.path.join(root, "tests")
+    env = dict(os.environ, BFHIP_RCCL_LIBRARY=str(mock))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]

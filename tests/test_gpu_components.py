@@ -146,3 +146,28 @@ def test_per_component_ops_reject_bad_arguments(ctx, pkg):
         ctx.logup_generate(0, 3, [0] * 8, [1] * 24, [0] * 4)
     with pytest.raises(pkg.BfhipError, match="twiddle tree"):
         ctx.eval_constraints(0, ctx.max_log_domain, 0, [0] * 8, [0] * 4, [1] * 24, [0] * 4, [0] * 48, [0] * 4)
+
+
+def _structure_vectors():
+    import json, os
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.json")))
+    return v["logup_structure"]
+
+
+@pytest.mark.parametrize("v", _structure_vectors(), ids=lambda v: f"component{v['component']}")
+def test_logup_structure_of_the_reference_interaction_tests(ctx, oracle, v):
+    """bfhip_logup_generate on the tables of the reference's 7 interaction-trace tests under LookupElements::dummy(): numerators,
+    denominator columns and their order (3 logUp columns for the processor) exactly as those tests write them — expected values from the
+    plain-Python LogupTraceGenerator of tests/conftest.py, not from the oracle."""
+    from conftest import logup_expected_dummy_elements
+    rows = np.array(v["rows"], dtype=np.uint32) if "rows" in v else oracle.table(v["code"], bytes(v["input"]), v["component"])
+    assert rows.shape[0] == len(v["columns"][0]["numerators"])
+    want, want_claimed = logup_expected_dummy_elements(rows.tolist(), v["columns"])
+    got, claimed = _logup_gpu(ctx, v["component"], np.ascontiguousarray(rows.T), [1, 0, 0, 0] * 6)
+    assert list(claimed) == [want_claimed, 0, 0, 0]
+    n_rep = len(got) - 4
+    for k in range(len(want) - 1):                      # non-last logUp columns come back row-granular, coordinate 0 first
+        assert np.array_equal(np.repeat(got[4 * k], 16), np.array(want[k], dtype=np.uint32)), f"logUp column {k}"
+        assert not any(g.any() for g in got[4 * k + 1: 4 * k + 4])
+    assert np.array_equal(got[n_rep], np.array(want[-1], dtype=np.uint32))
+    assert not any(g.any() for g in got[n_rep + 1:])

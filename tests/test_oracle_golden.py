@@ -113,6 +113,54 @@ def test_tables_golden(oracle, host, v):
     assert np.array_equal(host.table(trace, code_words, v["component"]), want)
 
 
+@pytest.mark.parametrize("v", V["table_errors"], ids=lambda v: f"component{v['component']}:{v['error']}")
+def test_table_error_paths(oracle, host, v):
+    """TraceError::EmptyTrace / InvalidEndOfExecution (the reference's empty-table and end-of-execution tests): both builders refuse."""
+    trace = np.ascontiguousarray(v["trace"], dtype=np.uint32).reshape(-1, 7)
+    cw = np.ascontiguousarray(v["code_words"], dtype=np.uint32)
+    nr, nc = ctypes.c_size_t(), ctypes.c_size_t()
+    args = (trace.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(trace.shape[0]), cw.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cw.size), v["component"])
+    assert oracle.L.orc_table_from_registers(*args, None, ctypes.c_size_t(0), ctypes.byref(nr), ctypes.byref(nc)) != 0
+    assert v["error"] in oracle.L.orc_last_error().decode()
+    assert host.L.bfhip_host_table(*args, None, ctypes.c_size_t(0), ctypes.byref(nr), ctypes.byref(nc)) != 0
+    assert v["error"] in host.L.bfhip_last_error().decode()
+
+
+def _logup_rows(oracle, v):
+    if "rows" in v:
+        return np.array(v["rows"], dtype=np.uint32)
+    return oracle.table(v["code"], bytes(v["input"]), v["component"])
+
+
+DUMMY_ELEMENTS = [1, 0, 0, 0] * 6        # LookupElements::dummy(): z = 1, alpha = 1 for the three relations
+
+
+@pytest.mark.parametrize("v", V["logup_structure"], ids=lambda v: f"component{v['component']}")
+def test_logup_structure_of_the_reference_interaction_tests(oracle, v):
+    """The 7 interaction-trace tests of the reference list, row by row, the numerator and the denominator columns each component writes
+    (under LookupElements::dummy()). The oracle's logUp generation on the same table must produce exactly the columns and the claimed sum
+    that a plain Python LogupTraceGenerator makes of that list."""
+    from conftest import logup_expected_dummy_elements
+    rows = _logup_rows(oracle, v)
+    assert rows.shape[0] == len(v["columns"][0]["numerators"]), "row count of the table differs from the reference test's"
+    want, want_claimed = logup_expected_dummy_elements(rows.tolist(), v["columns"])
+    got, claimed = oracle.logup_generate(v["component"], np.ascontiguousarray(rows.T), DUMMY_ELEMENTS)
+    assert list(claimed) == [want_claimed, 0, 0, 0]
+    for k, col in enumerate(want):
+        assert np.array_equal(got[4 * k], np.array(col, dtype=np.uint32)), f"logUp column {k}"
+        assert not got[4 * k + 1: 4 * k + 4].any()
+
+
+def test_memory_dummy_entries_do_not_change_the_claimed_sum(oracle):
+    """memory/table.rs:886-929 (test_interaction_trace_evaluation_dummy_entries_effect): the clk-gap and padding dummies (d = 1) contribute
+    numerator 0 — the claimed sum of the table with them equals the claimed sum of the real entries alone."""
+    with_dummies = [[0, 43, 91, 0, 1, 43, 91, 1], [1, 43, 91, 1, 2, 91, 9, 0], [2, 91, 9, 0, 2, 91, 9, 1], [2, 91, 9, 1, 3, 91, 9, 1]]
+    real_only = [[0, 43, 91, 0, 2, 91, 9, 0], [2, 91, 9, 0, 3, 91, 9, 1]]
+    a = oracle.logup_generate(0, np.ascontiguousarray(np.array(with_dummies, dtype=np.uint32).T), DUMMY_ELEMENTS)[1]
+    b = oracle.logup_generate(0, np.ascontiguousarray(np.array(real_only, dtype=np.uint32).T), DUMMY_ELEMENTS)[1]
+    assert list(a) == list(b)
+
+
 @pytest.mark.parametrize("name,inp", [("hello_kakarot.bf", b""), ("collatz.bf", b"7\n"), ("a-bc.bf", b"a"), ("loop.bf", b"")])
 def test_host_tables_equal_oracle_tables(oracle, host, name, inp):
     code = prog(name)
