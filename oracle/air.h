@@ -278,7 +278,7 @@ struct PointEvaluator : EvalBase<PointEvaluator, QM31> {
 // mirroring memory/component.rs:163-209 and plus_component.rs:145-190).
 struct AssertEvaluator : EvalBase<AssertEvaluator, M31> {
     const u32* is_first_col; const u32* const* trace_cols; const u32* const* inter_cols;
-    size_t row; u32 log_size; int ti = 0, ii = 0, ci = 0; int failed = -1;
+    size_t row; u32 log_size; int ti = 0, ii = 0, ci = 0; int failed = -1; QM31 failed_value = QM31::zero();
     M31 is_first_mask() { return M31(is_first_col[row]); }
     M31 next_trace_mask() { return M31(trace_cols[ti++][row]); }
     QM31 rd(size_t r) { return QM31::from_u32(inter_cols[ii][r], inter_cols[ii + 1][r], inter_cols[ii + 2][r], inter_cols[ii + 3][r]); }
@@ -292,8 +292,8 @@ struct AssertEvaluator : EvalBase<AssertEvaluator, M31> {
         size_t pr = bit_reverse_index((u32)coset_index_to_circle_domain_index(pc, log_size), log_size);
         c = rd(row); p = rd(pr); ii += 4;
     }
-    void add_constraint(M31 c) { if (!c.is_zero() && failed < 0) failed = ci; ci++; }
-    void add_constraint(QM31 c) { if (!c.is_zero() && failed < 0) failed = ci; ci++; }
+    void add_constraint(M31 c) { if (!c.is_zero() && failed < 0) { failed = ci; failed_value = QM31(c); } ci++; }
+    void add_constraint(QM31 c) { if (!c.is_zero() && failed < 0) { failed = ci; failed_value = c; } ci++; }
     M31 cst(u32 k) { return M31(k); }
 };
 

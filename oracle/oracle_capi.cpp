@@ -283,6 +283,39 @@ int orc_assert_constraints(const char* code, const u8* input, size_t n_in, int c
     ORC_CATCH
 }
 
+// The same check on a caller-supplied table (rows: n_main row-granular columns of n_rows values, column-major) — the reference's negative AIR
+// tests patch single cells of a built table (memory/component.rs:211-609). value4 receives the first failing constraint's value.
+int orc_assert_constraints_table(int component, const u32* rows, size_t n_rows, const u32* elems24, size_t* bad_row, int* bad_constraint, u32 value4[4]) {
+    ORC_TRY
+    Table t; t.init(N_MAIN_COLS[component], n_rows);
+    for (size_t c = 0; c < t.cols.size(); c++) memcpy(t.cols[c].data(), rows + c * n_rows, n_rows * sizeof(u32));
+    InteractionElements el;
+    auto q = [&](int i) { return QM31::from_u32(elems24[4 * i], elems24[4 * i + 1], elems24[4 * i + 2], elems24[4 * i + 3]); };
+    el.memory = LookupElements::make(q(0), q(1)); el.instruction = LookupElements::make(q(2), q(3)); el.processor = LookupElements::make(q(4), q(5));
+    u32 log = t.log_size();
+    std::vector<std::vector<u32>> main_cols;
+    for (auto& c : t.cols) main_cols.push_back(broadcast16(c));
+    QM31 claimed;
+    auto inter = gen_interaction_trace(component, t, el, &claimed);
+    std::vector<u32> isf(size_t(1) << log, 0); isf[0] = 1;
+    std::vector<const u32*> tc, ic;
+    for (auto& c : main_cols) tc.push_back(c.data());
+    for (auto& c : inter) ic.push_back(c.data());
+    for (size_t row = 0; row < (size_t(1) << log); row++) {
+        AssertEvaluator ae;
+        ae.is_first_col = isf.data(); ae.trace_cols = tc.data(); ae.inter_cols = ic.data(); ae.row = row; ae.log_size = log; ae.total_sum = claimed;
+        eval_component(component, ae, el);
+        if (ae.failed >= 0) {
+            if (bad_row) *bad_row = row;
+            if (bad_constraint) *bad_constraint = ae.failed;
+            if (value4) { auto v = ae.failed_value.to_u32(); for (int k = 0; k < 4; k++) value4[k] = v[k]; }
+            return 1;
+        }
+    }
+    return 0;
+    ORC_CATCH
+}
+
 // ---- per-component operations on caller-supplied columns (checkers for the bfhip per-component C ABI) -------------------------
 static InteractionElements elements_from(const u32* e) {
     auto q = [&](int i) { return QM31::from_u32(e[4 * i], e[4 * i + 1], e[4 * i + 2], e[4 * i + 3]); };

@@ -116,6 +116,14 @@ class Oracle:
         rc = self._chk(self.L.orc_assert_constraints(code.encode(), inp, ctypes.c_size_t(len(inp)), component, e, cc, ctypes.c_size_t(cr), ctypes.c_uint32(cv), ctypes.byref(bad_row), ctypes.byref(bad_c)))
         return rc, bad_row.value, bad_c.value
 
+    def assert_constraints_table(self, component, rows, elems):
+        """rows: (n_rows, n_main) table rows. Returns (rc, first failing storage row, constraint index, value[4])."""
+        cols = np.ascontiguousarray(np.asarray(rows, dtype=np.uint32).T)
+        bad_row, bad_c, val = ctypes.c_size_t(), ctypes.c_int(-1), (ctypes.c_uint32 * 4)()
+        rc = self._chk(self.L.orc_assert_constraints_table(component, cols.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(cols.shape[1]), (ctypes.c_uint32 * 24)(*elems),
+                                                            ctypes.byref(bad_row), ctypes.byref(bad_c), val))
+        return rc, bad_row.value, bad_c.value, list(val)
+
     def prove(self, code: str, inp: bytes = b"", log_max_rows=20):
         js, n, tr, sec = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_void_p(), ctypes.c_double()
         self._chk(self.L.orc_prove(code.encode(), inp, ctypes.c_size_t(len(inp)), log_max_rows, ctypes.byref(js), ctypes.byref(n), ctypes.byref(tr), ctypes.byref(sec)))

@@ -116,6 +116,38 @@ TABLES_R3 = [
      "expected": [[1, 2, 0, 0, 0, 0, 0]]},
 ]
 
+# The constructor-level tests (entry / row / add_entry literals), carried through the same builders: one register row per literal entry.
+TABLES_R3 += [
+    {"cite": "memory/table.rs:526-537,592-602 (test_memory_entry_new, test_add_entry: entry (0, 43, 91), d = 0) + pairing :121-151 with new_dummy :539-553 (d = 1)",
+     "component": 0, "code_words": [PLUS], "trace": [reg(clk=0, mp=43, mv=91)], "expected": mem_rows([[0, 43, 91, 0]])},
+    {"cite": "memory/table.rs:623-635 (test_add_multiple_entries literals) through sort :249-251, pad :291-303, pairing",
+     "component": 0, "code_words": [PLUS], "trace": [reg(clk=0, mp=43, mv=91), reg(clk=1, mp=91, mv=9), reg(clk=43, mp=62, mv=43)],
+     "expected": mem_rows([[0, 43, 91, 0], [43, 62, 43, 0], [1, 91, 9, 0], [2, 91, 9, 1]])},
+    {"cite": "instruction/table.rs:511-524,526-538 (test_new_instruction_entry (1, 43, 45) d = 0; new_dummy(ip): ci = ni = 0, d = 1) + pairing :116-145",
+     "component": 1, "code_words": [], "trace": [reg(ip=1, ci=43, ni=45)], "expected": [[1, 43, 45, 0, 1, 0, 0, 1]]},
+    {"cite": "instruction/table.rs:561-575 (test_add_entry literal (0, 43, 91)) + pairing",
+     "component": 1, "code_words": [], "trace": [reg(ip=0, ci=43, ni=91)], "expected": [[0, 43, 91, 0, 0, 0, 0, 1]]},
+    {"cite": "instruction/table.rs:577-594 (test_add_multiple_entries literals) through pad :239-248 and pairing",
+     "component": 1, "code_words": [], "trace": [reg(clk=0, ip=0, ci=43, ni=91), reg(clk=1, ip=1, ci=91, ni=9), reg(clk=2, ip=2, ci=62, ni=43)],
+     "expected": [[0, 43, 91, 0, 1, 91, 9, 0], [1, 91, 9, 0, 2, 62, 43, 0], [2, 62, 43, 0, 2, 0, 0, 1], [2, 0, 0, 1, 2, 0, 0, 1]]},
+    {"cite": "program/table.rs:278-292,315-328 (test_row_new / test_table_add_row: row (0, PutChar, 91), d = 0) as the first row of the program [PutChar, 91]",
+     "component": 2, "code_words": [PUTC, 91], "trace": [reg()], "expected": [[0, PUTC, 91, 0], [1, 91, 0, 0]]},
+    {"cite": "processor/table.rs:544-569 (test_processor_table_entry_from_registers) + row :571-600 with the builder's dummy (last.clk + 1, last.ip)",
+     "component": 3, "code_words": [PLUS], "trace": [reg(1, 5, 43, 91, 2, 7, 0)], "expected": [[1, 5, 43, 91, 2, 7, 0, 0, 2]]},
+    {"cite": "processor/table.rs:616-633 (test_add_entry literal)",
+     "component": 3, "code_words": [PLUS], "trace": [reg(10, 15, 43, 91, 20, 25, 1)], "expected": [[10, 15, 43, 91, 20, 25, 1, 0, 11]]},
+    {"cite": "processor/table.rs:635-676 (test_add_multiple_entries literals) through pad :241-253 and pairing :117-145",
+     "component": 3, "code_words": [PLUS], "trace": [reg(1, 5, 43, 91, 10, 15, 0), reg(2, 6, 44, 92, 11, 16, 1), reg(3, 7, 45, 93, 12, 17, 0)],
+     "expected": [[1, 5, 43, 91, 10, 15, 0, 0, 2], [2, 6, 44, 92, 11, 16, 1, 0, 3], [3, 7, 45, 93, 12, 17, 0, 0, 4], [4, 7, 0, 0, 0, 0, 0, 1, 5]]},
+    {"cite": "processor/instructions/table.rs:518-575 (test_processor_instruction_table_entry_from_registers / _row: entry (1, 5, '+', 91, 2, 7, 0) paired with a dummy of the "
+             "same ip: next_ip = 5, next_mp = next_mv = 0) — the Plus table, whose opcode the literal carries",
+     "component": 10, "code_words": [PLUS], "trace": [reg(1, 5, PLUS, 91, 2, 7, 0), reg(2, 5, 0, 0, 0, 0, 0)],
+     "expected": [[1, 5, PLUS, 91, 2, 7, 0, 0, 5, 0, 0]]},
+    {"cite": "end_of_execution/table.rs:318-336 (test_add_row literal: (10, 15, 0, 91, 20, 25, 1)) — the row with ci = 0 is the table",
+     "component": 12, "code_words": [PLUS], "trace": [reg(9, 14, PLUS, 0, 20, 24, 1), reg(10, 15, 0, 91, 20, 25, 1)],
+     "expected": [[10, 15, 0, 91, 20, 25, 1]]},
+]
+
 # Error paths of the table builders (TraceError, crates/brainfuck_prover/src/components/mod.rs): what the builders must refuse.
 TABLE_ERRORS = [
     {"cite": "memory/table.rs:749-755 (test_empty_trace_evaluation)", "component": 0, "code_words": [PLUS], "trace": [], "error": "EmptyTrace"},
@@ -129,6 +161,29 @@ TABLE_ERRORS = [
      "trace": None, "error": None},     # placeholder removed below: not reachable from a register trace (pairs are pushed together)
 ]
 TABLE_ERRORS = [e for e in TABLE_ERRORS if e["error"]]
+
+# The 10 negative AIR tests of the Memory component (memory/component.rs:211-609): a table built from registers, single cells patched, and the
+# row / value stwo's assert_constraints reports ("row: r, left: (v + 0i) + (0 + 0i)u"): row r of the trace domain in natural order = table row r
+# (its first SIMD lane), v = the first constraint that does not vanish there. `constraint` = its index in MemoryEval::evaluate's order
+# (memory/component.rs:81-121). Main columns: clk, mp, mv, d, next_clk, next_mp, next_mv, next_d.
+AIR_NEGATIVE = [
+    {"cite": "memory/component.rs:215-252 (test_invalid_boundary_clk)", "component": 0, "trace": [reg(clk=1)], "patch": [], "table_row": 0, "value": 1, "constraint": 0},
+    {"cite": "memory/component.rs:255-289 (test_invalid_boundary_mp)", "component": 0, "trace": [reg(mp=1)], "patch": [], "table_row": 0, "value": 1, "constraint": 1},
+    {"cite": "memory/component.rs:292-326 (test_invalid_boundary_mv)", "component": 0, "trace": [reg(mv=1)], "patch": [], "table_row": 0, "value": 1, "constraint": 2},
+    {"cite": "memory/component.rs:329-365 (test_invalid_boundary_d: table[0].d = 1)", "component": 0, "trace": [reg()], "patch": [[0, 3, 1]], "table_row": 0, "value": 1, "constraint": 3},
+    {"cite": "memory/component.rs:368-403 (test_invalid_transition_mp_increase: mp jumps by 2)", "component": 0, "trace": [reg(), reg(mp=2)], "patch": [],
+     "table_row": 0, "value": 2, "constraint": 6},
+    {"cite": "memory/component.rs:406-441 (test_invalid_transition_clk_increase: same mp, clk not increased)", "component": 0, "trace": [reg(), reg()], "patch": [],
+     "table_row": 0, "value": 1, "constraint": 7},
+    {"cite": "memory/component.rs:444-482 (test_invalid_transition_mp_increase_next_mv: mp + 1 but next_mv != 0)", "component": 0, "trace": [reg(), reg(mp=1, mv=1)], "patch": [],
+     "table_row": 0, "value": 1, "constraint": 8},
+    {"cite": "memory/component.rs:485-522 (test_invalid_transition_next_dummy: table[0].next_d = 2)", "component": 0, "trace": [reg(), reg(mp=1)], "patch": [[0, 7, 2]],
+     "table_row": 0, "value": 2, "constraint": 5},
+    {"cite": "memory/component.rs:525-565 (test_invalid_transition_d_mp: table[1].d = 1, table[1].next_mp = 2)", "component": 0, "trace": [reg(), reg(mp=1)],
+     "patch": [[1, 3, 1], [1, 5, 2]], "table_row": 1, "value": 1, "constraint": 9},
+    {"cite": "memory/component.rs:570-609 (test_invalid_transition_d_mv: table[1].d = 1, table[1].next_mv = 1)", "component": 0, "trace": [reg(), reg(mp=1)],
+     "patch": [[1, 3, 1], [1, 6, 1]], "table_row": 1, "value": 1, "constraint": 10},
+]
 
 # logUp structure of the 7 interaction-trace tests: per table row the numerator the reference writes (write_frac) and which main columns
 # enter the denominator `combine` (in that order), per logUp column. Evaluated under LookupElements::dummy() (z = 1, all alpha powers 1).
@@ -215,6 +270,7 @@ vectors = {
     ] + TABLES_R3,
     "table_errors": TABLE_ERRORS,
     "logup_structure": LOGUP_STRUCTURE,
+    "air_negative": AIR_NEGATIVE,
     # component log sizes measured for the bundled programs — SURVEY.md Appendix A.3 (derived from the reference's padding rules)
     "log_sizes": [
         {"program": "hello_kakarot.bf", "input": [], "steps": 651, "expected": [17, 14, 12, 14, 8, 4, 4, 10, 10, 9, 13, 11, 4]},

@@ -151,6 +151,20 @@ def test_logup_structure_of_the_reference_interaction_tests(oracle, v):
         assert not got[4 * k + 1: 4 * k + 4].any()
 
 
+@pytest.mark.parametrize("v", V["air_negative"], ids=lambda v: v["cite"].split("(")[1].split(":")[0].split(")")[0])
+def test_air_negative_cases_of_the_reference(oracle, host, v):
+    """The Memory component's 10 negative AIR tests: same registers, same patched cells; the first constraint that fails is the one the test
+    is named after, at the table row and with the value the reference's panic message quotes. Both table builders produce the table."""
+    elems = [5, 1, 2, 3, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83]      # drawn elements (dummy ones give a zero denominator)
+    rows = oracle_table_from_registers(oracle, v["trace"], [43], v["component"])
+    assert np.array_equal(rows, host.table(v["trace"], [43], v["component"]))
+    for r, c, val in v["patch"]:
+        rows[r, c] = val
+    rc, bad_row, bad_c, value = oracle.assert_constraints_table(v["component"], rows, elems)
+    assert rc == 1
+    assert bad_row // 16 == v["table_row"] and bad_c == v["constraint"] and value == [v["value"], 0, 0, 0], (bad_row, bad_c, value)
+
+
 def test_memory_dummy_entries_do_not_change_the_claimed_sum(oracle):
     """memory/table.rs:886-929 (test_interaction_trace_evaluation_dummy_entries_effect): the clk-gap and padding dummies (d = 1) contribute
     numerator 0 — the claimed sum of the table with them equals the claimed sum of the real entries alone."""
