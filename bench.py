@@ -134,6 +134,34 @@ def profile_report(lib, ctx):
     return rep
 
 
+def point_roofline(pkg, c, tr, lmr, sec_per_proof):
+    """The metric's own size (BASELINE 'at 2^22 rows'): kernel-time split, GPU-busy fraction and the dominant kernel's roofline of that proof, from
+    two extra untimed proofs — one with the dominant kernel bracketed by HIP events per run of launches (as in the timed region of the main
+    workload), one with every kernel bracketed (time split; the event pairs themselves stretch small proofs, so the busy fraction is the sum of
+    the kernel times over the UN-instrumented wall time and is an upper estimate when streams overlap)."""
+    lib = pkg.lib()
+    lib.bfhip_profile_enable(c._h, 2); lib.bfhip_profile_reset(c._h)
+    tr.prove(lmr, want_json=False); c.sync()
+    dom = profile_report(lib, c)
+    lib.bfhip_profile_enable(c._h, 1); lib.bfhip_profile_reset(c._h)
+    tr.prove(lmr, want_json=False); c.sync()
+    full = profile_report(lib, c)
+    lib.bfhip_profile_enable(c._h, 0)
+    out = {"kernels_ms_per_proof_instrumented": {k: round(v["total_ms"], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1]["total_ms"])}}
+    tot = sum(v["total_ms"] for v in full.values())
+    out["sum_of_kernel_ms"] = round(tot, 3)
+    out["gpu_busy_frac_estimate"] = round(min(1.0, tot / (sec_per_proof * 1e3)), 3)
+    d = dom.get("k_merkle_layer")
+    if d and d.get("units", 0) > 0 and d["total_ms"] > 0:
+        tops = d["units"] * VALU_OPS_PER_COMPRESSION / (d["total_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_merkle_layer", "bound": "valu", "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tops/s (int32 VALU lane-ops)",
+                           "frac": round(tops / VALU_PEAK_TOPS, 4), "launches": d["calls"], "avg_launch_us": round(d["total_ms"] / d["calls"] * 1e3, 2),
+                           "compressions_per_proof": round(d["units"]), "kernel_ms_per_proof": round(d["total_ms"], 3),
+                           "share_of_proof": round(d["total_ms"] / (sec_per_proof * 1e3), 3),
+                           "hbm": {"achieved": round(d["bytes"] / d["total_ms"] / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["bytes"] / d["total_ms"] / 1e6 / HBM_PEAK_GBS, 4)}}
+    return out
+
+
 def run_sweep(pkg, device, steps, logs):
     """Synthetic padded traces of 2^k domain rows, k in `logs`: one context sized for the largest, LOG_MAX_ROWS = k per point."""
     out = []
@@ -151,8 +179,11 @@ def run_sweep(pkg, device, steps, logs):
                 c.sync()
                 dt = (time.perf_counter() - t0) / steps
                 ok, why = pkg.verify_brainfuck(proof, k)
-                out.append({"log_domain_rows": k, "log_max_rows": k, "vm_steps": tr.n_steps, "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 3),
-                            "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok)})
+                row = {"log_domain_rows": k, "log_max_rows": k, "vm_steps": tr.n_steps, "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 3),
+                       "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok)}
+                if k == 22:
+                    row.update(point_roofline(pkg, c, tr, k, dt))
+                out.append(row)
             finally:
                 tr.close()
     finally:
@@ -216,12 +247,15 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
                 for _ in range(warm):
                     trace.prove(lmr)
                 ctx.sync()
+                t_before = ctx.group_times()
                 gate.wait(timeout=600)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     proof, phases = trace.prove(lmr)
                 ctx.sync()
-                res[k] = (time.perf_counter() - t0, proof, phases, trace.cells, before, ctx.group_stats())
+                dt_k = time.perf_counter() - t0
+                t_after = ctx.group_times()
+                res[k] = (dt_k, proof, phases, trace.cells, before, ctx.group_stats(), {kk: (t_after[kk] - t_before[kk]) / steps for kk in t_after})
             except Exception as e:
                 errors.append(repr(e))
                 gate.abort()
@@ -236,12 +270,17 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
             flush()
             raise RuntimeError(row["error"])
         dt = max(r[0] for r in res) / steps
-        _, proof, phases, cells, before, after = res[0]
+        _, proof, phases, cells, before, after, comm_ms = res[0]
         row.update({"ms_per_proof": round(dt * 1e3, 3), "cells": cells, "cells_per_s": cells / dt, "steps": steps,
                     "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
                     "all_members_same_proof": all(r[1] == proof for r in res),
                     "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
-                    "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after}})
+                    "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after},
+                    # where a proof over several GPUs spends its time: GPU-side milliseconds inside the collectives (HIP-event pairs on the rank's
+                    # stream: includes waiting for the slowest peer), rank 0 and the maximum over the ranks; the rest of ms_per_proof is compute
+                    "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()},
+                    "comm_ms_per_proof_max_rank": {k: round(max(r[6][k] for r in res), 3) for k in comm_ms},
+                    "comm_share_of_proof": round(sum(comm_ms.values()) / (dt * 1e3), 3)})
         if is_rank0:
             row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
         if name == "fib19":
@@ -614,7 +653,8 @@ def main():
                        "component_log_sizes": trace.log_sizes, "parallelism": ("shard group: one proof over all ranks (column-sharded transforms, row-sharded Merkle/constraints/quotients/folds, RCCL)" if sharded else "replicas") if world > 1 else "single", "proofs_in_flight_per_gpu": args.inflight, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
                        "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()},
                        "headline_2^22": ({"cells_per_s": headline22["cells_per_s"], "ms_per_proof": headline22["ms_per_proof"], "cells": headline22["cells"],
-                                          "workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')"}
+                                          "workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')",
+                                          **{k2: headline22[k2] for k2 in ("roofline", "gpu_busy_frac_estimate", "sum_of_kernel_ms", "kernels_ms_per_proof_instrumented") if k2 in headline22}}
                                          if headline22 else None)},
             "roofline": roofline,
             "fft": fft,

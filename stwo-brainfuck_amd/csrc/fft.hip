@@ -448,6 +448,85 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(const PassArgs* __r
     }
 }
 
+// Strided pass of K = 8, 9 or 10 layers (2^20 .. 2^22-cell transforms in TWO passes: 12 contiguous + K strided, instead of 6..8 + 7 + 7):
+// 2^K rows of 2^CL cells (rows at stride 2^lo) staged in LDS — 32 KiB for K = 8, 64 KiB for K = 9 (128-byte rows) and K = 10 (64-byte rows) —
+// read and written with 16-byte accesses, 32 cells per lane. The layers run as radix-16 rounds over 4 row bits each (16 values per lane
+// in registers, lanes of a wave on consecutive cells: conflict-free LDS accesses); the last round covers the top 4 row bits and applies
+// only the layers the earlier rounds have not. At 8-10 layers such a pass is as much butterfly work as HBM time (fft.hip header).
+template <bool INV, class TW> __device__ __forceinline__ void radix16_range(u32 (&v)[16], int jl_lo, TW tw) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int jl = INV ? s : 3 - s;
+        if (jl >= jl_lo) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int e0 = ((b >> jl) << (jl + 1)) | (b & ((1 << jl) - 1));
+                bfly<INV>(v[e0], v[e0 | (1 << jl)], tw(jl, e0 >> (jl + 1)));
+            }
+        }
+    }
+}
+template <bool INV, int K, int CL>
+__global__ void __launch_bounds__((1 << (K + CL)) / 32) k_fft_stridedK(const PassArgs* __restrict__ groups, u32 ngroups) {
+    constexpr u32 C = 1u << CL, ROWS = 1u << K, CELLS = ROWS * C, NT = CELLS / 32;
+    constexpr int NR = (K + 3) / 4;                 // rounds
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
+    __shared__ __attribute__((aligned(16))) u32 s_val[CELLS];
+    __shared__ u32 s_tw[ROWS];
+    const u32 t = threadIdx.x, lo = a.lo, tile = bg.tile;
+    const u32 n_lhi_log = lo - CL;
+    const u32 H = tile >> n_lhi_log, Lhi = tile & ((1u << n_lhi_log) - 1);
+    const u32 base = (H << (lo + K)) | (Lhi << CL);
+    // twiddles: local layer j (global lo + j), entry q < 2^(K-1-j) at ROWS - (ROWS >> j) + q; global h = (H << (K-1-j)) + q
+    for (u32 e = t; e < ROWS - 1; e += NT) {
+        const u32 j = __clz(~(e << (32 - K)));
+        const u32 q = e - (ROWS - (ROWS >> j));
+        s_tw[e] = layer_table(a, lo + j)[(H << (K - 1 - j)) + q];
+    }
+    auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[ROWS - (ROWS >> layer) + idx]; };
+    const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
+    for (u32 col = col0; col < col1; col++) {
+        g_cu32p src = as_global(a.src[col]);
+        g_u32p dst = as_global(a.dst[col]);
+        __syncthreads();      // twiddles staged / the previous column's stores have read s_val
+#pragma unroll
+        for (u32 i = 0; i < 8; i++) {
+            const u32 idx = 4 * (t + NT * i), m = idx >> CL, l = idx & (C - 1);
+            const uint4 v = ld16_stream(src + ((base | (m << lo) | l) & a.src_mask));
+            *reinterpret_cast<uint4*>(&s_val[idx]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int r = INV ? rr : NR - 1 - rr;
+            // window of 4 row bits [b, b + 4); the last round is shifted down to the top 4 bits and skips the layers already done
+            const int b = (4 * r + 4 <= K) ? 4 * r : K - 4;
+            const int jl_lo = 4 * r - b;
+#pragma unroll
+            for (u32 g2 = 0; g2 < 2; g2++) {
+                const u32 id = t + NT * g2, l = id & (C - 1), rest = id >> CL;      // rest: the K - 4 row bits outside the window
+                const u32 rest_lo = rest & ((1u << b) - 1), rest_hi = rest >> b;
+                const u32 m0 = (rest_hi << (b + 4)) | rest_lo;
+                u32 v[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) v[e] = s_val[((m0 | ((u32)e << b)) << CL) | l];
+                radix16_range<INV>(v, jl_lo, [&](int jl, int pe) -> u32 { return TW(b + jl, (rest_hi << (3 - jl)) + pe); });
+#pragma unroll
+                for (int e = 0; e < 16; e++) s_val[((m0 | ((u32)e << b)) << CL) | l] = v[e];
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (u32 i = 0; i < 8; i++) {
+            const u32 idx = 4 * (t + NT * i), m = idx >> CL, l = idx & (C - 1);
+            uint4 v = *reinterpret_cast<uint4*>(&s_val[idx]);
+            if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+            st16(dst + (base | (m << lo) | l), v);
+        }
+    }
+}
+
 // Tiny transforms (log <= 5): one thread per column, straight loops over registers/local memory. Only the handful of
 // 16..32-cell columns of empty sub-component tables take this route.
 template <bool INV>
@@ -480,7 +559,7 @@ __global__ void k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
 // Host-side pass planner. Inverse: contiguous pass first then strided passes upward; forward: mirror image.
 // fft_plan lays out the passes of every job (one job = the columns of one size and storage); the pass a job executes pi-th goes into
 // the launch (pi, kernel kind), so a batch of jobs costs at most (passes of the largest job) x (kinds in use) launches.
-enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_KINDS = 5 };
+enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_STRIDED_K8 = 5, K_STRIDED_K9 = 6, K_STRIDED_K10 = 7, K_KINDS = 8 };
 
 void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, const u32* tw, const u32* itw, u32 tw_root_log) {
     plan.inverse = inverse; plan.groups.clear(); plan.launches.clear(); plan.d_groups = nullptr;
@@ -507,6 +586,10 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
         if (log >= 12 && nl >= 6) {
             u32 ns = nl > 12 ? (nl - 12 + 6) / 7 : 0;
             u32 k0 = nl - 7 * ns;
+            // 20..22 layers: 12 contiguous + ONE strided pass of 8..10 layers through LDS (two passes instead of three)
+            static const bool two_pass = [] { const char* v = getenv("BFHIP_FFT_TWO_PASS"); return !v || v[0] != '0'; }();
+            const u32 big_k = (two_pass && nl >= 20 && nl <= 22) ? nl - 12 : 0;
+            if (big_k) { ns = 1; k0 = 12; }
             int np = 1 + (int)ns;
             max_np = std::max(max_np, np);
             // profiler accounting: `bytes` = what this pass moves (4 B in + 4 B out per cell), `alg` = this pass's share of the transform's
@@ -530,6 +613,11 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
                     a.lo = 0; a.k = k0; a.tile_log = 12; a.grid_x = ntiles;
                     PassArgs b = a; b.block0 = gy;      // block0 temporarily holds the group's grid_y
                     items.push_back({pi, K_TILE12, b, bytes, alg});
+                } else if (big_k) {
+                    a.lo = 12; a.k = big_k;
+                    const u32 cl = big_k == 10 ? 4 : 5;                       // 64-byte rows at 10 layers (64 KiB of LDS), 128-byte rows otherwise
+                    PassArgs b = a; b.grid_x = 1u << (log - big_k - cl); b.block0 = gy;
+                    items.push_back({pi, big_k == 8 ? K_STRIDED_K8 : big_k == 9 ? K_STRIDED_K9 : K_STRIDED_K10, b, bytes, alg});
                 } else {
                     a.lo = k0 + 7 * (p - 1); a.k = 7;
 #ifndef BF_STRIDED_WIDE_MIN_LOG
@@ -614,6 +702,21 @@ void fft_run(hipStream_t stream, const FftPlan& plan) {
                 ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);
                 if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_strided7<false, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
+                break; }
+            case K_STRIDED_K8: {
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL((k_fft_stridedK<false, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
+                break; }
+            case K_STRIDED_K9: {
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL((k_fft_stridedK<false, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
+                break; }
+            case K_STRIDED_K10: {
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL((k_fft_stridedK<false, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
                 break; }
             case K_PASS: {
                 ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L.bytes, L.alg);

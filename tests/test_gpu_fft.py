@@ -23,7 +23,7 @@ def _roundtrip(ctx, oracle, log, ncols, seed):
         ctx.free(p)
 
 
-@pytest.mark.parametrize("log", [3, 4, 5, 6, 7, 9, 11, 12, 13, 14, 16, 19, 20])
+@pytest.mark.parametrize("log", [3, 4, 5, 6, 7, 9, 11, 12, 13, 14, 16, 19, 20, 21])
 def test_fft_matches_oracle(ctx, oracle, log):
     _roundtrip(ctx, oracle, log, 3 if log < 19 else 2, seed=log * 16)
 

@@ -39,6 +39,7 @@ def run(pkg, n, steps, lmr=24):
         times[r] = (time.perf_counter() - t0) / steps
         if group:
             stats[r] = ctxs[r].group_stats()
+            stats[r]["times_ms"] = ctxs[r].group_times()
     th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
     [t.start() for t in th]; [t.join() for t in th]
     for r in range(n):
@@ -61,7 +62,9 @@ def main():
         row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "identical_to_single": proof == ref,
                "rank0_phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in ph.items()}}
         if stats[0]:
-            per_proof = {k: v / (steps + 1) for k, v in stats[0].items()}
+            per_proof = {k: v / (steps + 1) for k, v in stats[0].items() if k != "times_ms"}
+            # GPU-side time inside the collectives, per proof (HIP-event pairs; on one shared GPU this includes waiting for the peers' kernels)
+            row["rank0_collective_ms_per_proof"] = {k: round(v / (steps + 1), 3) for k, v in stats[0]["times_ms"].items()}
             row["rank0_per_proof"] = {"all_gathers": per_proof["all_gathers"], "max_reduces": per_proof["max_reduces"], "exchanges": per_proof["exchanges"],
                                       "MB_sent": round(per_proof["bytes_sent"] / 1e6, 1)}
         out.append(row)
