@@ -591,8 +591,8 @@ def main():
                                "the 128 x 2^24 kernel run is tools/fft_roofline.py -> profiles/"}
                 roofline["all_kernels_ms_per_proof_instrumented"] = {k: round(v["total_ms"], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1]["total_ms"])}
                 # every Blake2s compression of the proof's trees, whichever kernel ran it (fixed by the protocol): k_merkle_layer + the
-                # multi-level kernels of the small end (k_merkle_subtree, k_merkle_top, k_fri_tail)
-                roofline["compressions_per_proof_all_merkle_kernels"] = round(sum(v.get("units", 0) for k, v in full.items() if k in ("k_merkle_layer", "k_merkle_subtree", "k_merkle_top", "k_fri_tail")))
+                # multi-level kernels of the small end (k_merkle_subtree, k_merkle_top, k_fri_layer, k_fri_tail)
+                roofline["compressions_per_proof_all_merkle_kernels"] = round(sum(v.get("units", 0) for k, v in full.items() if k in ("k_merkle_layer", "k_merkle_subtree", "k_merkle_top", "k_fri_tail", "k_fri_layer")))
 
     # ---- N = 1: throughput with two proofs in flight (one context + host thread each): the VALU-bound hashing of one proof overlaps the
     # HBM-bound transforms of the other. Reported beside `value`, never as it.

@@ -66,10 +66,10 @@ int32_t bfhip_device_count(void);
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
-/* Intra-proof overlap on the context's partner streams (events only, bytes unchanged). bit 1 (default on): the FRI first-layer tree is
- * hashed level by level behind the quotient launches (compute_fri_quotients inside mod.rs:732); bit 0 (default off — transforms and Blake2s
- * are both VALU-limited on gfx950 and slow each other down when they co-run; measured neutral): the Merkle layers of a tree's largest
- * columns are hashed while its smaller columns are still being transformed (tree_builder.commit, mod.rs:500,583,723). */
+/* Intra-proof overlap on the context's partner streams (events only, bytes unchanged); default 0 = off. bit 1: the FRI first-layer tree is
+ * hashed level by level behind the quotient launches (compute_fri_quotients inside mod.rs:732); bit 0: the Merkle layers of a tree's largest
+ * columns are hashed while its smaller columns are still being transformed (tree_builder.commit, mod.rs:500,583,723). Both pairs of kernels
+ * are VALU-limited on gfx950 and stretch each other when they co-run: measured gain 0-0.3 ms of 31 (profiles/r03_overlap_ab*.txt). */
 int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask);
 /* Host waits of this context: 0 (default) = poll briefly, then yield / block; 1 = hipStreamSynchronize at once (hosts with more waiting
  * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s). */

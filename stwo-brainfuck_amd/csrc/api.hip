@@ -38,6 +38,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
     BF_HIP(hipHostMalloc((void**)&h_small, h_small_bytes));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
+    BF_HIP(hipMalloc((void**)&d_counters, 4 * 64 * sizeof(u32)));
+    BF_HIP(hipMemset(d_counters, 0, 4 * 64 * sizeof(u32)));
     // point tables: G^a and G^(b << 16) for the M31 circle generator G = (2, 1268011823)
     std::vector<uint2> tlo(1 << 16), thi(1 << 15);
     auto mulp = [](uint2 p, uint2 q) { return uint2{m_sub(m_mul(p.x, q.x), m_mul(p.y, q.y)), m_add(m_mul(p.x, q.y), m_mul(p.y, q.x))}; };
@@ -67,7 +69,7 @@ void Ctx::destroy() {
     if (stream) prof_forget(stream);
     if (stream2) prof_forget(stream2);
     arena.release();
-    (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
+    (void)hipFree(d_counters); (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
     if (h_stage) (void)hipHostFree(h_stage);
     if (h_small) (void)hipHostFree(h_small);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);

@@ -55,13 +55,18 @@ struct Ctx {
     // Ordered by events only; both are joined back (event wait) before the commitment returns.
     // overlap: bit 0 = hash a tree's largest layers beside the transforms of its smaller columns; bit 1 = hash the FRI first-layer tree level by
     // level behind the quotient launches (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
-    u32 overlap = 2;      // measured on one box (profiles/r03_overlap_ab.txt): bit 1 gains 0.3 ms on fib19, bit 0 nothing (both sides are VALU-limited)
+    u32 overlap = 0;      // measured (profiles/r03_overlap_ab*.txt): bit 1 gains 0-0.3 ms on fib19 box to box, bit 0 nothing — both sides of either overlap are
+                          // VALU-limited (co-running kernels stretch each other), and the dominant kernel's event-timed roofline would include the interference
     hipStream_t aux[2] = {nullptr, nullptr};
     hipStream_t id_main = nullptr;  // the main stream's handle (stream and stream2 are swapped while the preprocessed phase is enqueued)
     hipStream_t aux_of(hipStream_t s) const { return s == id_main ? aux[0] : aux[1]; }
     hipEvent_t evp[32] = {};        // ordering events (no timing), handed out round robin: a wait captures the event's state when it is enqueued
     u32 evp_next = 0;
     hipEvent_t next_event() { return evp[evp_next++ % 32]; }
+    // Ticket counters of the kernels whose last workgroup finishes a tree (merkle.hip: k_merkle_small_end, k_fri_layer): one zeroed word per
+    // stream that may run such a kernel (main, side and the two partners), reset by the kernels themselves.
+    u32* d_counters = nullptr;
+    u32* merkle_counter() { return d_counters + 64 * (stream == id_main ? 0 : stream == aux[0] ? 1 : stream == aux[1] ? 2 : 3); }
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
     u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
     u32* d_tw = nullptr; u32* d_itw = nullptr;

@@ -101,7 +101,8 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
 // level, the column descriptors of all levels in one array (level `lg` owns cols[col_off[lg] .. col_off[lg - 1]), levels descending,
 // col_off[-1] := n_cols).
 struct MerkleTreeDesc { uint4* layers[32]; u32 shifts[32]; u32 col_off[32]; const ColDesc* cols; u32 n_cols, max_log; };
-// levels [hi .. 10] in one launch, 11 <= hi <= 17, all of them un-replicated; bytes / compressions: profiler accounting
+// levels [hi .. MERKLE_SUBTREE_ROOT_LEVEL] in one launch, 11 <= hi <= 17, all of them un-replicated; bytes / compressions: profiler accounting
+static constexpr u32 MERKLE_SUBTREE_ROOT_LEVEL = 9;
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions);
 // levels [top_hi .. 0] by one workgroup, top_hi <= 9 (children of level top_hi from level top_hi + 1 in HBM unless top_hi == max_log);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
@@ -123,6 +124,15 @@ struct FriTailArgs {
     FriTailLayer layer[10];
 };
 void fri_tail(hipStream_t stream, const FriTailArgs* d_args, double bytes, double compressions);   // bytes / compressions: profiler accounting (tree nodes only)
+// One FRI inner layer of 2^log rows (11 <= log <= 16) in ONE launch: fold of the previous layer (src, 2^(log + 1) rows) with alpha8 (+ fold-in of
+// `quot`, a circle evaluation of 2^(log + 1) rows, or nullptr), the layer's evaluations (dst), its Merkle tree (tree[lg] = level lg) and the
+// channel step (mix_root, draw -> alpha_out[8]; root copy -> root_out). counter: one zero-initialised u32 in HBM (reset by the kernel).
+struct FriLayerArgs {
+    const u32* src[4]; const u32* quot[4]; u32* dst[4]; uint4* tree[18];
+    const u32* alpha8; const u32* itw; u32 tw_total, log, rfc, pad_;
+    u32* counter; u32* chan; u32* alpha_out; u32* root_out;
+};
+void fri_layer(hipStream_t stream, const FriLayerArgs& a);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.

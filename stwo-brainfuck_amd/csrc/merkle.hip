@@ -12,6 +12,7 @@
 // Column reads are coalesced (lane i reads cell i of each column; replicated columns read cell i >> 4), child hashes are read as
 // 4 x 16 B per lane, hashes are stored as 2 x 16 B per lane in AoS [node][8 x u32] order (the order decommitment needs).
 #include "kernels.h"
+#include <stdexcept>
 
 namespace bf {
 
@@ -185,9 +186,9 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
 // ---- the small end of a tree in two launches ---------------------------------------------------------------------------------------
 // Below 2^18 nodes a layer launch is pure latency (~5 us for < 2 us of work) and the layers form a dependent chain. With the tree's layout
 // in HBM (MerkleTreeDesc: layer pointers, per-level column lists) two kernels cover it:
-//   k_merkle_subtree: levels [hi .. 10], hi <= 17 — one workgroup per node of level 10 hashes that node's subtree: its 2^(hi-10) nodes of
-//                     level hi (children from level hi + 1 in HBM, or none: leaves), then level by level through LDS;
-//   k_merkle_top:     levels [min(max_log, 9) .. 0] by a single workgroup (children of its first level from HBM), columns included, then
+//   k_merkle_subtree: levels [hi .. 9], hi <= 17 — one workgroup (256 lanes) per node of level 9 hashes that node's subtree: its 2^(hi-9) nodes
+//                     of level hi (children from level hi + 1 in HBM, or none: leaves), then level by level through LDS;
+//   k_merkle_top:     levels [8 .. 0] (or [min(max_log, 9) .. 0] of a tree too small for the subtree kernel) by a single workgroup (children of its first level from HBM), columns included, then
 //                     (FRI commit phase) the channel step on the root.
 // Every level is also written to HBM: the decommitment reads hashes from there. Un-replicated levels only (node i stored at i).
 //
@@ -272,10 +273,10 @@ __device__ __forceinline__ void node_hash_lean(u32 (&h)[8], bool has, uint4 ka, 
     }
 }
 
-__global__ void __launch_bounds__(128) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
-    __shared__ uint4 s_lv[2][2 * 128];
+__global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
+    __shared__ uint4 s_lv[2][2 * 256];
     const MerkleTreeDesc& td = *tdp;
-    const u32 lo = 10, b = blockIdx.x, t = threadIdx.x, qi = t & 3, qn = t >> 2;
+    const u32 lo = MERKLE_SUBTREE_ROOT_LEVEL, b = blockIdx.x, t = threadIdx.x, qi = t & 3, qn = t >> 2;
     for (u32 lg = hi; lg >= lo; lg--) {
         const u32 n = 1u << (lg - lo);
         const ColDesc* cols = td.cols + td.col_off[lg];
@@ -503,6 +504,133 @@ __global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict_
         __syncthreads();
     }
 }
+// ---- one FRI inner layer of 2^11 .. 2^16 rows as ONE launch ----------------------------------------------------------------------------
+// fold (fold_line of the previous layer + fold-in of the quotient of that size), leaves, the tree and the channel step: a workgroup folds
+// and hashes 256 rows and reduces them to one node in LDS; the workgroup that finishes LAST (a ticket counter in HBM, release / acquire fences
+// at device scope) hashes the remaining levels above the workgroup roots and steps the channel. Three launches (fold, subtree, top) and two
+// kernel start-ups less on the latency chain of every such layer: 27-49 us per layer instead of ~61. The hand-over costs a device-scope release per
+// workgroup, which on this part writes the XCD's L2 back (the eight L2s are not coherent with each other): the kernel's time grows with the number
+// of workgroups (8: 27 us, 256: 49 us, 512: 73 us — slower than three launches), hence the 2^16-row limit; the same structure for the small end of
+// the big trees (512 workgroups) measured 70 us against 56-69 for k_merkle_subtree + k_merkle_top and was not kept (profiles/r03_small_end_fusion.txt).
+__global__ void __launch_bounds__(256) k_fri_layer(FriLayerArgs a) {
+    __shared__ uint4 s_h[2][2 * 512];
+    __shared__ u32 s_ch[16];
+    __shared__ u32 s_ticket;
+    const u32 t = threadIdx.x, qi = t & 3, qn = t >> 2, rfc = a.rfc, log = a.log;
+    const u32 nb = gridDim.x;                               // 2^(log - 8) workgroups
+    const u32 root_lv = log - 8;                            // level of the workgroup roots
+    // ---- fold: row i of this layer from rows 2i, 2i + 1 of the previous one (2^(log + 1) rows) ----
+    u32 leaf[4];
+    {
+        const u32 i = blockIdx.x * 256 + t, slog = log + 1;
+        const Q31 alpha = q_make(a.alpha8[0], a.alpha8[1], a.alpha8[2], a.alpha8[3]);
+        const u32 xinv = a.itw[a.tw_total - (1u << slog) + i];
+        const uint2 a0 = reinterpret_cast<const uint2*>(a.src[0])[i], a1 = reinterpret_cast<const uint2*>(a.src[1])[i], a2 = reinterpret_cast<const uint2*>(a.src[2])[i], a3 = reinterpret_cast<const uint2*>(a.src[3])[i];
+        const Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
+        Q31 r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+        if (a.quot[0]) {
+            const Q31 alpha_sq = q_make(a.alpha8[4], a.alpha8[5], a.alpha8[6], a.alpha8[7]);
+            const u32* t1 = a.itw + (a.tw_total - (1u << (slog - 1)));
+            const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
+            const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
+            const uint2 b0 = reinterpret_cast<const uint2*>(a.quot[0])[i], b1 = reinterpret_cast<const uint2*>(a.quot[1])[i], b2 = reinterpret_cast<const uint2*>(a.quot[2])[i], b3 = reinterpret_cast<const uint2*>(a.quot[3])[i];
+            const Q31 fp = q_make(b0.x, b1.x, b2.x, b3.x), fq = q_make(b0.y, b1.y, b2.y, b3.y);
+            const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fq), yinv)), q_add(fp, fq));
+            r = q_add(q_mul(r, alpha_sq), fprime);
+        }
+        leaf[0] = r.a.a; leaf[1] = r.a.b; leaf[2] = r.b.a; leaf[3] = r.b.b;
+        a.dst[0][i] = leaf[0]; a.dst[1][i] = leaf[1]; a.dst[2][i] = leaf[2]; a.dst[3][i] = leaf[3];
+    }
+    // ---- levels: kind 0 = leaves (level log, 256 per workgroup), 1 = inner; `wide` = nodes of the level this workgroup hashes ----
+    bool last_block = false;
+    u32 n_sent = 0;
+    for (int lg = (int)log, kind = 0;;) {
+        const bool in_block = !last_block;
+        const u32 n = kind >= 2 ? 1u : in_block ? 1u << (lg - (int)root_lv) : 1u << lg;        // nodes of this step
+        const u32 node0 = in_block && kind <= 1 ? blockIdx.x << (lg - (int)root_lv) : 0u;     // first node (global index) of this workgroup at level lg
+        const uint4* src = s_h[(lg + 1) & 1];
+        const bool from_hbm = last_block && kind == 1 && lg + 1 == (int)root_lv;                // the last workgroup's first level reads every workgroup's root
+        if (kind <= 1 && n > 64) {
+            for (u32 j = t; j < n; j += 256) {
+                u32 h[8];
+                uint4 ka = make_uint4(0, 0, 0, 0), kb = ka, kc = ka, kd = ka;
+                if (kind == 1) {
+                    if (from_hbm) { const uint4* p = a.tree[lg + 1]; ka = p[4 * j]; kb = p[4 * j + 1]; kc = p[4 * j + 2]; kd = p[4 * j + 3]; }
+                    else { ka = src[4 * j]; kb = src[4 * j + 1]; kc = src[4 * j + 2]; kd = src[4 * j + 3]; }
+                }
+                node_hash_lean(h, kind == 1, ka, kb, kc, kd, nullptr, kind == 0 ? 4u : 0u, node0 + j, rfc, leaf);
+                hash_to_hbm(a.tree[lg], node0 + j, h);
+                hash_to_lds(s_h[lg & 1], j, h);
+            }
+        } else if (qn < n) {
+            u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;
+            quad_iv(qi, ha, hb);
+            if (kind == 1) {
+                if (from_hbm) { const uint4* p = a.tree[lg + 1]; kids_to_m(m, p[4 * qn], p[4 * qn + 1], p[4 * qn + 2], p[4 * qn + 3]); }
+                else kids_to_m(m, src[4 * qn], src[4 * qn + 1], src[4 * qn + 2], src[4 * qn + 3]);
+                ha &= rfc; hb &= rfc; t0 &= rfc; f0 = rfc;
+            } else {
+#pragma unroll
+                for (int w = 0; w < 8; w++) m[w] = s_ch[w];
+                if (kind == 2) {
+                    const u32* root = reinterpret_cast<const u32*>(s_h[0]);
+#pragma unroll
+                    for (int w = 0; w < 8; w++) m[8 + w] = root[w];
+                    a.root_out[qi] = m[8 + qi]; a.root_out[4 + qi] = m[12 + qi];
+                } else {
+#pragma unroll
+                    for (int w = 9; w < 16; w++) m[w] = 0;
+                    m[8] = n_sent;
+                }
+            }
+            blake2s_compress_quad(ha, hb, m, t0, f0, qi);
+            if (kind == 1) {
+                u32* o = reinterpret_cast<u32*>(a.tree[lg]) + 8 * (size_t)(node0 + qn); o[qi] = ha; o[4 + qi] = hb;
+                u32* l = reinterpret_cast<u32*>(s_h[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
+            } else if (kind == 2) { s_ch[qi] = ha; s_ch[4 + qi] = hb; }
+            else { s_ch[8 + qi] = ha; s_ch[12 + qi] = hb; }
+        }
+        __syncthreads();
+        if (kind == 3) {
+            bool ok = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) ok = ok && s_ch[8 + w] < 2u * P31;
+            n_sent++;
+            if (ok) break;
+            __syncthreads();
+        } else if (kind == 2) kind = 3;
+        else if (in_block && lg == (int)root_lv) {
+            // this workgroup's root is in HBM: release it, take a ticket; every workgroup but the last one is done
+            __threadfence();
+            if (t == 0) s_ticket = atomicAdd(a.counter, 1u);
+            __syncthreads();
+            if (s_ticket != nb - 1) return;
+            __threadfence();                       // acquire: the other workgroups' roots
+            last_block = true;
+            if (t == 0) *a.counter = 0;            // ready for the next use of this counter
+            if (t < 8) s_ch[t] = a.chan[t];
+            if (root_lv == 0) kind = 2; else { lg--; kind = 1; }
+            __syncthreads();
+        } else if (lg == 0) kind = 2;
+        else { lg--; kind = 1; }
+    }
+    if (t == 0) {
+        u32 w4[4];
+        for (int w = 0; w < 4; w++) w4[w] = s_ch[8 + w] >= P31 ? s_ch[8 + w] - P31 : s_ch[8 + w];
+        const Q31 alpha = q_make(w4[0], w4[1], w4[2], w4[3]), sq = q_mul(alpha, alpha);
+        a.alpha_out[0] = alpha.a.a; a.alpha_out[1] = alpha.a.b; a.alpha_out[2] = alpha.b.a; a.alpha_out[3] = alpha.b.b;
+        a.alpha_out[4] = sq.a.a; a.alpha_out[5] = sq.a.b; a.alpha_out[6] = sq.b.a; a.alpha_out[7] = sq.b.b;
+        for (int w = 0; w < 8; w++) a.chan[w] = s_ch[w];
+        a.chan[8] = n_sent;
+    }
+}
+void fri_layer(hipStream_t stream, const FriLayerArgs& a) {
+    if (a.log < 11 || a.log > 16) throw std::runtime_error("fri_layer: 2^11 .. 2^16 rows");
+    const double nodes = (double)((2u << a.log) - 1);
+    ProfScope ps(stream, "k_fri_layer", 48.0 * nodes + 48.0 * (double)(1u << a.log), nodes);
+    hipLaunchKernelGGL(k_fri_layer, dim3(1u << (a.log - 8)), dim3(256), 0, stream, a);
+}
+
 void fri_tail(hipStream_t stream, const FriTailArgs* d_args, double bytes, double compressions) {
     ProfScope ps(stream, "k_fri_tail", bytes, compressions);
     hipLaunchKernelGGL(k_fri_tail, dim3(1), dim3(256), 0, stream, d_args);
@@ -527,7 +655,7 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
 }
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
-    hipLaunchKernelGGL(k_merkle_subtree, dim3(1024), dim3(128), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
 }
 void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_top", bytes, compressions);

@@ -177,7 +177,7 @@ struct HipProver {
     struct MerklePlan {
         DevMerkle mk; std::vector<DCol> cols; std::vector<size_t> off; std::vector<double> bytes; size_t n_all = 0;
         const ColDesc* d_all = nullptr; const MerkleTreeDesc* d_tree = nullptr; bool poseidon = false;
-        // launches: levels [max_log .. sub_hi + 1] one each (k_merkle_layer), [sub_hi .. 10] one (k_merkle_subtree; sub_hi == 0: none and the
+        // launches: levels [max_log .. sub_hi + 1] one each (k_merkle_layer), [sub_hi .. 9] one (k_merkle_subtree; sub_hi == 0: none and the
         // single-level launches go down to fused_top), [fused_top - 1 .. 0] one (k_merkle_top; fused_top == 0: none)
         u32 fused_top = 0, sub_hi = 0;
         double top_bytes = 0, top_comp = 0, sub_bytes = 0, sub_comp = 0;
@@ -219,7 +219,7 @@ struct HipProver {
         if (fused_top == 10 && mk.max_log >= 11 && c.shard.count == 1) {
             u32 hi = std::min<u32>(mk.max_log, 17);
             while (hi > 10 && mk.shifts[hi] != 0) hi--;
-            if (hi > 10) p.sub_hi = hi;
+            if (hi > 10) { p.sub_hi = hi; p.fused_top = fused_top = MERKLE_SUBTREE_ROOT_LEVEL; }     // the top starts below the subtree roots
         }
         auto level_cols = [&](int log) { return (log > 0 ? p.off[log - 1] : all.size()) - p.off[log]; };
         auto level_cost = [&](int log, double& bytes, double& comp) {
@@ -229,7 +229,7 @@ struct HipProver {
             comp += nodes * ((has ? 1.0 : 0.0) + (double)(((u32)nc + 15) / 16) + ((!has && nc == 0) ? 1.0 : 0.0));
         };
         for (int log = (int)fused_top - 1; log >= 0; log--) level_cost(log, p.top_bytes, p.top_comp);
-        if (p.sub_hi) for (int log = (int)p.sub_hi; log >= 10; log--) level_cost(log, p.sub_bytes, p.sub_comp);
+        if (p.sub_hi) for (int log = (int)p.sub_hi; log >= (int)MERKLE_SUBTREE_ROOT_LEVEL; log--) level_cost(log, p.sub_bytes, p.sub_comp);
         p.d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
         if (fused_top > 0) {
             MerkleTreeDesc td{};
@@ -568,6 +568,7 @@ struct HipProver {
         Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
         Hash32* pinned_root1 = pinned_root0 + 1;
         const bool reuse = cache.matches(c, log_max_rows);
+        BF_HIP(hipMemsetAsync(c.d_counters, 0, 4 * 64 * sizeof(u32), c.stream));      // ticket counters (a failed proof may have left one mid-count)
         BF_HIP(hipEventRecord(c.ev[0], c.stream));
         // In a shard group everything stays on the main stream: the group's exchanges are issued in one order on one stream per rank.
         const bool use_side = !sharded();
@@ -1144,15 +1145,35 @@ struct HipProver {
         // inner layers: commit layer k (-> alpha_{k+1}), then ONE launch folds it into layer k + 1 together with the quotient of layer k's
         // size (fold_line, then dst * alpha^2 + fold_circle: both with alpha_{k+1}). Below 2^10 rows the rest of the phase is one launch.
         const u32 TAIL_LOG = 10;
+        // layers of 2^11 .. 2^16 rows: fold + tree + channel step in ONE launch (merkle.hip: k_fri_layer) — device channel, one process
+        auto fused = [&](u32 k) { const u32 lg = line_log - k; return !host_channel && !sharded() && k >= 1 && k < n_inner && lg >= 11 && lg <= 16; };
+        auto take_quotient = [&](u32 size) -> const DSecure* {
+            const DSecure* q = (qi < quotients.size() && quotients[qi].log_size == size) ? &quotients[qi++] : nullptr;
+            if (qi < quotients.size() && quotients[qi].log_size == size) throw HipError("FRI: two quotient columns of one size");
+            return q;
+        };
+        u32* d_counter = nullptr;
         u32 li = 0;
         for (; li < n_inner; li++) {
             const u32 log = line_log - li;
             if (!host_channel && log <= TAIL_LOG) break;
             Inner in; in.ev = layers[li];
-            in.tree = commit_step(1 + li, secure_cols(layers[li]), li + 1, 1 + li);
+            if (fused(li)) {
+                d_counter = c.merkle_counter();
+                const DSecure* q = take_quotient(log + 1);        // the circle evaluation that folds into this layer
+                const DevMerkle& mk = plans[1 + li].mk;
+                if (mk.max_log != log) throw HipError("FRI layer: tree layout");
+                FriLayerArgs fa{};
+                for (int w = 0; w < 4; w++) { fa.src[w] = layers[li - 1].c[w]; fa.quot[w] = q ? q->c[w] : nullptr; fa.dst[w] = layers[li].c[w]; }
+                for (u32 lg = 0; lg <= log; lg++) { if (mk.shifts[lg] != 0) throw HipError("FRI layer: replicated level"); fa.tree[lg] = (uint4*)mk.layers[lg]; }
+                fa.alpha8 = d_alpha + 8 * li; fa.itw = c.d_itw; fa.tw_total = 1u << c.tw_root_log; fa.log = log; fa.rfc = c.conv.merkle_node_hash ? 0xFFFFFFFFu : 0u;
+                fa.counter = d_counter; fa.chan = d_chan; fa.alpha_out = d_alpha + 8 * (li + 1); fa.root_out = d_roots + 8 * (1 + li);
+                fri_layer(c.stream, fa);
+                in.tree = mk;
+            } else in.tree = commit_step(1 + li, secure_cols(layers[li]), li + 1, 1 + li);
             inner.push_back(in);
-            const DSecure* q = (qi < quotients.size() && quotients[qi].log_size == log) ? &quotients[qi++] : nullptr;
-            if (qi < quotients.size() && quotients[qi].log_size == log) throw HipError("FRI: two quotient columns of one size");
+            if (fused(li + 1)) continue;                           // the next layer folds this one itself
+            const DSecure* q = take_quotient(log);
             DSecure& next = layers[li + 1];
             const u32* src[4] = {layers[li].c[0], layers[li].c[1], layers[li].c[2], layers[li].c[3]};
             const u32* qs[4] = {q ? q->c[0] : nullptr, q ? q->c[1] : nullptr, q ? q->c[2] : nullptr, q ? q->c[3] : nullptr};

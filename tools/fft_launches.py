@@ -15,7 +15,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
                          int(r.get("Grid_Size_Y", 1) or 1), int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_one_hot") and (i == 0 or not rows[i - 1][2].startswith("k_one_hot"))]
+    starts = [i for i, r in enumerate(rows) if r[2].startswith("k_is_first_coeffs") and (i == 0 or not rows[i - 1][2].startswith("k_is_first_coeffs"))]
     rows = rows[starts[-1]:] if starts else rows
     agg = defaultdict(lambda: [0, 0.0])
     tot = 0.0

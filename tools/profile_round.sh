@@ -1,46 +1,98 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repository root):
-#   gpurun -- 'bash tools/profile_round.sh r02'
+#   gpurun -- 'bash tools/profile_round.sh r03 [part ...]'      parts: bench trace pmc clock fft poseidon shard misc   (default: all)
 # Writes into gpurun_out/<round>/ ; copy what should be judged into profiles/.
 set -u
-R=${1:-r02}
+R=${1:-r03}; shift || true
+PARTS=${*:-bench trace pmc clock fft poseidon shard misc}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+kt() { ls $1/*/*kernel_trace.csv | head -1; }
+
+if has bench; then
 # 1. headline bench line (roofline measured live with HIP events, CPU baseline on the host cores)
 python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.log" | tail -1 > "$OUT/${R}_bench.json"
 # 2. same command under rocprofv3 --kernel-trace --stats (per-kernel average durations must agree with the roofline object)
-rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep > "$OUT/bench_under_rocprof.log" 2>&1
+rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon > "$OUT/bench_under_rocprof.log" 2>&1
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
-# 2b. idle-gap analysis of one proof without the event instrumentation
-rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --steps 3 --warmup 1 > /dev/null 2>&1
-python3 "$ROOT/tools/timeline_gaps.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
-python3 "$ROOT/tools/fft_launches.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) > "$OUT/${R}_fft_launches.txt" 2>&1
-for K in k_quotients k_constraints k_fold k_eval; do python3 "$ROOT/tools/fft_launches.py" $(ls /tmp/prof_tl/*/*kernel_trace.csv | head -1) $K | head -12; done > "$OUT/${R}_field_kernel_launches.txt" 2>&1
+fi
+
+if has trace; then
+# 2b. idle-gap analysis of one proof without the event instrumentation: the bench workload and the metric's own size (2^22 rows), 2^20
+rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/tools/point.py" fib19 --steps 3 --warmup 1 > /dev/null 2>&1
+python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_tl) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
+python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_tl) > "$OUT/${R}_fib19_timeline.txt" 2>&1
+python3 "$ROOT/tools/fft_launches.py" $(kt /tmp/prof_tl) > "$OUT/${R}_fft_launches.txt" 2>&1
+for K in k_quotients k_constraints k_fold k_eval; do python3 "$ROOT/tools/fft_launches.py" $(kt /tmp/prof_tl) $K | head -12; done > "$OUT/${R}_field_kernel_launches.txt" 2>&1
+for w in 22 20; do
+  rm -rf /tmp/prof_$w; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 "$ROOT/tools/point.py" $w --steps 10 --warmup 2 > "$OUT/point_${w}_under_rocprof.json" 2>/dev/null
+  cp $(ls /tmp/prof_$w/*/*kernel_stats.csv | head -1) "$OUT/${R}_2p${w}_kernel_stats.csv"
+  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_$w) 15 > "$OUT/${R}_2p${w}_timeline_gaps.txt" 2>&1
+  python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) --summary > "$OUT/${R}_2p${w}_timeline_summary.txt" 2>&1
+  python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) > "$OUT/${R}_2p${w}_timeline.txt" 2>&1
+done
+for w in 20 21 22 23 24 25 26 fib19; do python3 "$ROOT/tools/point.py" $w --steps 10; done > "$OUT/${R}_points.jsonl" 2>/dev/null
+# overlap switches on this box (A/B), concurrent k_merkle_layer + k_quotients visible in the timeline with bit 1
+for rep in 1 2; do for ov in 0 1 2 3; do for w in 22 fib19; do echo -n "overlap=$ov $w: "; BFHIP_OVERLAP=$ov python3 "$ROOT/tools/point.py" $w --steps 20 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_proof'], d['ms_min'], d['proof_sha256'][:12])"; done; done; done > "$OUT/${R}_overlap_ab.txt" 2>&1
+fi
+
+if has pmc; then
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sweep > "$OUT/pmc_$C.log" 2>&1
+  rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon > "$OUT/pmc_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/${R}_pmc_traffic.json"
-# 3b. effective clock and issue-slot accounting of the Merkle kernel and of the register-only Blake2s micro-benchmark (one counter pass each)
+fi
+
 CNT="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"
+if has clock; then
+# 3b. effective clock and issue-slot accounting of the Merkle kernel and of the register-only Blake2s micro-benchmark (one counter pass each)
 rm -rf /tmp/prof_clock; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_clock -- python3 "$ROOT/tools/merkle_shapes.py" > /dev/null 2>&1
 python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_clock > "$OUT/${R}_merkle_clock.json" 2>&1
-hipcc -O3 --offload-arch=gfx950 -o /tmp/ubench_blake "$ROOT/tools/ubench_blake.hip" 2>/dev/null && { rm -rf /tmp/prof_ub; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_ub -- /tmp/ubench_blake > /dev/null 2>&1; python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_ub k_bench > "$OUT/${R}_ubench_blake_clock.json" 2>&1; }
-# 4. FFT kernel run (BASELINE config 3 (i)), Merkle shapes, one-call end-to-end, large synthetic trace
-python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
 python3 "$ROOT/tools/merkle_shapes.py" > "$OUT/${R}_merkle_shapes.txt" 2>&1
-python3 "$ROOT/tools/trace_time.py" > "$OUT/${R}_one_call.txt" 2>&1
-python3 "$ROOT/tools/big_trace.py" > "$OUT/${R}_big_trace.json" 2> "$OUT/big_trace.err"
-for n in 2 3; do python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --inflight $n 2>/dev/null | tail -1 > "$OUT/${R}_bench_inflight$n.json"; done
-python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep 2>/dev/null | tail -1 > "$OUT/${R}_bench_no_events.json"
-python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --reuse-preprocessed 2>/dev/null | tail -1 > "$OUT/${R}_bench_reuse_preprocessed.json"
-# 5. one proof over N ranks of this one GPU (local shard group): replicated vs divided work; Poseidon252 variant (config 5) and its bound
-python3 "$ROOT/tools/shard_local.py" 5 > "$OUT/${R}_shard_local_one_gpu.json" 2> "$OUT/shard_local.err"
+fi
+
+if has fft; then
+# 4. FFT kernel run (BASELINE config 3 (i)): HIP-event profile, rocprofv3 kernel stats of the same command, FETCH/WRITE counter passes
+python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
+rm -rf /tmp/prof_fft; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fft -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > "$OUT/fft_roofline_under_rocprof.json" 2>/dev/null
+cp $(ls /tmp/prof_fft/*/*kernel_stats.csv | head -1) "$OUT/${R}_fft_kernel_stats.csv"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/prof_fft_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_fft_$C -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
+done
+python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_fft_FETCH_SIZE /tmp/prof_fft_WRITE_SIZE > "$OUT/${R}_fft_pmc_traffic.json"
+for tp in 0 1; do for lg in 20 21 22; do echo "== two_pass=$tp log=$lg"; BFHIP_FFT_TWO_PASS=$tp python3 "$ROOT/tools/fft_roofline.py" $lg 4 32 | python3 -c "
+import sys,json
+for r in json.load(sys.stdin):
+    print(r['columns'], 'columns:', r['ifft_plus_lde_plus_fft_ms'], 'ms', {k:(v['avg_us'],v['GB/s_moved']) for k,v in r.items() if isinstance(v,dict)})"; done; done > "$OUT/${R}_fft_two_pass_ab.txt" 2>&1
+fi
+
+if has poseidon; then
+# 5. Poseidon252 variant (config 5): proof times, kernel stats, issue-slot counters of the layer kernel, register-only micro-benchmark
 python3 "$ROOT/tools/poseidon_trace.py" 24 2 > "$OUT/${R}_poseidon_trace_2p24.json" 2> "$OUT/poseidon_trace.err"
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -I "$ROOT/stwo-brainfuck_amd/csrc" -o /tmp/ubench_poseidon "$ROOT/tools/ubench_poseidon.hip" 2>/dev/null && /tmp/ubench_poseidon > "$OUT/${R}_ubench_poseidon.txt"
 rm -rf /tmp/prof_pos; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pos -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
 cp $(ls /tmp/prof_pos/*/*kernel_stats.csv | head -1) "$OUT/${R}_poseidon_2p22_kernel_stats.csv"
+rm -rf /tmp/prof_posc; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posc -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
+python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_posc k_merkle_layer_poseidon > "$OUT/${R}_poseidon_clock.json" 2>&1
+rm -rf /tmp/prof_posu; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posu -- /tmp/ubench_poseidon > /dev/null 2>&1
+python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_posu k_hades > "$OUT/${R}_ubench_poseidon_clock.json" 2>&1
+fi
+
+if has shard; then
+# 6. one proof over N ranks of this one GPU (local shard group): replicated vs divided work, per-collective GPU time
+python3 "$ROOT/tools/shard_local.py" 5 > "$OUT/${R}_shard_local_one_gpu.json" 2> "$OUT/shard_local.err"
+fi
+
+if has misc; then
+python3 "$ROOT/tools/trace_time.py" > "$OUT/${R}_one_call.txt" 2>&1
+python3 "$ROOT/tools/big_trace.py" > "$OUT/${R}_big_trace.json" 2> "$OUT/big_trace.err"
+for n in 2 3; do python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon --inflight $n 2>/dev/null | tail -1 > "$OUT/${R}_bench_inflight$n.json"; done
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon 2>/dev/null | tail -1 > "$OUT/${R}_bench_no_events.json"
+python3 "$ROOT/bench.py" --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon --reuse-preprocessed 2>/dev/null | tail -1 > "$OUT/${R}_bench_reuse_preprocessed.json"
+fi
 ls -la "$OUT"
