@@ -273,6 +273,32 @@ __device__ __forceinline__ void node_hash_lean(u32 (&h)[8], bool has, uint4 ka, 
     }
 }
 
+// The same node hash by a QUAD of lanes (ha = h[qi], hb = h[4 + qi] on return), any number of columns: one quad compression site in a loop.
+// Every lane of the quad builds the whole message block (the 4 lanes read the same addresses).
+__device__ __forceinline__ void node_hash_quad(u32& ha, u32& hb, bool has, uint4 ka, uint4 kb, uint4 kc, uint4 kd, const ColDesc* __restrict__ cols, u32 ncols, u32 i, u32 rfc, u32 qi) {
+    quad_iv(qi, ha, hb); ha &= rfc; hb &= rfc;
+    const u32 nblk = (has ? 1u : 0u) + (ncols + 15) / 16 + ((!has && ncols == 0) ? 1u : 0u);
+    u32 done = 0;
+#pragma unroll 1
+    for (u32 blk = 0; blk < nblk; blk++) {
+        u32 m[16];
+        if (blk == 0 && has) { kids_to_m(m, ka, kb, kc, kd); done = 64; }
+        else {
+            const u32 c0 = 16 * (blk - (has ? 1u : 0u));
+#pragma unroll
+            for (u32 w = 0; w < 16; w++) {
+                const u32 cc = c0 + w;
+                u32 v = 0;
+                if (cc < ncols) v = ld_col(cols[cc], i);
+                m[w] = v;
+            }
+            done += min(64u, 4u * (ncols - min(ncols, c0)));
+        }
+        const bool last = blk + 1 == nblk;
+        blake2s_compress_quad(ha, hb, m, done & rfc, last ? rfc : 0u, qi);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
     __shared__ uint4 s_lv[2][2 * 256];
     const MerkleTreeDesc& td = *tdp;
@@ -285,7 +311,7 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __
         const uint4* prev = first && has ? td.layers[hi + 1] : nullptr;
         const u32 ps = first && has ? td.shifts[hi + 1] : 0u;
         const uint4* src = s_lv[(lg + 1) & 1];
-        const bool quad = ncols == 0 && has && 4 * n <= blockDim.x;
+        const bool quad = 4 * n <= blockDim.x;
         const u32 j = quad ? qn : t;
         if (j < n) {
             const u32 i = (b << (lg - lo)) + j;
@@ -295,10 +321,8 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __
                 else { ka = src[4 * j]; kb = src[4 * j + 1]; kc = src[4 * j + 2]; kd = src[4 * j + 3]; }
             }
             if (quad) {
-                u32 m[16], ha, hb;
-                kids_to_m(m, ka, kb, kc, kd);
-                quad_iv(qi, ha, hb); ha &= rfc; hb &= rfc;
-                blake2s_compress_quad(ha, hb, m, 64u & rfc, rfc, qi);
+                u32 ha, hb;
+                node_hash_quad(ha, hb, has, ka, kb, kc, kd, cols, ncols, i, rfc, qi);
                 u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * (size_t)i; o[qi] = ha; o[4 + qi] = hb;
                 u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * j; l[qi] = ha; l[4 + qi] = hb;
             } else {
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __rest
         const uint4* prev = tree && first && has ? td.layers[lg + 1] : nullptr;
         const uint4* src = s_lv[(lg + 1) & 1];
         const u32 n = tree ? 1u << lg : 1u;
-        const bool quad = !tree || (ncols == 0 && has && n <= 64);
+        const bool quad = !tree || n <= 64;
         if (!quad) {
             for (u32 i = t; i < n; i += blockDim.x) {
                 u32 h[8];
@@ -343,14 +367,22 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __rest
                 hash_to_hbm(td.layers[lg], i, h);
                 hash_to_lds(s_lv[lg & 1], i, h);
             }
+        } else if (tree) {
+            if (qn < n) {
+                u32 ha, hb;
+                uint4 ka = make_uint4(0, 0, 0, 0), kb = ka, kc = ka, kd = ka;
+                if (has) {
+                    if (first) { ka = prev[4 * qn]; kb = prev[4 * qn + 1]; kc = prev[4 * qn + 2]; kd = prev[4 * qn + 3]; }
+                    else { ka = src[4 * qn]; kb = src[4 * qn + 1]; kc = src[4 * qn + 2]; kd = src[4 * qn + 3]; }
+                }
+                node_hash_quad(ha, hb, has, ka, kb, kc, kd, cols, ncols, qn, rfc, qi);
+                u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
+                u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
+            }
         } else if (qn < n) {
             u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;
             quad_iv(qi, ha, hb);
-            if (tree) {
-                if (first) kids_to_m(m, prev[4 * qn], prev[4 * qn + 1], prev[4 * qn + 2], prev[4 * qn + 3]);
-                else kids_to_m(m, src[4 * qn], src[4 * qn + 1], src[4 * qn + 2], src[4 * qn + 3]);
-                ha &= rfc; hb &= rfc; t0 &= rfc; f0 = rfc;
-            } else {
+            {
 #pragma unroll
                 for (int k = 0; k < 8; k++) m[k] = s_ch[k];
                 if (lg == -1) {         // mix_root: Blake2s(digest || root)
@@ -365,10 +397,7 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __rest
                 }
             }
             blake2s_compress_quad(ha, hb, m, t0, f0, qi);
-            if (tree) {
-                u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
-                u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
-            } else if (lg == -1) { s_ch[qi] = ha; s_ch[4 + qi] = hb; }
+            if (lg == -1) { s_ch[qi] = ha; s_ch[4 + qi] = hb; }
             else { s_ch[8 + qi] = ha; s_ch[12 + qi] = hb; }
         }
         __syncthreads();
