@@ -97,16 +97,16 @@ void is_first_coeffs(hipStream_t stream, const IsFirstCols& a, const u32* itw, u
 // node_conv = Conventions::merkle_node_hash
 void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc* d_cols, u32 ncols, u32 log, double col_bytes, u32 out_shift, u32 prev_shift,
                   u32 node_conv, u32 first = 0, u32 count = 0);
-// A tree's layout in HBM for the kernels that walk several levels (merkle_subtree, merkle_top): layer pointers and replication shifts by
+// A tree's layout, passed BY VALUE to the kernels that walk several levels (merkle_subtree, merkle_top): layer pointers and replication shifts by
 // level, the column descriptors of all levels in one array (level `lg` owns cols[col_off[lg] .. col_off[lg - 1]), levels descending,
 // col_off[-1] := n_cols).
 struct MerkleTreeDesc { uint4* layers[32]; u32 shifts[32]; u32 col_off[32]; const ColDesc* cols; u32 n_cols, max_log; };
 // levels [hi .. MERKLE_SUBTREE_ROOT_LEVEL] in one launch, 11 <= hi <= 17, all of them un-replicated; bytes / compressions: profiler accounting
 static constexpr u32 MERKLE_SUBTREE_ROOT_LEVEL = 9;
-void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions);
+void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 node_conv, double bytes, double compressions);
 // levels [top_hi .. 0] by one workgroup, top_hi <= 9 (children of level top_hi from level top_hi + 1 in HBM unless top_hi == max_log);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
-void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions);
+void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions);
 // The FRI commit phase below 2^10 rows as ONE single-workgroup launch (merkle.hip: k_fri_tail): per layer the Merkle tree of its 4 coordinate
 // columns, the channel step (mix_root, draw alpha), the fold into the next layer (+ fold-in of the quotient of that size), all through LDS;
 // evaluations, hashes, roots and alphas also go to HBM for the decommitment and the host's channel replay.

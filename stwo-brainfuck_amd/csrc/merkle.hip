@@ -185,7 +185,7 @@ __global__ void k_channel_mix_root_draw(u32* __restrict__ chan, const u32* __res
 
 // ---- the small end of a tree in two launches ---------------------------------------------------------------------------------------
 // Below 2^18 nodes a layer launch is pure latency (~5 us for < 2 us of work) and the layers form a dependent chain. With the tree's layout
-// in HBM (MerkleTreeDesc: layer pointers, per-level column lists) two kernels cover it:
+// as a kernel argument (MerkleTreeDesc: layer pointers, per-level column lists; 528 bytes of kernarg — no staging copy to wait for) two kernels cover it:
 //   k_merkle_subtree: levels [hi .. 9], hi <= 17 — one workgroup (256 lanes) per node of level 9 hashes that node's subtree: its 2^(hi-9) nodes
 //                     of level hi (children from level hi + 1 in HBM, or none: leaves), then level by level through LDS;
 //   k_merkle_top:     levels [8 .. 0] (or [min(max_log, 9) .. 0] of a tree too small for the subtree kernel) by a single workgroup (children of its first level from HBM), columns included, then
@@ -299,9 +299,8 @@ __device__ __forceinline__ void node_hash_quad(u32& ha, u32& hb, bool has, uint4
     }
 }
 
-__global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __restrict__ tdp, u32 hi, u32 rfc) {
+__global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc td, u32 hi, u32 rfc) {
     __shared__ uint4 s_lv[2][2 * 256];
-    const MerkleTreeDesc& td = *tdp;
     const u32 lo = MERKLE_SUBTREE_ROOT_LEVEL, b = blockIdx.x, t = threadIdx.x, qi = t & 3, qn = t >> 2;
     for (u32 lg = hi; lg >= lo; lg--) {
         const u32 n = 1u << (lg - lo);
@@ -337,12 +336,11 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc* __
 }
 
 // chan != nullptr: Blake2sChannel::mix_root(root) and draw_felt() follow the root as two more quad steps (levels -1 and -2 of the loop).
-__global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc* __restrict__ tdp, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
+__global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
     // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
     // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
     __shared__ uint4 s_lv[2][2 * 512];
     __shared__ u32 s_ch[16];              // [0, 8): channel digest; [8, 16): the draw's output
-    const MerkleTreeDesc& td = *tdp;
     const u32 t = threadIdx.x, qi = t & 3, qn = t >> 2;
     if (chan && t < 8) s_ch[t] = chan[t];
     u32 n_sent = 0;
@@ -682,13 +680,13 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
     if (blocks >= (1u << 14)) blocks /= MERKLE_NODES_PER_LANE;   // >= 2^22 nodes: several nodes per lane (measured: 2..16 equivalent, 4 kept)
     hipLaunchKernelGGL(k_merkle_layer, dim3(blocks), dim3(threads), 0, stream, (uint4*)out, (const uint4*)prev, d_cols, ncols, n, out_shift, prev_shift, count ? first : 0u, node_conv ? 0xFFFFFFFFu : 0u);
 }
-void merkle_subtree(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 hi, u32 node_conv, double bytes, double compressions) {
+void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 node_conv, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
-    hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, d_tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
 }
-void merkle_top(hipStream_t stream, const MerkleTreeDesc* d_tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
+void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_top", bytes, compressions);
-    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, d_tree, top_hi, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, tree, top_hi, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
 }
 
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {

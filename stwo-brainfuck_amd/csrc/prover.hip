@@ -176,7 +176,7 @@ struct HipProver {
     // arena storage, column descriptors written to the staging ring — inside the caller's StageBatch), merkle_run = the launches.
     struct MerklePlan {
         DevMerkle mk; std::vector<DCol> cols; std::vector<size_t> off; std::vector<double> bytes; size_t n_all = 0;
-        const ColDesc* d_all = nullptr; const MerkleTreeDesc* d_tree = nullptr; bool poseidon = false;
+        const ColDesc* d_all = nullptr; MerkleTreeDesc tree{}; bool poseidon = false;
         // launches: levels [max_log .. sub_hi + 1] one each (k_merkle_layer), [sub_hi .. 9] one (k_merkle_subtree; sub_hi == 0: none and the
         // single-level launches go down to fused_top), [fused_top - 1 .. 0] one (k_merkle_top; fused_top == 0: none)
         u32 fused_top = 0, sub_hi = 0;
@@ -236,7 +236,7 @@ struct HipProver {
             if (mk.max_log >= 32) throw HipError("merkle: tree too deep");
             for (u32 lg = 0; lg <= mk.max_log; lg++) { td.layers[lg] = (uint4*)mk.layers[lg]; td.shifts[lg] = mk.shifts[lg]; td.col_off[lg] = (u32)p.off[lg]; }
             td.cols = p.d_all; td.n_cols = (u32)all.size(); td.max_log = mk.max_log;
-            p.d_tree = c.stage(&td, 1);
+            p.tree = td;
         }
         // Shard group: the un-replicated layers with at least 256 nodes per rank are hashed share-wise; the smallest of them is
         // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
@@ -291,8 +291,8 @@ struct HipProver {
         }
         prof_run_end(c.stream);
         apply_waits(0);
-        if (p.sub_hi) merkle_subtree(c.stream, p.d_tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
-        if (fused_top > 0) merkle_top(c.stream, p.d_tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr, p.top_bytes, p.top_comp);
+        if (p.sub_hi) merkle_subtree(c.stream, p.tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
+        if (fused_top > 0) merkle_top(c.stream, p.tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr, p.top_bytes, p.top_comp);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
