@@ -1,7 +1,7 @@
 //! `HipBackend`: stwo's backend trait surface over `libbfhip.so` — the drop-in for `SimdBackend` at the places the reference fixes it
 //! (`crates/brainfuck_prover/src/brainfuck_air/mod.rs:56,399,480,486-487,497,732`, `components/mod.rs:42`).
 //!
-//! SOURCE ONLY: the build image has no Rust toolchain and the `stwo-prover` crate (rev 31e8dbc, `Cargo.toml:41`) is not vendored, so this
+//! A NON-BUILDING SKETCH, SOURCE ONLY (behind the crate feature `stwo-backend`, off by default): the build image has no Rust toolchain and the `stwo-prover` crate (rev 31e8dbc, `Cargo.toml:41`) is not vendored, so this
 //! file has never been compiled. It is written against the trait shapes of that revision as far as the reference's call sites and our
 //! recollection pin them; every method body is a thin call into `bfhip_sys` (generated from `include/bfhip.h`).
 //! `tests/test_abi_and_replicas.py::test_hip_backend_covers_the_trait_surface` keeps the method list in step with INTEGRATION.md §2.
@@ -51,18 +51,25 @@ pub struct HipBackend;
 
 struct CtxHandle(*mut sys::BfhipCtx);
 unsafe impl Send for CtxHandle {}
-unsafe impl Sync for CtxHandle {}
+
+/// Exclusive use of the process-wide context for the duration of one FFI call: the C context requires SERIAL calls (one stream, one staging
+/// ring), while stwo's prover may call backend operations from rayon workers (`--features parallel`). The guard is a temporary of the call
+/// expression, so the lock is held exactly as long as the call (no `Sync` claim on a bare handle).
+pub struct CtxGuard(std::sync::MutexGuard<'static, CtxHandle>);
+impl CtxGuard {
+    pub fn p(&self) -> *mut sys::BfhipCtx { (self.0).0 }
+}
 
 /// The process-wide context of GPU 0: stream, twiddle tree (`SimdBackend::precompute_twiddles(CanonicCoset::new(LOG_MAX_ROWS + 2 + blowup)…)`,
-/// `mod.rs:480-484`) and scratch memory. One context per GPU; calls on it are serial, like the reference's single control thread.
-fn ctx() -> *mut sys::BfhipCtx {
-    static CTX: OnceLock<CtxHandle> = OnceLock::new();
-    CTX.get_or_init(|| {
+/// `mod.rs:480-484`) and scratch memory. One context per GPU; calls on it are serialised by the mutex.
+fn ctx() -> CtxGuard {
+    static CTX: OnceLock<std::sync::Mutex<CtxHandle>> = OnceLock::new();
+    let m = CTX.get_or_init(|| {
         let mut p = std::ptr::null_mut();
         check(unsafe { sys::bfhip_ctx_create(0, LOG_MAX_ROWS + 2, &mut p) });
-        CtxHandle(p)
-    })
-    .0
+        std::sync::Mutex::new(CtxHandle(p))
+    });
+    CtxGuard(m.lock().unwrap_or_else(|e| e.into_inner()))
 }
 
 fn check(rc: i32) {
@@ -95,25 +102,25 @@ impl<T> HipColumn<T> {
     fn words_per_elem() -> usize { std::mem::size_of::<T>() / 4 }
     fn alloc(len: usize) -> Self {
         let mut p: *mut c_void = std::ptr::null_mut();
-        check(unsafe { sys::bfhip_malloc(ctx(), len * std::mem::size_of::<T>(), &mut p) });
+        check(unsafe { sys::bfhip_malloc(ctx().p(), len * std::mem::size_of::<T>(), &mut p) });
         HipColumn { ptr: p as *mut u32, len, _t: PhantomData }
     }
 }
 impl<T> Drop for HipColumn<T> {
-    fn drop(&mut self) { unsafe { sys::bfhip_free(ctx(), self.ptr as *mut c_void) }; }
+    fn drop(&mut self) { unsafe { sys::bfhip_free(ctx().p(), self.ptr as *mut c_void) }; }
 }
 impl<T> Clone for HipColumn<T> {
     fn clone(&self) -> Self {
         let c = Self::alloc(self.len);
         let host = self.download_words();
-        check(unsafe { sys::bfhip_upload(ctx(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
         c
     }
 }
 impl<T> HipColumn<T> {
     fn download_words(&self) -> Vec<u32> {
         let mut v = vec![0u32; self.len * Self::words_per_elem()];
-        check(unsafe { sys::bfhip_download(ctx(), v.as_mut_ptr() as *mut c_void, self.ptr as *const c_void, v.len() * 4) });
+        check(unsafe { sys::bfhip_download(ctx().p(), v.as_mut_ptr() as *mut c_void, self.ptr as *const c_void, v.len() * 4) });
         v
     }
 }
@@ -121,7 +128,7 @@ impl<T> HipColumn<T> {
 impl Column<BaseField> for HipColumn<BaseField> {
     fn zeros(len: usize) -> Self {
         let c = Self::alloc(len);
-        check(unsafe { sys::bfhip_memset_zero(ctx(), c.ptr as *mut c_void, len * 4) });
+        check(unsafe { sys::bfhip_memset_zero(ctx().p(), c.ptr as *mut c_void, len * 4) });
         c
     }
     unsafe fn uninitialized(len: usize) -> Self { Self::alloc(len) }
@@ -129,25 +136,25 @@ impl Column<BaseField> for HipColumn<BaseField> {
     fn len(&self) -> usize { self.len }
     fn at(&self, index: usize) -> BaseField {
         let (idx, mut out) = (index as u64, 0u32);
-        check(unsafe { sys::bfhip_gather(ctx(), self.ptr, &idx, 1, &mut out) });
+        check(unsafe { sys::bfhip_gather(ctx().p(), self.ptr, &idx, 1, &mut out) });
         BaseField::from_u32_unchecked(out)
     }
     fn set(&mut self, index: usize, value: BaseField) {
-        check(unsafe { sys::bfhip_upload(ctx(), self.ptr.add(index) as *mut c_void, &value.0 as *const u32 as *const c_void, 4) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), self.ptr.add(index) as *mut c_void, &value.0 as *const u32 as *const c_void, 4) });
     }
 }
 impl FromIterator<BaseField> for HipColumn<BaseField> {
     fn from_iter<I: IntoIterator<Item = BaseField>>(iter: I) -> Self {
         let host: Vec<u32> = iter.into_iter().map(|x| x.0).collect();
         let c = Self::alloc(host.len());
-        check(unsafe { sys::bfhip_upload(ctx(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
         c
     }
 }
 impl Column<Blake2sHash> for HipColumn<Blake2sHash> {
     fn zeros(len: usize) -> Self {
         let c = Self::alloc(len);
-        check(unsafe { sys::bfhip_memset_zero(ctx(), c.ptr as *mut c_void, len * 32) });
+        check(unsafe { sys::bfhip_memset_zero(ctx().p(), c.ptr as *mut c_void, len * 32) });
         c
     }
     unsafe fn uninitialized(len: usize) -> Self { Self::alloc(len) }
@@ -159,20 +166,20 @@ impl Column<Blake2sHash> for HipColumn<Blake2sHash> {
     fn at(&self, index: usize) -> Blake2sHash {
         let idx: Vec<u64> = (0..8).map(|k| (8 * index + k) as u64).collect();
         let mut out = [0u32; 8];
-        check(unsafe { sys::bfhip_gather(ctx(), self.ptr, idx.as_ptr(), 8, out.as_mut_ptr()) });
+        check(unsafe { sys::bfhip_gather(ctx().p(), self.ptr, idx.as_ptr(), 8, out.as_mut_ptr()) });
         let mut b = [0u8; 32];
         for (i, x) in out.iter().enumerate() { b[4 * i..4 * i + 4].copy_from_slice(&x.to_le_bytes()); }
         Blake2sHash(b)
     }
     fn set(&mut self, index: usize, value: Blake2sHash) {
-        check(unsafe { sys::bfhip_upload(ctx(), self.ptr.add(8 * index) as *mut c_void, value.0.as_ptr() as *const c_void, 32) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), self.ptr.add(8 * index) as *mut c_void, value.0.as_ptr() as *const c_void, 32) });
     }
 }
 impl FromIterator<Blake2sHash> for HipColumn<Blake2sHash> {
     fn from_iter<I: IntoIterator<Item = Blake2sHash>>(iter: I) -> Self {
         let host: Vec<u8> = iter.into_iter().flat_map(|h| h.0).collect();
         let c = Self::alloc(host.len() / 32);
-        check(unsafe { sys::bfhip_upload(ctx(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len()) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len()) });
         c
     }
 }
@@ -215,7 +222,7 @@ impl ColumnOps<BaseField> for HipBackend {
     /// `bfhip_bit_reverse` is out of place: permute into a fresh buffer and swap.
     fn bit_reverse_column(column: &mut Self::Column) {
         let dst = HipColumn::<BaseField>::alloc(column.len);
-        check(unsafe { sys::bfhip_bit_reverse(ctx(), column.ptr, dst.ptr, column.len.ilog2()) });
+        check(unsafe { sys::bfhip_bit_reverse(ctx().p(), column.ptr, dst.ptr, column.len.ilog2()) });
         *column = dst;
     }
 }
@@ -228,13 +235,13 @@ impl ColumnOps<Blake2sHash> for HipBackend {
     fn bit_reverse_column(_column: &mut Self::Column) { unimplemented!("hash columns are never bit-reversed on the prove path") }
 }
 impl FieldOps<BaseField> for HipBackend {
-    fn batch_inverse(column: &Self::Column, dst: &mut Self::Column) { check(unsafe { sys::bfhip_batch_inverse_m31(ctx(), column.ptr, dst.ptr, column.len) }); }
+    fn batch_inverse(column: &Self::Column, dst: &mut Self::Column) { check(unsafe { sys::bfhip_batch_inverse_m31(ctx().p(), column.ptr, dst.ptr, column.len) }); }
 }
 impl FieldOps<SecureField> for HipBackend {
     /// `LogupTraceGenerator::finalize_col`'s denominators (`memory/table.rs:513`).
     fn batch_inverse(column: &HipSecureColumn, dst: &mut HipSecureColumn) {
         let (s, d) = (column.ptrs(), dst.ptrs_mut());
-        check(unsafe { sys::bfhip_batch_inverse_qm31(ctx(), s.as_ptr(), d.as_ptr(), column.len()) });
+        check(unsafe { sys::bfhip_batch_inverse_qm31(ctx().p(), s.as_ptr(), d.as_ptr(), column.len()) });
     }
 }
 
@@ -258,7 +265,7 @@ impl PolyOps for HipBackend {
     }
     fn precompute_twiddles(coset: Coset) -> TwiddleTree<Self> {
         let (mut tw, mut itw, mut root_log) = (std::ptr::null(), std::ptr::null(), 0u32);
-        check(unsafe { sys::bfhip_twiddles(ctx(), &mut tw, &mut itw, &mut root_log) });
+        check(unsafe { sys::bfhip_twiddles(ctx().p(), &mut tw, &mut itw, &mut root_log) });
         assert!(coset.log_size() <= root_log, "context twiddle tree too small: create it with a larger max_log_domain");
         let t = HipTwiddles { tw, itw, root_log };
         TwiddleTree { root_coset: coset, twiddles: t.clone(), itwiddles: t }
@@ -271,26 +278,26 @@ impl PolyOps for HipBackend {
         let cols: Vec<_> = columns.into_iter().collect();
         let mut by_log: std::collections::BTreeMap<u32, Vec<*mut u32>> = Default::default();
         for c in &cols { by_log.entry(c.domain.log_size()).or_default().push(c.values.ptr); }
-        for (log, ptrs) in by_log { check(unsafe { sys::bfhip_interpolate(ctx(), ptrs.as_ptr(), ptrs.as_ptr(), ptrs.len() as u32, log, 0) }); }
+        for (log, ptrs) in by_log { check(unsafe { sys::bfhip_interpolate(ctx().p(), ptrs.as_ptr(), ptrs.as_ptr(), ptrs.len() as u32, log, 0) }); }
         cols.into_iter().map(|c| CirclePoly::new(c.values)).collect()
     }
     fn eval_at_point(poly: &CirclePoly<Self>, point: CirclePoint<SecureField>) -> SecureField {
         let (x, y) = (qm31_words(point.x), qm31_words(point.y));
         let p8 = [x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]];
         let mut out = [0u32; 4];
-        check(unsafe { sys::bfhip_eval_at_point(ctx(), poly.coeffs.ptr, poly.log_size(), 0, p8.as_ptr(), out.as_mut_ptr()) });
+        check(unsafe { sys::bfhip_eval_at_point(ctx().p(), poly.coeffs.ptr, poly.log_size(), 0, p8.as_ptr(), out.as_mut_ptr()) });
         SecureField::from_m31_array(out.map(BaseField::from_u32_unchecked))
     }
     fn extend(poly: &CirclePoly<Self>, log_size: u32) -> CirclePoly<Self> {
         let mut c = HipColumn::<BaseField>::zeros(1 << log_size);
         let host = poly.coeffs.download_words();
-        check(unsafe { sys::bfhip_upload(ctx(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
+        check(unsafe { sys::bfhip_upload(ctx().p(), c.ptr as *mut c_void, host.as_ptr() as *const c_void, host.len() * 4) });
         CirclePoly::new(c)
     }
     fn evaluate(poly: &CirclePoly<Self>, domain: CircleDomain, _tw: &TwiddleTree<Self>) -> CircleEvaluation<Self, BaseField, BitReversedOrder> {
         let out = HipColumn::<BaseField>::alloc(domain.size());
         let (src, dst) = ([poly.coeffs.ptr], [out.ptr]);
-        check(unsafe { sys::bfhip_evaluate(ctx(), src.as_ptr(), dst.as_ptr(), 1, poly.log_size(), domain.log_size(), 0) });
+        check(unsafe { sys::bfhip_evaluate(ctx().p(), src.as_ptr(), dst.as_ptr(), 1, poly.log_size(), domain.log_size(), 0) });
         CircleEvaluation::new(domain, out)
     }
     /// `tree_builder.commit(channel)` -> LDE by the blowup factor: one batched launch per size group.
@@ -298,7 +305,7 @@ impl PolyOps for HipBackend {
         let outs: Vec<HipColumn<BaseField>> = polys.iter().map(|p| HipColumn::alloc(1 << (p.log_size() + log_blowup_factor))).collect();
         let mut by_log: std::collections::BTreeMap<u32, (Vec<*mut u32>, Vec<*mut u32>)> = Default::default();
         for (p, o) in polys.iter().zip(&outs) { let e = by_log.entry(p.log_size()).or_default(); e.0.push(p.coeffs.ptr); e.1.push(o.ptr); }
-        for (log, (src, dst)) in by_log { check(unsafe { sys::bfhip_evaluate(ctx(), src.as_ptr(), dst.as_ptr(), src.len() as u32, log, log + log_blowup_factor, 0) }); }
+        for (log, (src, dst)) in by_log { check(unsafe { sys::bfhip_evaluate(ctx().p(), src.as_ptr(), dst.as_ptr(), src.len() as u32, log, log + log_blowup_factor, 0) }); }
         polys.iter().zip(outs).map(|(p, o)| CircleEvaluation::new(CanonicCoset::new(p.log_size() + log_blowup_factor).circle_domain(), o)).collect()
     }
 }
@@ -311,13 +318,13 @@ impl MerkleOps<Blake2sMerkleHasher> for HipBackend {
         let out = HipColumn::<Blake2sHash>::alloc(1 << log_size);
         let ptrs: Vec<*const u32> = columns.iter().map(|c| c.ptr as *const u32).collect();
         let prev = prev_layer.map_or(std::ptr::null(), |p| p.ptr as *const c_void);
-        check(unsafe { sys::bfhip_merkle_commit_layer(ctx(), log_size, prev, ptrs.as_ptr(), std::ptr::null(), ptrs.len() as u32, out.ptr as *mut c_void) });
+        check(unsafe { sys::bfhip_merkle_commit_layer(ctx().p(), log_size, prev, ptrs.as_ptr(), std::ptr::null(), ptrs.len() as u32, out.ptr as *mut c_void) });
         out
     }
 }
 impl AccumulationOps for HipBackend {
     fn accumulate(column: &mut SecureColumnByCoords<Self>, other: &SecureColumnByCoords<Self>) {
-        for k in 0..4 { check(unsafe { sys::bfhip_accumulate(ctx(), column.columns[k].ptr, other.columns[k].ptr, other.columns[k].len) }); }
+        for k in 0..4 { check(unsafe { sys::bfhip_accumulate(ctx().p(), column.columns[k].ptr, other.columns[k].ptr, other.columns[k].len) }); }
     }
     fn generate_secure_powers(felt: SecureField, n_powers: usize) -> Vec<SecureField> {
         std::iter::successors(Some(SecureField::from(BaseField::from(1))), |x| Some(*x * felt)).take(n_powers).collect()   // 103 values: host
@@ -338,7 +345,7 @@ impl QuotientOps for HipBackend {
         let mut out = SecureColumnByCoords::<Self> { columns: std::array::from_fn(|_| HipColumn::alloc(domain.size())) };
         let (ptrs, o) = (columns.iter().map(|c| c.values.ptr as *const u32).collect::<Vec<_>>(), coords_mut(&mut out));
         let rc = qm31_words(random_coeff);
-        check(unsafe { sys::bfhip_accumulate_quotients(ctx(), domain.log_size(), ptrs.as_ptr(), std::ptr::null(), ptrs.len() as u32, n_samples.as_ptr(), points.as_ptr(),
+        check(unsafe { sys::bfhip_accumulate_quotients(ctx().p(), domain.log_size(), ptrs.as_ptr(), std::ptr::null(), ptrs.len() as u32, n_samples.as_ptr(), points.as_ptr(),
                                                        values.as_ptr(), rc.as_ptr(), o.as_ptr()) });
         SecureEvaluation::new(domain, out)
     }
@@ -348,12 +355,12 @@ impl FriOps for HipBackend {
         let log = eval.len().ilog2();
         let mut out = SecureColumnByCoords::<Self> { columns: std::array::from_fn(|_| HipColumn::alloc(eval.len() / 2)) };
         let (s, d, a) = (coords(&eval.values), coords_mut(&mut out), qm31_words(alpha));
-        check(unsafe { sys::bfhip_fold_line(ctx(), s.as_ptr(), d.as_ptr(), log, a.as_ptr()) });
+        check(unsafe { sys::bfhip_fold_line(ctx().p(), s.as_ptr(), d.as_ptr(), log, a.as_ptr()) });
         LineEvaluation::new(eval.domain().double(), out)
     }
     fn fold_circle_into_line(dst: &mut LineEvaluation<Self>, src: &SecureEvaluation<Self, BitReversedOrder>, alpha: SecureField, _tw: &TwiddleTree<Self>) {
         let (d, s, a) = (coords_mut(&mut dst.values), coords(&src.values), qm31_words(alpha));
-        check(unsafe { sys::bfhip_fold_circle_into_line(ctx(), d.as_ptr(), s.as_ptr(), src.domain.log_size(), a.as_ptr()) });
+        check(unsafe { sys::bfhip_fold_circle_into_line(ctx().p(), d.as_ptr(), s.as_ptr(), src.domain.log_size(), a.as_ptr()) });
     }
     fn decompose(_eval: &SecureEvaluation<Self, BitReversedOrder>) -> (SecureEvaluation<Self, BitReversedOrder>, SecureField) {
         unimplemented!("only reached for column sizes outside the FRI log-size range; the reference's PcsConfig::default() never does")
@@ -362,7 +369,7 @@ impl FriOps for HipBackend {
 impl GrindOps<Blake2sChannel> for HipBackend {
     fn grind(channel: &Blake2sChannel, pow_bits: u32) -> u64 {
         let mut nonce = 0u64;
-        check(unsafe { sys::bfhip_grind(ctx(), channel.digest().0.as_ptr(), pow_bits, &mut nonce) });
+        check(unsafe { sys::bfhip_grind(ctx().p(), channel.digest().0.as_ptr(), pow_bits, &mut nonce) });
         nonce
     }
 }
@@ -404,7 +411,7 @@ impl<E: BrainfuckEval> ComponentProver<HipBackend> for FrameworkComponent<E> {
         let [mut accum] = evaluation_accumulator.columns([(log_size + 1, n_cons as usize)]);
         let coeffs: Vec<u32> = accum.random_coeff_powers.iter().rev().flat_map(|c| qm31_words(*c)).collect();
         let (lookup, sum, acc) = (self.lookup_words(), qm31_words(self.claimed_sum()), coords_mut(accum.col));
-        check(unsafe { sys::bfhip_eval_constraints(ctx(), E::COMPONENT, log_size, is_first, main.as_ptr(), std::ptr::null(), inter.as_ptr(), std::ptr::null(), lookup.as_ptr(),
+        check(unsafe { sys::bfhip_eval_constraints(ctx().p(), E::COMPONENT, log_size, is_first, main.as_ptr(), std::ptr::null(), inter.as_ptr(), std::ptr::null(), lookup.as_ptr(),
                                                    sum.as_ptr(), coeffs.as_ptr(), acc.as_ptr()) });
     }
 }
@@ -420,6 +427,6 @@ pub fn interaction_trace_evaluation(component: i32, log_size: u32, main_rows: &[
     let outs: Vec<HipColumn<BaseField>> = (0..4 * n_logup).map(|k| HipColumn::alloc(if k + 4 >= 4 * n_logup { rows * 16 } else { rows })).collect();
     let (src, dst): (Vec<*const u32>, Vec<*mut u32>) = (main_rows.iter().map(|c| c.ptr as *const u32).collect(), outs.iter().map(|c| c.ptr).collect());
     let mut sum = [0u32; 4];
-    check(unsafe { sys::bfhip_logup_generate(ctx(), component, log_size, src.as_ptr(), lookup.as_ptr(), dst.as_ptr(), sum.as_mut_ptr()) });
+    check(unsafe { sys::bfhip_logup_generate(ctx().p(), component, log_size, src.as_ptr(), lookup.as_ptr(), dst.as_ptr(), sum.as_mut_ptr()) });
     (outs, SecureField::from_m31_array(sum.map(BaseField::from_u32_unchecked)))
 }

@@ -11,6 +11,8 @@
 pub mod sys;
 /// stwo's backend trait surface (`Backend`, `ColumnOps`, `FieldOps`, `PolyOps`, `MerkleOps`, `QuotientOps`, `FriOps`, `AccumulationOps`, `GrindOps`,
 /// `ComponentProver`) over the FFI — for `prover::prove::<HipBackend, _>` at `mod.rs:732`.
+/// Never compiled (no toolchain, stwo not vendored): kept out of the default module tree behind the feature `stwo-backend`.
+#[cfg(feature = "stwo-backend")]
 #[path = "hip_backend.rs"]
 pub mod hip_backend;
 

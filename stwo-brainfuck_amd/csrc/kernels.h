@@ -209,7 +209,7 @@ void prev_row_copy(hipStream_t stream, u32* dst, const u32* src, u32 log_size);
 struct GatherReq { const u32* base; u64 index; u32 out_off; u32 n_words; };
 void gather_u32(hipStream_t stream, const GatherReq* d_req, u32 n, u32* d_out);
 void accumulate(hipStream_t stream, u32* dst, const u32* src, u32 n);
-struct AccumulateSizes { u32* dst[4]; const u32* src[8][4]; u32 log[8]; u32 n; };   // sources sorted by descending size, all <= 2^log of dst
+struct AccumulateSizes { u32* dst[4]; const u32* src[12][4]; u32 log[12]; u32 n; };   // <= 12 sources (13 components: at most 13 distinct sizes), sorted by descending size, all <= 2^log of dst
 void accumulate_sizes(hipStream_t stream, const AccumulateSizes& a);
 void batch_inverse_m31(hipStream_t stream, const u32* src, u32* dst, u32 n);
 void batch_inverse_qm31(hipStream_t stream, const u32* const src[4], u32* const dst[4], u32 n);

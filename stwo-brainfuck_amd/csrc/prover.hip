@@ -853,7 +853,7 @@ struct HipProver {
                 logs.push_back(log);
                 for (int w = 0; w < 4; w++) { DCol v; v.ptr = acc[log].c[w]; v.log_size = log; v.shift = 0; all_vals.push_back(v); }
             }
-            if (logs.size() > 9) throw HipError("composition: too many distinct sizes");
+            if (logs.size() > 13) throw HipError("composition: too many distinct sizes");
             fft_cols(true, all_vals, all_vals);
             AccumulateSizes as{};
             for (int w = 0; w < 4; w++) as.dst[w] = acc[logs[0]].c[w];

@@ -50,3 +50,14 @@ def test_random_program_proof_matches_oracle_row_group_constraint_kernel(ctx, pk
     log_max_rows = max(max(oracle.log_sizes(code, inp)[0]), 8)
     want, _, _ = oracle.prove(code, inp, log_max_rows=log_max_rows)
     assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=log_max_rows) == want
+
+
+def test_program_with_ten_distinct_component_sizes(ctx, pkg, oracle):
+    """Found by tools/fuzz_campaign.py persistent (seed 40402, round 3): 10 of the 13 components have distinct sizes, i.e. 10 composition
+    accumulators merged by ONE k_accumulate_sizes launch — a first version of that kernel's argument block held 9."""
+    code, inp, _ = random_program(40402, 6000, min_steps=300)
+    sizes = oracle.log_sizes(code, inp)[0]
+    assert len(set(sizes)) >= 10
+    lmr = max(sizes)
+    want, _, _ = oracle.prove(code, inp, log_max_rows=lmr)
+    assert pkg.prove_brainfuck(code, inp, ctx=ctx, log_max_rows=lmr) == want

@@ -323,6 +323,52 @@ def test_poseidon252_variant_on_a_2_to_22_row_trace(pkg, _oracle):
         _oracle.set_conventions(0, 0, 0, 0)
 
 
+@pytest.mark.single_conv
+def test_poseidon252_variant_on_a_2_to_24_row_trace_and_its_shard_group(pkg, _oracle):
+    """BASELINE configs 4/5 on the one GPU of the test box: the 2^24-domain-row synthetic trace under the Poseidon252MerkleChannel (one proof,
+    ~1.5 s), accepted by both verifiers, and the same trace proved by a 2-rank shard group (in-process transport) — the bytes must be equal.
+    (2^26 rows run in bench.py's `poseidon252` point; the 8-GPU runs are the driver's.)"""
+    import threading
+    code = "+" * 14 + "[>" + "+" * 4000 + "[>+<-]<-]"
+    conv = (0, 0, 0, 1)
+    pkg.set_default_conventions(*conv)
+    _oracle.set_conventions(*conv)
+    try:
+        c = pkg.Context(0, max_log_domain=26)
+        try:
+            tr = pkg.Trace(c, code, b"")
+            assert max(tr.log_sizes) == 24
+            proof, _ = tr.prove(24)
+            tr.close()
+        finally:
+            c.close()
+        assert pkg.verify_brainfuck(proof, 24) == (True, "")
+        ok, err = _oracle.verify(proof, 24)
+        assert ok, err
+        group = pkg.LocalGroup(2)
+        ctxs = [pkg.Context(0, max_log_domain=26) for _ in range(2)]
+        out, errors = [None, None], []
+
+        def run(r):
+            try:
+                ctxs[r].join_local_group(group, r)
+                t = pkg.Trace(ctxs[r], code, b"")
+                out[r] = t.prove(24)[0]
+                t.close()
+            except Exception as e:
+                errors.append(e)
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        for cx in ctxs:
+            cx.leave_group(); cx.close()
+        group.close()
+        assert not errors, errors
+        assert out[0] == proof and out[1] == proof
+    finally:
+        pkg.set_default_conventions(0, 0, 0, 0)
+        _oracle.set_conventions(0, 0, 0, 0)
+
+
 def test_bfprove_tool_prove_then_verify(tmp_path):
     """tools/bfprove.py: the prove / verify sub-commands of the reference's bin/brainfuck_prover.rs over the C ABI, proof file in between."""
     import subprocess, sys
