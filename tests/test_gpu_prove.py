@@ -425,3 +425,22 @@ def test_prove_entries_reject_null_arguments(pkg, ctx):
     assert L.bfhip_trace_create(ctx._h, None, None, ctypes.c_size_t(0), ctypes.byref(t), None, None, None, None) == -1
     assert L.bfhip_trace_create(ctx._h, b"+", None, ctypes.c_size_t(0), None, None, None, None, None) == -1
     assert L.bfhip_trace_column(ctx._h, None, 0, 0, None, ctypes.c_size_t(0), ctypes.byref(n)) == -1
+
+
+@pytest.mark.single_conv
+def test_overlap_modes_do_not_change_the_proof(pkg, oracle):
+    """bfhip_ctx_set_overlap: the two intra-proof overlaps (tree commitment on a partner stream beside the transforms of the smaller columns;
+    FRI first-layer tree level by level behind the quotient launches) reorder work across streams, never bytes. collatz at LOG_MAX_ROWS 21 has
+    trees of 2^22 leaves, large enough for both paths to engage."""
+    code = _prog("collatz.bf")
+    want, _, _ = oracle.prove(code, b"7\n", log_max_rows=21)
+    c = pkg.Context(0, max_log_domain=23)
+    try:
+        for mask in (0, 1, 2, 3, 0):
+            c.set_overlap(mask)
+            for _ in range(2):
+                assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want, f"overlap mask {mask}"
+        with pytest.raises(pkg.BfhipError):
+            c.set_overlap(4)
+    finally:
+        c.close()
