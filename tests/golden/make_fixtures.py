@@ -215,6 +215,25 @@ LOGUP_STRUCTURE = [
      "columns": [{"denominator_columns": [0, 1, 2, 3, 4, 5, 6], "numerators": [-1]}]},
 ]
 
+# The reference's 13 positive AIR tests (`test_*_constraints`): table of one component from a program run, logUp under LookupElements::dummy(),
+# `assert_constraints` on CanonicCoset(LOG_SIZE) passes. LOG_SIZE (a literal of each test) pins the table's padded size: 2^LOG_SIZE = 16 * rows.
+_C = "crates/brainfuck_prover/src/components/"
+AIR_POSITIVE = [
+    {"cite": _C + "memory/component.rs:163-212 (test_memory_constraints)", "component": 0, "code": "+>,<[>+.<-]", "input": [1], "log_size": 9},
+    {"cite": _C + "instruction/component.rs:164-213 (test_instruction_constraints)", "component": 1, "code": "+>,<[>+.<-]", "input": [1], "log_size": 9},
+    {"cite": _C + "program/component.rs:129-176 (test_program_constraints)", "component": 2, "code": "+>,<[>+.<-]", "input": [1], "log_size": 8},
+    {"cite": _C + "processor/component.rs:178-230 (test_processor_constraints)", "component": 3, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 9},
+    {"cite": _C + "processor/instructions/jump/jump_if_not_zero_component.rs:154-202 (test_jump_if_not_zero_constraints)", "component": 4, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 6},
+    {"cite": _C + "processor/instructions/jump/jump_if_zero_component.rs:154-202 (test_jump_if_zero_constraints)", "component": 5, "code": "[][]+[-]", "input": [], "log_size": 6},
+    {"cite": _C + "processor/instructions/input_component.rs:142-190 (test_input_instruction_constraints)", "component": 6, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 4},
+    {"cite": _C + "processor/instructions/left_component.rs:142-190 (test_left_instruction_constraints)", "component": 7, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 6},
+    {"cite": _C + "processor/instructions/minus_component.rs:144-192 (test_minus_instruction_constraints)", "component": 8, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 6},
+    {"cite": _C + "processor/instructions/output_component.rs:145-193 (test_output_instruction_constraints)", "component": 9, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 6},
+    {"cite": _C + "processor/instructions/plus_component.rs:145-193 (test_plus_instruction_constraints)", "component": 10, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 7},
+    {"cite": _C + "processor/instructions/right_component.rs:142-190 (test_right_instruction_constraints)", "component": 11, "code": "+++>,<[>+.<-]", "input": [1], "log_size": 6},
+    {"cite": _C + "processor/instructions/end_of_execution/component.rs:114-162 (test_end_of_execution_instruction_constraints)", "component": 12, "code": "++[-]+.", "input": [1], "log_size": 4},
+]
+
 vectors = {
     "compile": [  # crates/brainfuck_vm/src/compiler.rs:62-79
         {"code": "++>,<[>+.<-]", "expected": [43, 43, 62, 44, 60, 91, 13, 62, 43, 46, 60, 45, 93, 7]},
@@ -271,6 +290,7 @@ vectors = {
     "table_errors": TABLE_ERRORS,
     "logup_structure": LOGUP_STRUCTURE,
     "air_negative": AIR_NEGATIVE,
+    "air_positive": AIR_POSITIVE,
     # component log sizes measured for the bundled programs — SURVEY.md Appendix A.3 (derived from the reference's padding rules)
     "log_sizes": [
         {"program": "hello_kakarot.bf", "input": [], "steps": 651, "expected": [17, 14, 12, 14, 8, 4, 4, 10, 10, 9, 13, 11, 4]},

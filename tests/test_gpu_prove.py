@@ -10,6 +10,9 @@ PROGRAMS = [
     ("+++><[>+<-]", b""),            # mod.rs:835 test_proof_no_input
     ("++[-]+.", b""),                # mod.rs:849 test_proof_jump_middle_of_program
     ("++++++++++[>+++++++>++++++++++>+++>+<<<<-]>++.>+.+++++++..+++.>++.<<+++++++++++++++.>.+++.------.--------.>+.>.", b""),  # mod.rs:821 hello world
+    ("+>,<[>+.<-]", b"\x01"),        # memory/instruction/program component.rs test_*_constraints (tests/golden air_positive)
+    ("[][]+[-]", b""),               # jump_if_zero_component.rs:154 test_jump_if_zero_constraints
+    ("++[-]+.", b"\x01"),            # end_of_execution/component.rs:114 (an input byte that is never read)
 ]
 
 

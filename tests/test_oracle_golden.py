@@ -238,3 +238,17 @@ def test_host_side_agrees_with_the_oracle_on_unconstrained_programs(pkg, oracle)
     d = json.loads(r.stdout)
     assert r.returncode == 0 and d["ok"], d["problems"]
     assert d["programs"] > 2000 and d["compile_errors"] > 100 and d["run_errors"] > 100 and d["ran"] > 300 and d["tables_compared"] > 3000
+
+
+@pytest.mark.parametrize("v", V["air_positive"], ids=lambda v: v["cite"].split("(")[1].split(")")[0])
+def test_air_positive_cases_of_the_reference(oracle, host, v):
+    """The 13 `test_*_constraints` of the reference: the table of one component from the cited program run has 2^LOG_SIZE / 16 rows (LOG_SIZE is a
+    literal of each test), both table builders agree on it, and every constraint — the logUp ones included, under LookupElements::dummy() as the
+    reference draws them — vanishes on the whole trace domain."""
+    inp = bytes(v["input"])
+    rows = oracle.table(v["code"], inp, v["component"])
+    assert 16 * rows.shape[0] == 1 << v["log_size"]
+    _, trace = oracle.run(v["code"], inp)
+    assert np.array_equal(rows, host.table(trace, oracle.compile(v["code"]), v["component"]))
+    rc, bad_row, bad_c, value = oracle.assert_constraints_table(v["component"], rows, DUMMY_ELEMENTS)
+    assert rc == 0, (bad_row, bad_c, value)
