@@ -541,9 +541,9 @@ int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint
     }
     std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
     build_quotient_batches(samples, q_from_h(random_coeff_h), batches, entries);
+    quotient_entries_finish(batches.data(), batches.size(), entries.data(), descs.data());
     c.stage_checkpoint();
     QuotientArgs a{};
-    a.cols = n_cols ? c.stage(descs.data(), descs.size()) : nullptr;
     a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
     a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
     a.n_batches = (u32)batches.size(); a.log = log_size; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;

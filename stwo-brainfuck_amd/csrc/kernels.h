@@ -49,6 +49,18 @@ __device__ __forceinline__ g_u32p as_global(u32* p) { return (g_u32p)(unsigned l
 __device__ __forceinline__ uint4 ld16(g_cu32p p) { bf_u32x4 v = *(const BF_GLOBAL bf_u32x4*)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint4 ld16_stream(g_cu32p p) { bf_u32x4 v = __builtin_nontemporal_load((const BF_GLOBAL bf_u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void st16(g_u32p p, uint4 v) { bf_u32x4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, (BF_GLOBAL bf_u32x4*)p); }   // streamed: no reuse before eviction
+// Parameter tables written by the host before the launch and only read by the kernel (staged batches, entries, descriptors): address space 4
+// turns a load at a wave-uniform address into s_load (SGPR result, lgkmcnt) instead of a 64-lane flat_load that competes with the column
+// traffic for vmcnt and VGPRs.
+#define BF_CONSTANT __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ T ld_constant(const T* p) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "word-sized parameter blocks only");
+    T out;
+    const BF_CONSTANT u32* s = (const BF_CONSTANT u32*)(unsigned long long)p;
+#pragma unroll
+    for (u32 i = 0; i < sizeof(T) / 4; i++) reinterpret_cast<u32*>(&out)[i] = s[i];
+    return out;
+}
 // value of cell i of a column: 32-bit byte offset (columns hold < 2^30 cells) on the descriptor's base pointer
 __device__ __forceinline__ u32 ld_col(const ColDesc& d, u32 i) {
     const u32 byte_off = (i >> d.shift) << 2;
@@ -184,11 +196,14 @@ void broadcast16(hipStream_t stream, const u32* d_rows, u32* d_out, u32 n_cells)
 // quotient.hip
 struct EvalJob { const u32* coeffs; u32 log_n; u32 point; u32 factor_shift; u32 partial_off; u32 out_idx; u32 pad_; };   // result -> out[out_idx]
 void eval_at_points(hipStream_t stream, const EvalJob* d_jobs, u32 n_jobs, u32 total_partials, const void* d_factors, void* d_partials, void* d_out);
-struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; C31 kden; u32 pad_; };   // kden = prx * piy - pry * pix
-struct QuotientEntry { Q31 c; u32 col; u32 pad_[3]; };
+struct QuotientBatch { C31 prx, pry, pix, piy; Q31 a_sum, b_sum, batch_coeff; u32 n_cols; C31 kden; u32 n_full; };   // kden = prx * piy - pry * pix; n_full: see QuotientEntry
+// One sampled column of a batch: its constant and where its cells are (cell of row i = ptr[i >> shift], shift 0 or >= 2). Within a batch the
+// entries with shift == 0 come first (QuotientBatch::n_full of them): quotient_entries_finish orders them and fills ptr / shift from `col`.
+struct QuotientEntry { Q31 c; const u32* ptr; u32 shift; u32 col; };
+void quotient_entries_finish(QuotientBatch* batches, size_t n_batches, QuotientEntry* entries, const ColDesc* cols);
 // row0 / n_rows: range of rows to compute (n_rows == 0: all 2^log rows; both multiples of 4); out pointers may be virtual bases
 // block0: first workgroup of this size group within the one launch that covers all of them (set by quotient_groups_layout)
-struct QuotientArgs { const ColDesc* cols; const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; u32 row0, n_rows; u32 block0, pad_; };
+struct QuotientArgs { const QuotientBatch* batches; const QuotientEntry* entries; u32 n_batches; u32 log; const u32* tw; u32 tw_total; u32* out[4]; u32 row0, n_rows; u32 block0, pad_; };
 // every size group of a proof in one launch: fill h_groups, call quotient_groups_layout (sets block0, returns the grid size), copy the table
 // to device memory the stream can read, launch
 u32 quotient_groups_layout(QuotientArgs* h_groups, u32 n_groups);

@@ -974,6 +974,7 @@ struct HipProver {
             }
             std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
             build_quotient_batches(samples, random_coeff, batches, entries);
+            quotient_entries_finish(batches.data(), batches.size(), entries.data(), descs.data());
             // shard group: the quotient of a row-sharded size is computed for this rank's row range only (every column of the group is
             // either complete or row-sharded over the same range)
             const bool sl = slice_log(log);
@@ -982,7 +983,6 @@ struct HipProver {
             QuotientArgs a{};
             if (sl) { a.row0 = (u32)slice_first(log); a.n_rows = (u32)slice_cells(log); }
             for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && flat[k].col.shift == 0) throw HipError("quotients: inconsistent row-sharding in a size group");
-            a.cols = c.stage(descs.data(), descs.size());
             a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
             a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
             a.n_batches = (u32)batches.size(); a.log = log; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;

@@ -2,6 +2,7 @@
 // Replaces stwo `PolyOps::eval_at_point`, `QuotientOps::accumulate_quotients`, `FriOps::{fold_circle_into_line, fold_line}` and
 // the column reads of the Merkle/FRI decommitment, all reached from prover::prove at
 // crates/brainfuck_prover/src/brainfuck_air/mod.rs:732 (CommitmentSchemeProver::prove_values).
+#include <algorithm>
 #include "kernels.h"
 #include <stdexcept>
 
@@ -157,33 +158,74 @@ __global__ void __launch_bounds__(256) k_quotients(const QuotientArgs* __restric
     Q31 acc[4] = {q_zero(), q_zero(), q_zero(), q_zero()};
     u32 e = 0;
     for (u32 b = 0; b < a.n_batches; b++) {
-        const QuotientBatch qb = a.batches[b];
-        // numerators sum_k c_k * f_k(row): 64-bit dot products with lazy reduction (m31.h: m_fold / m_canon), folded every third column;
-        // columns stored once per 4+ rows go into one accumulator shared by the lane's 4 rows
+        const QuotientBatch qb = ld_constant(a.batches + b);
+        // numerators sum_k c_k * f_k(row): 64-bit dot products with lazy reduction (m31.h: m_fold / m_canon). Three products of < 2^62 fit on
+        // top of a folded accumulator (< 2^34), so the columns are taken three at a time: the loads of the NEXT three are issued before the
+        // products of the current three (the loop is latency-bound otherwise: entry -> pointer -> cell is one dependent chain per column and
+        // only the 5 resident waves overlap them). A batch lists its full-size columns first (n_full, one 16-byte access for the lane's 4
+        // rows), then the columns stored once per 4+ rows, which go into one accumulator shared by the lane's 4 rows.
         u64 n64[4][4], s64[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { n64[r][0] = 0; n64[r][1] = 0; n64[r][2] = 0; n64[r][3] = 0; }
         s64[0] = 0; s64[1] = 0; s64[2] = 0; s64[3] = 0;
-        u32 pending = 0;
-        for (u32 k = 0; k < qb.n_cols; k++, e++) {
-            const QuotientEntry qe = a.entries[e];
-            ColDesc cd = a.cols[qe.col];
-            if (pending == 3) {
+        const QuotientEntry* ent = a.entries + e;
+        e += qb.n_cols;
+        const u32 nf = qb.n_full, nr = qb.n_cols - qb.n_full;
+        // Two buffers of three columns, used in turn: the loads into one are in flight during the products of the other. The loads are
+        // unconditional (indices past the end re-read the last column and are not used): a load that is only issued on some paths makes the
+        // wait before the products a wait for everything.
+        if (nf) {
+            uint4 A[3], B[3];
+            const u32 last = nf - 1;
+            auto load3 = [&](uint4 (&buf)[3], u32 k) {
+#pragma unroll
+                for (u32 j = 0; j < 3; j++) buf[j] = ld16(as_global(ld_constant(&ent[min(k + j, last)].ptr)) + row0);
+            };
+            auto mac3 = [&](const uint4 (&buf)[3], u32 k) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) { n64[r][0] = m_fold(n64[r][0]); n64[r][1] = m_fold(n64[r][1]); n64[r][2] = m_fold(n64[r][2]); n64[r][3] = m_fold(n64[r][3]); }
-                s64[0] = m_fold(s64[0]); s64[1] = m_fold(s64[1]); s64[2] = m_fold(s64[2]); s64[3] = m_fold(s64[3]);
-                pending = 0;
-            }
-            pending++;
-            const u32 c0 = qe.c.a.a, c1 = qe.c.a.b, c2 = qe.c.b.a, c3 = qe.c.b.b;
-            if (cd.shift == 0) {
-                const uint4 v = ld16(as_global(cd.ptr) + row0);
-                const u32 vr[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int r = 0; r < 4; r++) { n64[r][0] += (u64)c0 * vr[r]; n64[r][1] += (u64)c1 * vr[r]; n64[r][2] += (u64)c2 * vr[r]; n64[r][3] += (u64)c3 * vr[r]; }
-            } else {
-                const u32 v = ld_col(cd, row0);            // shift >= 2: the 4 rows share one stored cell
-                s64[0] += (u64)c0 * v; s64[1] += (u64)c1 * v; s64[2] += (u64)c2 * v; s64[3] += (u64)c3 * v;
+                for (u32 j = 0; j < 3; j++) {
+                    if (k + j < nf) {
+                        const Q31 cc = ld_constant(&ent[k + j].c);
+                        const u32 vr[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
+#pragma unroll
+                        for (int r = 0; r < 4; r++) { n64[r][0] += (u64)cc.a.a * vr[r]; n64[r][1] += (u64)cc.a.b * vr[r]; n64[r][2] += (u64)cc.b.a * vr[r]; n64[r][3] += (u64)cc.b.b * vr[r]; }
+                    }
+                }
+            };
+            load3(A, 0);
+            for (u32 k = 0; k < nf; k += 6) {
+                load3(B, k + 3);
+                mac3(A, k);
+                load3(A, k + 6);
+                mac3(B, k + 3);
+            }
+        }
+        if (nr) {
+            const QuotientEntry* er = ent + nf;
+            u32 A[3], B[3];
+            const u32 last = nr - 1;
+            auto load3 = [&](u32 (&buf)[3], u32 k) {
+#pragma unroll
+                for (u32 j = 0; j < 3; j++) { const u32 i = min(k + j, last); buf[j] = as_global(ld_constant(&er[i].ptr))[row0 >> ld_constant(&er[i].shift)]; }
+            };
+            auto mac3 = [&](const u32 (&buf)[3], u32 k) {
+                s64[0] = m_fold(s64[0]); s64[1] = m_fold(s64[1]); s64[2] = m_fold(s64[2]); s64[3] = m_fold(s64[3]);
+#pragma unroll
+                for (u32 j = 0; j < 3; j++) {
+                    if (k + j < nr) {
+                        const Q31 cc = ld_constant(&er[k + j].c);
+                        s64[0] += (u64)cc.a.a * buf[j]; s64[1] += (u64)cc.a.b * buf[j]; s64[2] += (u64)cc.b.a * buf[j]; s64[3] += (u64)cc.b.b * buf[j];
+                    }
+                }
+            };
+            load3(A, 0);
+            for (u32 k = 0; k < nr; k += 6) {
+                load3(B, k + 3);
+                mac3(A, k);
+                load3(A, k + 6);
+                mac3(B, k + 3);
             }
         }
         // line part A y + B for y = +yv (rows 0, 3) and y = -yv (rows 1, 2)
@@ -217,6 +259,14 @@ __global__ void __launch_bounds__(256) k_quotients(const QuotientArgs* __restric
     *reinterpret_cast<uint4*>(a.out[1] + row0) = make_uint4(acc[0].a.b, acc[1].a.b, acc[2].a.b, acc[3].a.b);
     *reinterpret_cast<uint4*>(a.out[2] + row0) = make_uint4(acc[0].b.a, acc[1].b.a, acc[2].b.a, acc[3].b.a);
     *reinterpret_cast<uint4*>(a.out[3] + row0) = make_uint4(acc[0].b.b, acc[1].b.b, acc[2].b.b, acc[3].b.b);
+}
+void quotient_entries_finish(QuotientBatch* batches, size_t n_batches, QuotientEntry* entries, const ColDesc* cols) {
+    for (size_t b = 0; b < n_batches; b++) {
+        QuotientEntry* first = entries; QuotientEntry* last = entries + batches[b].n_cols;
+        for (QuotientEntry* q = first; q != last; q++) { q->ptr = cols[q->col].ptr; q->shift = cols[q->col].shift; }
+        batches[b].n_full = (u32)(std::stable_partition(first, last, [](const QuotientEntry& q) { return q.shift == 0; }) - first);
+        entries = last;
+    }
 }
 // h_groups: host copy of the table (block0 is filled in here BEFORE the caller stages it: call quotient_groups_layout first)
 u32 quotient_groups_layout(QuotientArgs* h_groups, u32 n_groups) {
