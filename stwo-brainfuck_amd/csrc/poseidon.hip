@@ -3,8 +3,9 @@
 // starknet-crypto's `poseidon_hash_many`. node(i) = poseidon_hash_many([left, right]? ++ blocks), a block = 8 M31 values of the
 // layer's columns packed as w = w * 2^31 + v (zero padded to a multiple of 8).
 //
-// Arithmetic: the Stark field p = 2^251 + 17 * 2^192 + 1, 8 x 32-bit limbs, Montgomery form with R = 2^256. p = 1 (mod 2^32), so the
-// Montgomery factor of every CIOS step is m = -t0 and m * p touches only limbs 0, 6, 7. One Hades permutation (width 3, x^3 S-box,
+// Arithmetic: the Stark field p = 2^251 + 17 * 2^192 + 1, Montgomery form with R = 2^261: products on 9 limbs of 29 bits (one u64
+// accumulator per column, no carry instructions; p = 1 (mod 2^29) and m * p touches only columns i, i + 6, i + 8), the linear layer on
+// 8 x 32-bit words (poseidon_dev.h). One Hades permutation (width 3, x^3 S-box,
 // 4 full + 83 partial + 4 full rounds, MDS [[3,1,1],[1,-1,1],[1,1,-2]]) is 214 field multiplications ≈ 90 k lane-ops: this hasher
 // is ~90x more VALU work per 64 hashed bytes than Blake2s — firmly VALU-bound. The permutation is pinned by the public Hades([0,0,0])
 // known-answer vector (tests/test_gpu_poseidon.py); the node layout is recalled from stwo (unpinned).
@@ -17,25 +18,23 @@
 
 namespace bf {
 
-// consts layout in device memory: P[8], R1[8], R2[8], ARK[273][8]
 // Replication-aware and range-aware like k_merkle_layer (merkle.hip): node i is stored at slot i >> out_shift, its children at
 // (2i) >> prev_shift and (2i + 1) >> prev_shift; [first, first + n_stored) is the range of stored slots this launch computes (the whole
-// layer, or one rank's share of it in a shard group).
-__global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__ out, const u32* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
+// layer, or one rank's share of it in a shard group). consts: the PoseidonConsts block (poseidon_dev.h).
+__global__ void __launch_bounds__(128, 4) k_merkle_layer_poseidon(u32* __restrict__ out, const u32* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols, u32 n_stored,
                                                               u32 out_shift, u32 prev_shift, u32 first, const u32* __restrict__ consts) {
     u32 st = blockIdx.x * blockDim.x + threadIdx.x;
     if (st >= n_stored) return;
     st += first;
     const u32 i = st << out_shift;          // representative node of this stored slot
-    const u32* P = consts; const u32* R1 = consts + 8; const u32* R2p = consts + 16; const u32* ark = consts + 24;
-    Fe R2 = fe_load_const(R2p);
-    Sponge sp; sp.init(ark, P, R1);
+    const PoseidonConsts pc(consts);
+    Sponge sp(pc);
     if (prev) {
         const size_t cl = ((size_t)2 * i) >> prev_shift, cr = ((size_t)2 * i + 1) >> prev_shift;
         Fe l, r;
         for (int k = 0; k < 8; k++) { l.l[k] = prev[8 * cl + k]; r.l[k] = prev[8 * cr + k]; }
-        sp.absorb(fe_mul(l, R2, P));        // canonical -> Montgomery
-        sp.absorb(fe_mul(r, R2, P));
+        sp.absorb(f9_from_canonical(l, pc));
+        sp.absorb(f9_from_canonical(r, pc));
     }
     for (u32 c0 = 0; c0 < ncols; c0 += 8) {
         // w = sum_k v_k * 2^(31 * (7 - k)): value k occupies bits [31 (7-k), 31 (8-k))  (< 2^248 < p, no reduction needed)
@@ -48,24 +47,20 @@ __global__ void __launch_bounds__(128) k_merkle_layer_poseidon(u32* __restrict__
             w.l[limb] |= v << off;
             if (off > 1 && limb + 1 < 8) w.l[limb + 1] |= v >> (32 - off);
         }
-        sp.absorb(fe_mul(w, R2, P));
+        sp.absorb(f9_from_canonical(w, pc));
     }
-    Fe h = sp.finish();
-    Fe one_plain; for (int k = 0; k < 8; k++) one_plain.l[k] = k == 0 ? 1u : 0u;
-    h = fe_mul(h, one_plain, P);            // Montgomery -> canonical
+    const Fe h = f9_to_canonical(sp.finish(), pc);
     for (int k = 0; k < 8; k++) out[(size_t)8 * st + k] = h.l[k];
 }
 
 // Test hook: one Hades permutation of 3 canonical field elements (24 words in, 24 words out).
 __global__ void k_hades_once(const u32* __restrict__ in, u32* __restrict__ out, const u32* __restrict__ consts) {
     if (threadIdx.x || blockIdx.x) return;
-    const u32* P = consts; const u32* R2p = consts + 16; const u32* ark = consts + 24;
-    Fe R2 = fe_load_const(R2p);
-    Fe s[3];
-    for (int k = 0; k < 3; k++) { Fe x; for (int i = 0; i < 8; i++) x.l[i] = in[8 * k + i]; s[k] = fe_mul(x, R2, P); }
-    hades(s, ark, P);
-    Fe one_plain; for (int k = 0; k < 8; k++) one_plain.l[k] = k == 0 ? 1u : 0u;
-    for (int k = 0; k < 3; k++) { Fe y = fe_mul(s[k], one_plain, P); for (int i = 0; i < 8; i++) out[8 * k + i] = y.l[i]; }
+    const PoseidonConsts pc(consts);
+    F9 s[3];
+    for (int k = 0; k < 3; k++) { Fe x; for (int i = 0; i < 8; i++) x.l[i] = in[8 * k + i]; s[k] = f9_from_canonical(x, pc); }
+    hades(s, pc.table);
+    for (int k = 0; k < 3; k++) { const Fe y = f9_to_canonical(s[k], pc); for (int i = 0; i < 8; i++) out[8 * k + i] = y.l[i]; }
 }
 
 static u32* g_poseidon_consts[64] = {nullptr};   // per device; tiny (8.8 KB each), kept for the life of the process
@@ -76,8 +71,9 @@ static const u32* poseidon_consts() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) throw std::runtime_error("hipGetDevice(poseidon constants)");
     if (!g_poseidon_consts[dev]) {
         std::vector<u32> h;
-        h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_R1, POSEIDON_R1 + 8); h.insert(h.end(), POSEIDON_R2, POSEIDON_R2 + 8);
-        for (int r = 0; r < 273; r++) h.insert(h.end(), POSEIDON_ARK[r], POSEIDON_ARK[r] + 8);
+        h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_DEV_R1, POSEIDON_DEV_R1 + 9); h.insert(h.end(), POSEIDON_DEV_R2, POSEIDON_DEV_R2 + 9);
+        for (int r = 0; r < 91; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
+        if (h.size() != POSEIDON_CONSTS_WORDS) throw std::runtime_error("poseidon constants: layout mismatch");
         u32* p = nullptr;
         if (hipMalloc((void**)&p, h.size() * sizeof(u32)) != hipSuccess) throw std::runtime_error("hipMalloc(poseidon constants)");
         if (hipMemcpy(p, h.data(), h.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); throw std::runtime_error("hipMemcpy(poseidon constants)"); }

@@ -1,138 +1,57 @@
 // Device-side Stark-field (felt252) arithmetic, Hades permutation and the Poseidon sponge for gfx950 — shared by poseidon.hip (Merkle
 // layers of the Poseidon252 variant) and tools/ubench_poseidon.hip (register-only rate of the same code).
-// p = 2^251 + 17 * 2^192 + 1, 8 x 32-bit limbs, Montgomery form with R = 2^256. p = 1 (mod 2^32), so the Montgomery factor of every CIOS
-// step is m = -t0 and m * p touches only limbs 0, 6, 7.
+// p = 2^251 + 17 * 2^192 + 1. Inside the kernels an element is 9 limbs of 29 bits (F9) in Montgomery form with R = 2^261 = 2^(9*29);
+// the 8 x 32-bit word form (Fe) exists only where hashes and packed column values enter and leave.
+//
+// Why 29-bit limbs. A limb product is < 2^58 (< 2^60 for the lazily added operands below) and a column of the 9 x 9 product has at most
+// 9 of them, so a whole column — products, the two reduction terms and the carry of the column below — is one u64 accumulator fed by
+// v_mad_u64_u32 with no carry instruction at all; with 32-bit limbs every mad needs a v_addc into a third word (64 extra instructions per
+// product) and the reduction has to chase carries across words. The linear layer gains as much: limb-wise additions have no carry chain
+// (on gfx950 a v_addc that consumes the VCC of the previous one costs a wait state, so a 256-bit add is 16 issue slots, not 8), small
+// multiples and differences are formed per limb, and one 8-step carry sweep per output restores the limb bound.
+// tools/ubench_poseidon.hip: 490 M permutations/s with 8 x 32-bit limbs -> see DESIGN.md §9 for the 9 x 29 figures.
 #pragma once
 #include "m31.h"
 
 namespace bf {
 
-struct Fe { u32 l[8]; };
+struct Fe { u32 l[8]; };          // 256-bit little-endian words
+struct F9 { u32 l[9]; };          // 29-bit limbs: "normalised" = l[0..7] < 2^29; l[8] holds bits 232 and up
+
+static constexpr u32 M29 = (1u << 29) - 1;
+static constexpr u32 F9_C6 = 17u << 18;      // p = 1 + F9_C6 * 2^(29*6) + 2^19 * 2^(29*8)
+// round-constant table: per round 6 x 9 words — K0, K1, K2 (added to the S-box inputs; K0 = K1 = 0 in a partial round, whose constants for
+// elements 0 and 1 are folded into L) and L0, L1, L2 (added by the linear layer: folded constants + the multiples of p, spread over the
+// limbs, that keep every limb-wise difference and the reduction non-negative) — tools/gen_poseidon_constants.py
+static constexpr u32 F9_ROUND_WORDS = 54;
 
 __device__ __forceinline__ Fe fe_load_const(const u32* p) { Fe r; for (int i = 0; i < 8; i++) r.l[i] = p[i]; return r; }
+__device__ __forceinline__ F9 f9_load_const(const u32* p) { F9 r; for (int i = 0; i < 9; i++) r.l[i] = p[i]; return r; }
+__device__ __forceinline__ F9 f9_zero() { F9 r; for (int i = 0; i < 9; i++) r.l[i] = 0; return r; }
 
-__device__ __forceinline__ Fe fe_add(const Fe& a, const Fe& b, const u32* __restrict__ P) {
-    Fe r; u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)a.l[i] + b.l[i]; r.l[i] = (u32)c; c >>= 32; }
-    Fe s; u64 br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u64 d = (u64)r.l[i] - P[i] - br; s.l[i] = (u32)d; br = d >> 63; }
-    return br ? r : s;
-}
-__device__ __forceinline__ Fe fe_sub(const Fe& a, const Fe& b, const u32* __restrict__ P) {
-    Fe r; u64 br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { u64 d = (u64)a.l[i] - b.l[i] - br; r.l[i] = (u32)d; br = d >> 63; }
-    if (br) { u64 c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { c += (u64)r.l[i] + P[i]; r.l[i] = (u32)c; c >>= 32; } }
+__device__ __forceinline__ F9 to_f9(const Fe& a) {
+    F9 r;
+    r.l[0] = a.l[0] & M29;
+    r.l[1] = __builtin_amdgcn_alignbit(a.l[1], a.l[0], 29) & M29;
+    r.l[2] = __builtin_amdgcn_alignbit(a.l[2], a.l[1], 26) & M29;
+    r.l[3] = __builtin_amdgcn_alignbit(a.l[3], a.l[2], 23) & M29;
+    r.l[4] = __builtin_amdgcn_alignbit(a.l[4], a.l[3], 20) & M29;
+    r.l[5] = __builtin_amdgcn_alignbit(a.l[5], a.l[4], 17) & M29;
+    r.l[6] = __builtin_amdgcn_alignbit(a.l[6], a.l[5], 14) & M29;
+    r.l[7] = __builtin_amdgcn_alignbit(a.l[7], a.l[6], 11) & M29;
+    r.l[8] = a.l[7] >> 8;
     return r;
 }
-// ---- lazy (weakly reduced) arithmetic used by the Hades permutation ---------------------------------------------------------------------
-// The 8 limbs hold 256 bits and p < 2^251.0001, so sums of up to 15 p fit. State elements are kept in [0, 2p) ("weak form") between rounds,
-// the additions of the linear layer are plain 256-bit additions, and one cheap weak reduction per output replaces twelve
-// compare-and-subtract modular additions per round. The Montgomery product needs a * b < p * 2^256, i.e. operands up to 5 p, and returns
-// a value below a * b / 2^256 + p < 2 p without a final subtraction. Only the squeezed hash is brought to canonical form.
-
-// 96-bit multiply-accumulate (hi : lo) += sum a_i * b_i for one column of the product: per term v_mad_u64_u32 adds the 64-bit product into `lo`
-// and leaves the carry in VCC, one v_addc_co_u32 folds it into `hi` — two instructions per limb product. One asm statement per COLUMN:
-// the compiler pads every asm statement with an s_nop, and its own u64 formulation of a carry-save row takes three to four
-// instructions plus register moves per product.
-#define BF_MAC(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-#define BF_MAC_OUT : "+v"(lo), "+v"(hi)
-__device__ __forceinline__ void mac_col(u64& lo, u32& hi, u32 a0, u32 b0) { asm(BF_MAC("%2", "%3") BF_MAC_OUT : "v"(a0), "v"(b0) : "vcc"); }
-__device__ __forceinline__ void mac_col(u64& lo, u32& hi, u32 a0, u32 b0, u32 a1, u32 b1) {
-    asm(BF_MAC("%2", "%3") BF_MAC("%4", "%5") BF_MAC_OUT : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
-}
-__device__ __forceinline__ void mac_col(u64& lo, u32& hi, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2) {
-    asm(BF_MAC("%2", "%3") BF_MAC("%4", "%5") BF_MAC("%6", "%7") BF_MAC_OUT : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2) : "vcc");
-}
-__device__ __forceinline__ void mac_col(u64& lo, u32& hi, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2, u32 a3, u32 b3) {
-    asm(BF_MAC("%2", "%3") BF_MAC("%4", "%5") BF_MAC("%6", "%7") BF_MAC("%8", "%9") BF_MAC_OUT : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3) : "vcc");
-}
-#undef BF_MAC_OUT
-// column K of a * b: products a_i * b_(K - i), i in [max(0, K - 7), min(7, K)], in groups of at most four per asm statement
-template <int K> __device__ __forceinline__ void comba_col(u64& lo, u32& hi, const Fe& a, const Fe& b) {
-    constexpr int i0 = K < 8 ? 0 : K - 7, i1 = K < 8 ? K : 7, n = i1 - i0 + 1;
-    constexpr int n4 = n >= 4 ? 4 : n;
-    if constexpr (n4 == 1) mac_col(lo, hi, a.l[i0], b.l[K - i0]);
-    else if constexpr (n4 == 2) mac_col(lo, hi, a.l[i0], b.l[K - i0], a.l[i0 + 1], b.l[K - i0 - 1]);
-    else if constexpr (n4 == 3) mac_col(lo, hi, a.l[i0], b.l[K - i0], a.l[i0 + 1], b.l[K - i0 - 1], a.l[i0 + 2], b.l[K - i0 - 2]);
-    else mac_col(lo, hi, a.l[i0], b.l[K - i0], a.l[i0 + 1], b.l[K - i0 - 1], a.l[i0 + 2], b.l[K - i0 - 2], a.l[i0 + 3], b.l[K - i0 - 3]);
-    constexpr int r = n - n4, j0 = i0 + n4;      // remaining products of the column (at most four)
-    if constexpr (r == 1) mac_col(lo, hi, a.l[j0], b.l[K - j0]);
-    else if constexpr (r == 2) mac_col(lo, hi, a.l[j0], b.l[K - j0], a.l[j0 + 1], b.l[K - j0 - 1]);
-    else if constexpr (r == 3) mac_col(lo, hi, a.l[j0], b.l[K - j0], a.l[j0 + 1], b.l[K - j0 - 1], a.l[j0 + 2], b.l[K - j0 - 2]);
-    else if constexpr (r == 4) mac_col(lo, hi, a.l[j0], b.l[K - j0], a.l[j0 + 1], b.l[K - j0 - 1], a.l[j0 + 2], b.l[K - j0 - 2], a.l[j0 + 3], b.l[K - j0 - 3]);
-}
-template <int K> __device__ __forceinline__ void comba_cols(u32 (&T)[16], u64& lo, u32& hi, const Fe& a, const Fe& b) {
-    comba_col<K>(lo, hi, a, b);
-    T[K] = (u32)lo; lo = (lo >> 32) | ((u64)hi << 32); hi = 0;
-    if constexpr (K < 14) comba_cols<K + 1>(T, lo, hi, a, b);
-}
-// Montgomery product a * b * 2^-256 mod p in weak form: operands < 5 p (a * b < p * 2^256), result < 2 p.
-// Product scanning (Comba) for the 512-bit product, then one reduction sweep: p = 1 + 17 * 2^192 + 2^251 = 1 (mod 2^32), so the factor of step
-// i is m_i = -T'[i] and m_i * p only (a) zeroes limb i, leaving a carry that is simply "some limb up to i was non-zero", and (b) adds
-// 17 m_i at limb i + 6 and m_i * 2^27 across limbs i + 7, i + 8.
-__device__ __forceinline__ Fe fe_mul_weak(const Fe& a, const Fe& b) {
-    u32 T[16];
-    u64 lo = 0; u32 hi = 0;
-    comba_cols<0>(T, lo, hi, a, b);
-    T[15] = (u32)lo;
-    u32 A[8], B[8], C[8];          // what m_i * p adds at limbs i + 6, i + 7, i + 8
-    auto terms = [&](int i, u32 m) { const u64 m17 = (u64)m * 17u; A[i] = (u32)m17; B[i] = (u32)(m17 >> 32) | (m << 27); C[i] = m >> 5; };
-    u32 nz = 0, c = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { terms(i, 0u - (T[i] + c)); nz |= T[i]; c = nz ? 1u : 0u; }
+__device__ __forceinline__ Fe from_f9(const F9& a) {       // normalised, a.l[8] < 2^24
     Fe r;
-#pragma unroll
-    for (int k = 6; k < 16; k++) {
-        // limb k = T[k] + A[k-6] + B[k-7] + C[k-8] + carry; C and the carry are small (27 bits + a few units): pre-added without overflow
-        u32 small = c + (k >= 8 ? C[k - 8] : 0u);
-        u32 c1 = 0, c2 = 0, c3 = 0;
-        u32 v = T[k];
-        if (k - 6 < 8) v = __builtin_addc(v, A[k - 6], 0u, &c1);
-        if (k >= 7 && k - 7 < 8) v = __builtin_addc(v, B[k - 7], 0u, &c2);
-        v = __builtin_addc(v, small, 0u, &c3);
-        c = c1 + c2 + c3;
-        if (k < 8) { terms(k, 0u - v); c += v ? 1u : 0u; }     // limbs 6, 7 are still reduction steps: zero them, carry "was non-zero"
-        else r.l[k - 8] = v;
-    }
-    return r;
-}
-// [0, 2^255) -> [0, 2 p): subtract (q - 1) p with q = x >> 251 (the estimate q p may exceed x by a little, (q - 1) p never does)
-__device__ __forceinline__ Fe fe_weak_reduce(const Fe& x) {
-    const u32 q = x.l[7] >> 27;
-    const u32 k = q ? q - 1 : 0u;
-    Fe r; u32 br = 0;
-    r.l[0] = __builtin_subc(x.l[0], k, 0u, &br);
-#pragma unroll
-    for (int i = 1; i < 6; i++) r.l[i] = __builtin_subc(x.l[i], 0u, br, &br);
-    r.l[6] = __builtin_subc(x.l[6], 17u * k, br, &br);
-    r.l[7] = __builtin_subc(x.l[7], k << 27, br, &br);
-    return r;
-}
-__device__ __forceinline__ Fe add256(const Fe& a, const Fe& b) {
-    Fe r; u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = __builtin_addc(a.l[i], b.l[i], c, &c);
-    return r;
-}
-__device__ __forceinline__ Fe sub256(const Fe& a, const Fe& b) {
-    Fe r; u32 br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = __builtin_subc(a.l[i], b.l[i], br, &br);
-    return r;
-}
-// x + 6 p  (6 p = 6 + 102 * 2^192 + 6 * 2^251: limbs {6, 0, 0, 0, 0, 0, 102, 0x30000000})
-__device__ __forceinline__ Fe add_6p(const Fe& x) {
-    Fe r; u32 c = 0;
-    r.l[0] = __builtin_addc(x.l[0], 6u, 0u, &c);
-#pragma unroll
-    for (int i = 1; i < 6; i++) r.l[i] = __builtin_addc(x.l[i], 0u, c, &c);
-    r.l[6] = __builtin_addc(x.l[6], 102u, c, &c);
-    r.l[7] = __builtin_addc(x.l[7], 0x30000000u, c, &c);
+    r.l[0] = a.l[0] | (a.l[1] << 29);
+    r.l[1] = (a.l[1] >> 3) | (a.l[2] << 26);
+    r.l[2] = (a.l[2] >> 6) | (a.l[3] << 23);
+    r.l[3] = (a.l[3] >> 9) | (a.l[4] << 20);
+    r.l[4] = (a.l[4] >> 12) | (a.l[5] << 17);
+    r.l[5] = (a.l[5] >> 15) | (a.l[6] << 14);
+    r.l[6] = (a.l[6] >> 18) | (a.l[7] << 11);
+    r.l[7] = (a.l[7] >> 21) | (a.l[8] << 8);
     return r;
 }
 // weak form [0, 2 p) -> canonical [0, p)
@@ -142,48 +61,126 @@ __device__ __forceinline__ Fe fe_canon(const Fe& x, const u32* __restrict__ P) {
     for (int i = 0; i < 8; i++) s.l[i] = __builtin_subc(x.l[i], P[i], br, &br);
     return br ? x : s;
 }
-// Montgomery product with canonical result (conversions in and out of Montgomery form)
-__device__ __forceinline__ Fe fe_mul(const Fe& a, const Fe& b, const u32* __restrict__ P) { return fe_canon(fe_mul_weak(a, b), P); }
 
-// Hades permutation on weak-form Montgomery elements: state in [0, 2 p) in and out.
-__device__ __forceinline__ void hades(Fe s[3], const u32* __restrict__ ark, const u32* __restrict__ P) {
-    (void)P;
-    for (int r = 0; r < 91; r++) {
-        const u32* k = ark + (size_t)r * 24;
-        s[0] = add256(s[0], fe_load_const(k));              // < 3 p
-        s[1] = add256(s[1], fe_load_const(k + 8));
-        s[2] = add256(s[2], fe_load_const(k + 16));
-        const bool full = r < 4 || r >= 87;
-        if (full) {
-            Fe q0 = fe_mul_weak(s[0], s[0]), q1 = fe_mul_weak(s[1], s[1]);
-            s[0] = fe_mul_weak(q0, s[0]); s[1] = fe_mul_weak(q1, s[1]);   // < 2 p
-        }
-        Fe q2 = fe_mul_weak(s[2], s[2]);
-        s[2] = fe_mul_weak(q2, s[2]);
-        // MDS [[3,1,1],[1,-1,1],[1,1,-2]]: t = s0 + s1 + s2 (< 8 p); t + 2 s0, t + 6 p - 2 s1, t + 6 p - 3 s2 (each < 14 p < 2^255, non-negative)
-        const Fe t = add256(add256(s[0], s[1]), s[2]);
-        const Fe t6 = add_6p(t);
-        const Fe d0 = add256(s[0], s[0]), d1 = add256(s[1], s[1]), d2 = add256(add256(s[2], s[2]), s[2]);
-        s[0] = fe_weak_reduce(add256(t, d0)); s[1] = fe_weak_reduce(sub256(t6, d1)); s[2] = fe_weak_reduce(sub256(t6, d2));
+// ---- Montgomery product ----------------------------------------------------------------------------------------------------------------
+// p = 1 (mod 2^29): the factor of step i is m_i = -T_i mod 2^29, and m_i * p adds m_i at column i (clearing its low 29 bits),
+// m_i * 17 * 2^18 at column i + 6 and m_i * 2^19 at column i + 8. Columns are produced in order (product scanning); column k < 9 yields
+// m_k, column k >= 9 yields result limb k - 9.
+// SQUARE: b == a and a2 = 2 a limb-wise — column k is sum_{i < k - i} (2 a_i) a_(k-i) (+ a_(k/2)^2): 45 limb products instead of 81, same column sums.
+template <int K, bool SQUARE> __device__ __forceinline__ void f9_columns(F9& r, u32 (&m)[9], u64& acc, const F9& a, const F9& b, const F9& a2) {
+    constexpr int i0 = K < 9 ? 0 : K - 8, i1 = K < 9 ? K : 8;
+    if constexpr (SQUARE) {
+#pragma unroll
+        for (int i = i0; 2 * i < K; i++) acc += (u64)a2.l[i] * a.l[K - i];
+        if constexpr (K % 2 == 0) acc += (u64)a.l[K / 2] * a.l[K / 2];
+    } else {
+#pragma unroll
+        for (int i = i0; i <= i1; i++) acc += (u64)a.l[i] * b.l[K - i];
     }
+    if constexpr (K >= 6 && K - 6 < 9) acc += (u64)m[K - 6] * F9_C6;
+    if constexpr (K >= 8) acc += (u64)m[K - 8] * (1u << 19);
+    if constexpr (K < 9) { m[K] = (0u - (u32)acc) & M29; acc += m[K]; }
+    else r.l[K - 9] = (u32)acc & M29;
+    acc >>= 29;
+    if constexpr (K < 16) f9_columns<K + 1, SQUARE>(r, m, acc, a, b, a2);
+}
+// a * b * 2^-261 mod p. Operands: limbs < 2^30 (one lazy addition on top of normalised limbs: 9 * 2^60 + reduction terms < 2^64), values
+// < 2^256 (a * b < p * 2^261). Result: normalised, < a * b / 2^261 + p < 2 p.
+__device__ __forceinline__ F9 f9_mul(const F9& a, const F9& b) {
+    F9 r; u32 m[9]; u64 acc = 0;
+    f9_columns<0, false>(r, m, acc, a, b, a);
+    r.l[8] = (u32)acc;
+    return r;
+}
+__device__ __forceinline__ F9 f9_sqr(const F9& a) {          // same contract as f9_mul(a, a): limbs < 2^30, so 2 a limbs < 2^31
+    F9 a2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a2.l[i] = a.l[i] << 1;
+    F9 r; u32 m[9]; u64 acc = 0;
+    f9_columns<0, true>(r, m, acc, a, a, a2);
+    r.l[8] = (u32)acc;
+    return r;
+}
+__device__ __forceinline__ F9 f9_cube(const F9& a) { return f9_mul(f9_sqr(a), a); }
+// limb-wise a + k, k a table entry (normalised constants): limbs < 2^30
+__device__ __forceinline__ F9 f9_add_const(const F9& a, const u32* __restrict__ k) {
+    F9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + k[i];
+    return r;
+}
+// carry sweep: limbs < 2^32 -> normalised (same value)
+__device__ __forceinline__ void f9_normalise(F9& x) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { x.l[i + 1] += x.l[i] >> 29; x.l[i] &= M29; }
+}
+// Output of the linear layer (limbs < 2^32, value < 32 p, with the slack the L constants put into limbs 0, 6 and 8) -> normalised, < 3 p:
+// q = bits 251 and up, estimated from limb 8 and the carry of limb 7 alone (at most one too small); subtract (q - 1) p — p touches only
+// limbs 0, 6, 8 — then sweep the carries. x - (q - 1) p stays positive (q <= x / 2^251) and below 3 * 2^251.
+__device__ __forceinline__ F9 f9_reduce(F9 x) {
+    const u32 q = (x.l[8] + (x.l[7] >> 29)) >> 19;
+    const u32 k = max(q, 1u) - 1u;
+    x.l[0] -= k; x.l[6] -= __umul24(k, F9_C6); x.l[8] -= k << 19;       // k <= 24, F9_C6 < 2^23: the full-rate 24-bit multiply
+    f9_normalise(x);
+    return x;
 }
 
-struct Sponge {
-    Fe s[3]; u32 count;
-    const u32* ark; const u32* P; const u32* R1;
-    __device__ __forceinline__ void init(const u32* ark_, const u32* P_, const u32* R1_) {
-        ark = ark_; P = P_; R1 = R1_; count = 0;
-        for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) s[k].l[i] = 0;
+// Hades permutation (width 3, x^3, 4 full + 83 partial + 4 full rounds, MDS [[3,1,1],[1,-1,1],[1,1,-2]]) on Montgomery forms.
+// State in: normalised limbs, values < 6 p. State out: normalised, < 3 p.
+// Linear layer per limb: o0 = 3 c0 + c1 + c2 + L0, o1 = c0 + c2 + L1 - c1, o2 = c0 + c1 + L2 - 2 c2 where c_i are the S-box outputs (in a
+// partial round c0, c1 are the state itself: their round constants are inside L). L1 and L2 carry 10 p spread so that limb i of L1 exceeds
+// any c1 limb and limb i of L2 any 2 c2 limb, L0 carries 2 p; all three leave f9_reduce its slack. Bounds: tools/gen_poseidon_constants.py.
+template <bool FULL> __device__ __forceinline__ void hades_round(F9 (&s)[3], const u32* __restrict__ t) {
+    F9 c0 = s[0], c1 = s[1];
+    if (FULL) { c0 = f9_cube(f9_add_const(s[0], t)); c1 = f9_cube(f9_add_const(s[1], t + 9)); }
+    const F9 c2 = f9_cube(f9_add_const(s[2], t + 18));
+    F9 o0, o1, o2;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        o0.l[i] = 3u * c0.l[i] + c1.l[i] + c2.l[i] + t[27 + i];
+        o1.l[i] = c0.l[i] + c2.l[i] + t[36 + i] - c1.l[i];
+        o2.l[i] = c0.l[i] + c1.l[i] + t[45 + i] - 2u * c2.l[i];
     }
-    __device__ __forceinline__ void absorb(const Fe& v) {      // v in Montgomery form, canonical or weak (< 2 p)
-        if ((count & 1) == 0) s[0] = fe_weak_reduce(add256(s[0], v));
-        else { s[1] = fe_weak_reduce(add256(s[1], v)); hades(s, ark, P); }
+    s[0] = f9_reduce(o0); s[1] = f9_reduce(o1); s[2] = f9_reduce(o2);
+}
+__device__ __forceinline__ void hades(F9 (&s)[3], const u32* __restrict__ table) {
+    for (int r = 0; r < 4; r++) hades_round<true>(s, table + r * F9_ROUND_WORDS);
+    for (int r = 4; r < 87; r++) hades_round<false>(s, table + r * F9_ROUND_WORDS);
+    for (int r = 87; r < 91; r++) hades_round<true>(s, table + r * F9_ROUND_WORDS);
+}
+
+// device constants block (poseidon.hip uploads it): P[8] (words), R1[9], R2[9] (F9: 2^261 mod p, 2^522 mod p), table[91][54]
+struct PoseidonConsts {
+    const u32* P; const u32* R1; const u32* R2; const u32* table;
+    __device__ __forceinline__ explicit PoseidonConsts(const u32* base) : P(base), R1(base + 8), R2(base + 17), table(base + 26) {}
+};
+static constexpr u32 POSEIDON_CONSTS_WORDS = 26 + 91 * F9_ROUND_WORDS;
+
+// canonical words -> Montgomery F9 (< 2 p), and back
+__device__ __forceinline__ F9 f9_from_canonical(const Fe& x, const PoseidonConsts& pc) { return f9_mul(to_f9(x), f9_load_const(pc.R2)); }
+__device__ __forceinline__ Fe f9_to_canonical(const F9& x, const PoseidonConsts& pc) {
+    F9 one = f9_zero(); one.l[0] = 1;
+    return fe_canon(from_f9(f9_mul(x, one)), pc.P);
+}
+
+struct Sponge {          // starknet poseidon_hash_many: rate 2, padding 1 0*
+    F9 s[3]; u32 count;
+    const PoseidonConsts pc;
+    __device__ __forceinline__ explicit Sponge(const PoseidonConsts& pc_) : count(0), pc(pc_) { s[0] = f9_zero(); s[1] = f9_zero(); s[2] = f9_zero(); }
+    static __device__ __forceinline__ void add_to(F9& x, const F9& v) {      // state < 3 p, v < 2 p (normalised): sum < 6 p, normalised again
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.l[i] += v.l[i];
+        f9_normalise(x);
+    }
+    __device__ __forceinline__ void absorb(const F9& v) {
+        if ((count & 1) == 0) add_to(s[0], v);
+        else { add_to(s[1], v); hades(s, pc.table); }
         count++;
     }
-    __device__ __forceinline__ Fe finish() {                    // poseidon_hash_many padding: a single one; result in weak form
-        Fe one = fe_load_const(R1);
-        if (count & 1) s[1] = fe_weak_reduce(add256(s[1], one)); else s[0] = fe_weak_reduce(add256(s[0], one));
-        hades(s, ark, P);
+    __device__ __forceinline__ F9 finish() {
+        const F9 one = f9_load_const(pc.R1);
+        if (count & 1) add_to(s[1], one); else add_to(s[0], one);
+        hades(s, pc.table);
         return s[0];
     }
 };

@@ -22,11 +22,11 @@ __global__ void __launch_bounds__(256) k_mad(u32* out, int iters) {
 }
 __global__ void __launch_bounds__(128) k_hades(u32* out, const u32* __restrict__ consts, int iters) {
     u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const u32* P = consts; const u32* ark = consts + 24;
-    Fe s[3];
-    for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) s[k].l[i] = (tid * 31 + 8 * k + i) & (i == 7 ? 0x03ffffffu : 0xffffffffu);
-    for (int it = 0; it < iters; it++) hades(s, ark, P);
-    u32 acc = 0; for (int k = 0; k < 3; k++) for (int i = 0; i < 8; i++) acc ^= s[k].l[i];
+    const PoseidonConsts pc(consts);
+    F9 s[3];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < 9; i++) s[k].l[i] = (tid * 31 + 9 * k + i) & (i == 8 ? 0x000fffffu : M29);
+    for (int it = 0; it < iters; it++) hades(s, pc.table);
+    u32 acc = 0; for (int k = 0; k < 3; k++) for (int i = 0; i < 9; i++) acc ^= s[k].l[i];
     out[tid] = acc;
 }
 int main() {
@@ -38,8 +38,8 @@ int main() {
       hipEventRecord(e0); k_mad<<<blocks, 256>>>(d, iters); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
       double n = (double)blocks * 256 * iters * 64;
       printf("v_mad_u64_u32: %.2f T/s chip-wide (%.2f lanes per clock per CU at 2.4 GHz)\n", n / ms / 1e9, n / (ms * 1e-3) / 256 / 2.4e9); }
-    { std::vector<u32> h; h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_R1, POSEIDON_R1 + 8); h.insert(h.end(), POSEIDON_R2, POSEIDON_R2 + 8);
-      for (int r = 0; r < 273; r++) h.insert(h.end(), POSEIDON_ARK[r], POSEIDON_ARK[r] + 8);
+    { std::vector<u32> h; h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_DEV_R1, POSEIDON_DEV_R1 + 9); h.insert(h.end(), POSEIDON_DEV_R2, POSEIDON_DEV_R2 + 9);
+      for (int r = 0; r < 91; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
       u32* c; hipMalloc(&c, h.size() * 4); hipMemcpy(c, h.data(), h.size() * 4, hipMemcpyHostToDevice);
       int blocks = 2048, iters = 8;
       k_hades<<<blocks, 128>>>(d, c, 1); hipDeviceSynchronize();
