@@ -98,26 +98,23 @@ struct Ctx {
         if ((sync_blocking && !grouped) || !sync_ev) { BF_HIP(hipStreamSynchronize(stream)); return; }
         BF_HIP(hipEventRecord(sync_ev, stream));
         const auto t0 = std::chrono::steady_clock::now();
-        bool long_wait = false;
         for (u32 polls = 0;; polls++) {
             hipError_t e = hipEventQuery(sync_ev);
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) BF_HIP(e);
             if (polls < 64) continue;
-            if (long_wait || (polls & 1023u) == 0) {
+            if ((polls & 1023u) == 0) {
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                if (waited > 200e-6) {
-                    // a long wait (a whole proof, a big trace, a peer): stop burning a core and the runtime's lock
-                    if (!grouped) { BF_HIP(hipEventSynchronize(sync_ev)); return; }
-                    long_wait = true;
-                }
-                if (grouped && (!long_wait || (polls & 63u) == 0)) {
+                if (grouped) {
                     try { shard.comm->check_async(); } catch (...) { shard.comm->abort(); throw; }
                     if (waited > comm_timeout_seconds()) { shard.comm->abort(); throw HipError("shard group: the stream did not complete within the communication timeout (a peer failed or diverged)"); }
+                } else if (waited > 200e-6 && !grouped) {
+                    // a long wait (a whole proof, a big trace): stop burning a core
+                    BF_HIP(hipEventSynchronize(sync_ev));
+                    return;
                 }
             }
-            if (long_wait) std::this_thread::sleep_for(std::chrono::microseconds(30));   // bounded, unlike hipEventSynchronize: the group can still be aborted
-            else std::this_thread::yield();      // several contexts may be waiting on as many host threads
+            std::this_thread::yield();      // several contexts may be waiting on as many host threads
         }
     }
     // Copy a small host block to device scratch (valid until the ring is recycled by stage_checkpoint()). Stream-ordered.
