@@ -217,13 +217,15 @@ def run_poseidon_point(pkg, device, log):
 
 
 def probe_stages(args):
-    """(name, program, LOG_MAX_ROWS, conventions, warm-up proofs, timed proofs): the bench workload, then BASELINE configs 3/4 (a 2^24-row
-    synthetic trace) and 5 (a 2^26-row trace with the Poseidon252 MerkleChannel) proved by the whole group."""
+    """(name, program, LOG_MAX_ROWS, conventions, warm-up proofs, timed proofs, overlap mask): the bench workload, then BASELINE configs 3/4 (a
+    2^24-row synthetic trace) and 5 (a 2^26-row trace with the Poseidon252 MerkleChannel) proved by the whole group, and last the bench workload
+    again with the column -> row exchanges on the partner stream (bfhip_ctx_set_overlap bit 2: unmeasured on hardware until a multi-GPU run)."""
     conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
-    stages = [("fib19", FIB19, args.log_max_rows, conv, 2, args.probe_steps)]
+    stages = [("fib19", FIB19, args.log_max_rows, conv, 2, args.probe_steps, 0)]
     if not args.probe_fib19_only:
-        stages.append(("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3))
-        stages.append(("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1))
+        stages.append(("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, 0))
+        stages.append(("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, 0))
+        stages.append(("fib19_exchange_overlap", FIB19, args.log_max_rows, conv, 1, args.probe_steps, 4))
     return stages
 
 
@@ -231,8 +233,8 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
     """Runs every stage on `members` (the contexts this process drives: one with RCCL, all N of an in-process group — one host thread
     each). Results go to out["stages"][name]; a failed stage ends the probe (the other members may be inside its collectives)."""
     import threading
-    for name, code, lmr, conv, warm, steps in stages:
-        row = {"log_max_rows": lmr, "conventions": list(conv)}
+    for name, code, lmr, conv, warm, steps, overlap in stages:
+        row = {"log_max_rows": lmr, "conventions": list(conv), "overlap_mask": overlap}
         out["stages"][name] = row
         n = len(members)
         gate = threading.Barrier(n)
@@ -242,6 +244,7 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
             ctx, trace = members[k], None
             try:
                 ctx.set_conventions(*conv)
+                ctx.set_overlap(overlap)
                 trace = pkg.Trace(ctx, code, b"")
                 before = ctx.group_stats()
                 for _ in range(warm):
@@ -283,7 +286,7 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
                     "comm_share_of_proof": round(sum(comm_ms.values()) / (dt * 1e3), 3)})
         if is_rank0:
             row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
-        if name == "fib19":
+        if name.startswith("fib19"):
             want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
             row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
         flush()

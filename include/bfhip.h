@@ -69,7 +69,10 @@ int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
 /* Intra-proof overlap on the context's partner streams (events only, bytes unchanged); default 0 = off. bit 1: the FRI first-layer tree is
  * hashed level by level behind the quotient launches (compute_fri_quotients inside mod.rs:732); bit 0: the Merkle layers of a tree's largest
  * columns are hashed while its smaller columns are still being transformed (tree_builder.commit, mod.rs:500,583,723). Both pairs of kernels
- * are VALU-limited on gfx950 and stretch each other when they co-run: measured gain 0-0.3 ms of 31 (profiles/r03_overlap_ab*.txt). */
+ * are VALU-limited on gfx950 and stretch each other when they co-run: measured gain 0-0.3 ms of 31 (profiles/r03_overlap_ab*.txt).
+ * bit 2 (shard groups only): the column -> row send-receive of a tree's largest size class is issued on the partner stream and overlaps the
+ * transforms of the tree's smaller columns; the rest follows in a second send-receive on the same stream (every rank of the group must use
+ * the same mask: it changes the number of collectives). Unmeasured on multi-GPU hardware. */
 int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask);
 /* Host waits of this context: 0 (default) = poll briefly, then yield / block; 1 = hipStreamSynchronize at once (hosts with more waiting
  * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s). */

@@ -124,7 +124,8 @@ class Context:
         return cv.merkle_node_hash, cv.mix_u64, cv.logup_mask_order, cv.merkle_channel
 
     def set_overlap(self, mask=1):
-        """bit 0: tree commitment (Merkle beside the transforms of the smaller columns), bit 1: quotients / FRI first-layer tree."""
+        """bit 0: tree commitment (Merkle beside the transforms of the smaller columns), bit 1: quotients / FRI first-layer tree, bit 2 (shard
+        groups): the send-receive of a tree's largest size class on the partner stream beside the transforms of the smaller columns."""
         _check(lib().bfhip_ctx_set_overlap(self._h, int(mask)))
 
     def set_table_builder(self, on_gpu=True):

@@ -30,7 +30,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
-    if (const char* v = getenv("BFHIP_OVERLAP")) overlap = (u32)atoi(v) & 3u;
+    if (const char* v = getenv("BFHIP_OVERLAP")) overlap = (u32)atoi(v) & 7u;
     for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
@@ -225,7 +225,7 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking) { API_CTX(ctx) ctx->c.sync_blocking = blocking != 0; return 0; API_CATCH }
 int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask) {
     API_CTX(ctx)
-    if (mask > 3) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer");
+    if (mask > 7) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer, bit 2 = shard-group exchanges");
     ctx->c.sync();
     ctx->c.overlap = mask;
     return 0;

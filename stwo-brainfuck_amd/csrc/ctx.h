@@ -54,7 +54,8 @@ struct Ctx {
     // HBM-bound transforms of the smaller columns continue on the stream itself (aux[0] beside the main stream, aux[1] beside the side stream).
     // Ordered by events only; both are joined back (event wait) before the commitment returns.
     // overlap: bit 0 = hash a tree's largest layers beside the transforms of its smaller columns; bit 1 = hash the FRI first-layer tree level by
-    // level behind the quotient launches (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
+    // level behind the quotient launches; bit 2 (shard groups) = the send-receive of a tree's largest size class on aux[0] beside the transforms of
+    // its smaller columns (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
     u32 overlap = 0;      // measured (profiles/r03_overlap_ab*.txt): bit 1 gains 0-0.3 ms on fib19 box to box, bit 0 nothing — both sides of either overlap are
                           // VALU-limited (co-running kernels stretch each other), and the dominant kernel's event-timed roofline would include the interference
     hipStream_t aux[2] = {nullptr, nullptr};

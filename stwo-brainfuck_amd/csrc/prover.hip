@@ -419,11 +419,10 @@ struct HipProver {
             }
             t.evals[i] = e;
         }
-        fft_cols(false, fsrc, fdst);
-        if (sharded()) {
+        // the grouped send-receive that hands every rank its row range of the owned columns `idx` (after the owner's previous-row copies)
+        auto exchange_columns = [&](hipStream_t comm_stream, const std::vector<size_t>& idx, hipEvent_t after_copies) {
             std::vector<Xfer> sends, recvs;
-            for (size_t i = 0; i < n; i++) {
-                if (t.owner[i] == OWNER_ALL) continue;
+            for (size_t i : idx) {
                 const u32 el = t.evals[i].log_size;
                 const size_t cells = slice_cells(el), bytes = cells * sizeof(u32), first = slice_first(el);
                 if (t.owner[i] == c.shard.rank) {
@@ -436,7 +435,42 @@ struct HipProver {
                 recvs.push_back({t.owner[i], t.evals[i].ptr + first, bytes});
                 if (with_prev) recvs.push_back({t.owner[i], t.prev[i].ptr + first, bytes});
             }
-            if (!recvs.empty()) c.shard.comm->exchange(c.stream, sends, recvs);
+            if (recvs.empty()) return;
+            if (comm_stream != c.stream) { BF_HIP(hipEventRecord(after_copies, c.stream)); BF_HIP(hipStreamWaitEvent(comm_stream, after_copies, 0)); }
+            c.shard.comm->exchange(comm_stream, sends, recvs);
+        };
+        std::vector<size_t> owned;
+        u32 big = 0;
+        for (size_t i = 0; i < n; i++) if (t.owner[i] != OWNER_ALL) { owned.push_back(i); big = std::max(big, t.evals[i].log_size); }
+        std::vector<size_t> first_wave, second_wave;
+        for (size_t i : owned) (t.evals[i].log_size == big ? first_wave : second_wave).push_back(i);
+        // bfhip_ctx_set_overlap bit 2 (shard groups): the largest size class is transformed first and travels on the partner stream while the
+        // remaining columns are being transformed; the second send-receive follows on the same partner stream (every rank issues the group's
+        // collectives in one order), and the main stream resumes behind both. Needs at least two size classes among the owned columns.
+        if (sharded() && (c.overlap & 4u) && !second_wave.empty() && c.aux[0]) {
+            std::vector<DCol> sa, da, sb2, db2;
+            {
+                size_t k = 0;   // fsrc / fdst hold, in index order, every column this rank transforms
+                for (size_t i = 0; i < n; i++) {
+                    const bool mine = t.owner[i] == OWNER_ALL || t.owner[i] == c.shard.rank;
+                    if (!mine) continue;
+                    const bool wave_a = t.owner[i] != OWNER_ALL && t.evals[i].log_size == big;
+                    (wave_a ? sa : sb2).push_back(fsrc[k]); (wave_a ? da : db2).push_back(fdst[k]);
+                    k++;
+                }
+            }
+            c.stage_checkpoint();
+            FftPlan pa = fft_prepare(false, sa, da), pb = fft_prepare(false, sb2, db2);
+            fft_launch(pa);
+            exchange_columns(c.aux[0], first_wave, c.next_event());
+            fft_launch(pb);
+            exchange_columns(c.aux[0], second_wave, c.next_event());
+            hipEvent_t done = c.next_event();
+            BF_HIP(hipEventRecord(done, c.aux[0]));
+            BF_HIP(hipStreamWaitEvent(c.stream, done, 0));
+        } else {
+            fft_cols(false, fsrc, fdst);
+            if (sharded()) exchange_columns(c.stream, owned, nullptr);
         }
         BF_HIP(hipGetLastError());
         t.mk = merkle_commit(t.evals, pinned_root);

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 PROGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "programs")
 
 
-def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False):
+def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False, overlap=0):
     """`count` contexts of this process on the one GPU, one host thread each, joined into a local shard group (bfhip_local_group_*)."""
     group = pkg.LocalGroup(count)
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(count)]
@@ -23,6 +23,8 @@ def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False):
         try:
             ctxs[rank].join_local_group(group, rank)
             assert ctxs[rank].group_info()[:2] == (rank, count)
+            if overlap:
+                ctxs[rank].set_overlap(overlap)
             proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr, with_transcript=with_transcript)
             stats[rank] = ctxs[rank].group_stats()
         except Exception as e:      # the other ranks run into the rendezvous timeout of the library
@@ -56,6 +58,20 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
     assert oracle.verify(single, lmr)[0]
     for st in _prove_sharded.last_stats:     # the work really was divided: trees hashed share-wise, columns cut into row ranges, samples reduced
         assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
+
+
+@pytest.mark.parametrize("count", [2, 4, 8])
+def test_exchange_on_the_partner_stream_does_not_change_the_proof(pkg, oracle, count):
+    """bfhip_ctx_set_overlap bit 2: the column -> row send-receive of a tree's largest size class runs on the partner stream while the smaller
+    columns are still being transformed (two exchanges per multi-size tree instead of one). Same bytes, one more exchange per such tree."""
+    code = open(os.path.join(PROGS, "collatz.bf")).read()
+    lmr = 21
+    plain = _prove_sharded(pkg, code, b"7\n", lmr, count)
+    n_plain = _prove_sharded.last_stats[0]["exchanges"]
+    chunked = _prove_sharded(pkg, code, b"7\n", lmr, count, overlap=4)
+    assert all(p == plain[0] for p in plain + chunked)
+    assert _prove_sharded.last_stats[0]["exchanges"] > n_plain, (_prove_sharded.last_stats[0], n_plain)
+    assert oracle.verify(plain[0], lmr)[0]
 
 
 @pytest.mark.parametrize("seed,count", [(311, 2), (313, 2), (302, 4), (306, 4), (303, 8), (304, 8), (302, 2), (303, 4), (301, 8), (311, 8)])

@@ -13,6 +13,7 @@ FIB19 = open(os.path.join(ROOT, "tests", "golden", "programs", "fib19.bf")).read
 # bench.py's sweep with LOG_MAX_ROWS = k (BASELINE config 5 family) instead of fib19
 POSEIDON = os.environ.get("SHARD_LOCAL_POSEIDON") == "1"
 SYN_LOG = int(os.environ.get("SHARD_LOCAL_LOG", "0"))
+OVERLAP = int(os.environ.get("SHARD_LOCAL_OVERLAP", "0"))      # bfhip_ctx_set_overlap mask of every rank (4: exchanges on the partner stream)
 
 
 def run(pkg, n, steps, lmr=24):
@@ -30,6 +31,8 @@ def run(pkg, n, steps, lmr=24):
     def work(r):
         if group:
             ctxs[r].join_local_group(group, r)
+            if OVERLAP:
+                ctxs[r].set_overlap(OVERLAP)
         traces[r].prove(lmr)
         # the first proof of a context loads code objects (seconds, inside whatever collective comes first): counters and collective times are
         # taken as differences over the timed proofs only
