@@ -993,8 +993,17 @@ struct HipProver {
         std::stable_sort(flat.begin(), flat.end(), [](const FlatCol& a, const FlatCol& b) { return a.col.log_size > b.col.log_size; });
         std::vector<DSecure> out;
         std::vector<QuotientArgs> launches;
+        // Launches: one per size group of >= 2^19 rows, largest first, each followed by an event (q_waits) — the FRI first-layer tree hashes
+        // level L as soon as the quotient of size L exists, on the partner stream, while the smaller groups are still being computed — and one
+        // launch for all the smaller groups together. (Shard group / host channel: one launch, no events.)
+        const bool pipelined = (c.overlap & 2u) && q_waits && !sharded() && c.conv.merkle_channel == 0;
+        // Otherwise the LARGEST group is launched as soon as its own constants exist (four composition columns: a handful of products) and the
+        // host prepares the constants of the other groups — ~40 us of QM31 arithmetic, with the GPU idle behind the sampled values' round trip —
+        // while that launch runs; the rest follows as the second launch.
+        const bool early_first = !pipelined && !sharded();
+        u32 launched = 0;
         c.stage_checkpoint();
-        StageBatch sb(c);
+        auto sb = std::make_unique<StageBatch>(c);
         for (size_t i = 0; i < flat.size();) {
             size_t j = i; u32 log = flat[i].col.log_size;
             while (j < flat.size() && flat[j].col.log_size == log) j++;
@@ -1024,21 +1033,26 @@ struct HipProver {
             launches.push_back(a);
             out.push_back(q);
             i = j;
+            if (early_first && launches.size() == 1 && i < flat.size()) {
+                QuotientArgs first = launches[0];
+                const u32 nblocks = quotient_groups_layout(&first, 1);
+                const QuotientArgs* d_first = c.stage(&first, 1);
+                sb->end();
+                accumulate_quotients(c.stream, d_first, 1, nblocks);
+                sb = std::make_unique<StageBatch>(c);
+                launched = 1;
+            }
         }
-        // Launches: one per size group of >= 2^19 rows, largest first, each followed by an event (q_waits) — the FRI first-layer tree hashes
-        // level L as soon as the quotient of size L exists, on the partner stream, while the smaller groups are still being computed — and one
-        // launch for all the smaller groups together. (Shard group / host channel: one launch, no events.)
-        const bool pipelined = (c.overlap & 2u) && q_waits && !sharded() && c.conv.merkle_channel == 0;
         std::vector<std::pair<u32, u32>> ranges;      // [first group, count)
         {
-            u32 g = 0;
+            u32 g = launched;
             if (pipelined) while (g < launches.size() && launches[g].log >= 19) { ranges.push_back({g, 1u}); g++; }
             if (g < launches.size()) ranges.push_back({g, (u32)launches.size() - g});
         }
         std::vector<u32> blocks;
         for (auto& r : ranges) blocks.push_back(quotient_groups_layout(launches.data() + r.first, r.second));
         const QuotientArgs* d_groups = launches.empty() ? nullptr : c.stage(launches.data(), launches.size());
-        sb.end();                                   // one copy for the parameter blocks of every size group
+        sb->end();                                  // one copy for the parameter blocks of every (remaining) size group
         for (size_t k = 0; k < ranges.size(); k++) {
             accumulate_quotients(c.stream, d_groups + ranges[k].first, ranges[k].second, blocks[k]);
             if (pipelined) { hipEvent_t e = c.next_event(); BF_HIP(hipEventRecord(e, c.stream)); q_waits->push_back({(int)launches[ranges[k].first].log, e}); }

@@ -77,7 +77,11 @@ def persistent(budget, seed):
         slack = rng.choice((0, 0, 1, 2))
         gpu_tables = rng.random() < 0.7
         via_trace = rng.random() < 0.5
-        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack, "gpu_tables": gpu_tables, "via_trace": via_trace}
+        # bfhip_ctx_set_overlap: single contexts take any of the intra-proof modes, a group the same mask on every rank (bit 2 = exchanges on the
+        # partner stream changes the number of collectives)
+        overlap = rng.choice((0, 0, 1, 2, 3)) if count == 1 else rng.choice((0, 0, 4, 4, 7))
+        case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack, "gpu_tables": gpu_tables, "via_trace": via_trace,
+                "overlap": overlap}
         try:
             code, inp, steps = program(seed, cls, bound)
             orc.set_conventions(*conv)
@@ -98,6 +102,7 @@ def persistent(budget, seed):
                     if group is not None:
                         c.join_local_group(group, r)
                     c.set_table_builder(gpu_tables)
+                    c.set_overlap(overlap)
                     a = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
                     if via_trace:                                                    # second proof: the cached tree (if on), a warm arena,
                         tr = pkg.Trace(c, code, inp)                                 # and the resident-trace entry instead of the one-call entry
@@ -137,6 +142,7 @@ def persistent(budget, seed):
         summary["by_conventions"][cname] = summary["by_conventions"].get(cname, 0) + 1
         summary["lmr_slack"][str(slack)] = summary["lmr_slack"].get(str(slack), 0) + 1
         summary["reuse_preprocessed_on"] += int(reuse)
+        summary.setdefault("by_overlap_mask", {})[str(overlap)] = summary.setdefault("by_overlap_mask", {}).get(str(overlap), 0) + 1
         seed += 1
     for c in ctxs:
         c.close()
