@@ -697,6 +697,8 @@ struct HipProver {
         { Q31 z, a; ch.draw_two_felts(z, a); el.instruction = make_lookup(z, a); }    // InstructionElements::draw
         { Q31 z, a; ch.draw_two_felts(z, a); el.processor = make_lookup(z, a); }      // ProcessorElements::draw
         uint4* d_claimed = (uint4*)c.arena.alloc(sizeof(uint4) * N_COMPONENTS);
+        CompositionPlan composition_plan;
+        SamplePlan sample_plan;
         std::vector<DCol> inter_vals;
         std::vector<LogupLaunch> logups(N_COMPONENTS);
         for (int k = 0; k < N_COMPONENTS; k++) {
@@ -728,30 +730,68 @@ struct HipProver {
             logup_batch_run(c.stream, c.stage(&lb, 1), lb);
         }
         BF_HIP(hipGetLastError());
-        {
+        trees[2].polys = inter_vals;          // interpolate in place
+        auto take_claimed = [&](const uint4* h_claimed) {
+            for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
+            for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
+        };
+        if (sharded()) {
+            // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner
+            // interpolates and extends a column; the row-granular ones and the small ones are transformed by every rank.
             uint4 h_claimed[N_COMPONENTS];
             c.read_back(h_claimed, d_claimed, sizeof(h_claimed));
-            for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
-        }
-        trees[2].polys = inter_vals;          // interpolate in place
-        // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner
-        // interpolates and extends a column; the row-granular ones and the small ones are transformed by every rank.
-        for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
-        if (sharded()) {
+            take_claimed(h_claimed);
             trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
             std::vector<DCol> mine_cols;
             for (size_t i = 0; i < inter_vals.size(); i++) if (trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank) mine_cols.push_back(inter_vals[i]);
             fft_cols(true, mine_cols, mine_cols);
             commit_tree(trees[2], nullptr, /*with_prev=*/true);
-        } else commit_tree_overlapped(trees[2], nullptr, &inter_vals);
+        } else {
+            // Nothing on the GPU waits for the claimed sums: they travel to their pinned slot behind the logUp kernels, the interaction tree is
+            // enqueued right away, and the host mixes claim and root in protocol order after ONE synchronisation (no idle gap between the logUp
+            // kernels and the transforms).
+            uint4* pinned_claimed = reinterpret_cast<uint4*>(c.h_small + 2048);
+            Hash32* pinned_root2 = reinterpret_cast<Hash32*>(c.h_small + 2304);
+            BF_HIP(hipMemcpyAsync(pinned_claimed, d_claimed, sizeof(uint4) * N_COMPONENTS, hipMemcpyDeviceToHost, c.stream));
+            commit_tree_overlapped(trees[2], pinned_root2, &inter_vals);
+            composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);      // host work under the tree's kernels
+            c.sync();
+            take_claimed(pinned_claimed);
+            trees[2].mk.root = *pinned_root2;
+            ch.mix_root(trees[2].mk.root);
+        }
         tap("root2");
         tm.interaction = now() - t0;
 
         // ---- prover::prove (mod.rs:732): composition polynomial -----------------------------------------------------------------
         t0 = now();
         Q31 random_coeff = ch.draw_felt();
-        compute_composition(trees, bp, main_off, inter_off, el, random_coeff);
-        if (sharded()) commit_tree(trees[3]); else commit_tree_overlapped(trees[3], nullptr);
+        if (sharded()) composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);
+        compute_composition(trees, bp, composition_plan, random_coeff);
+        // per tree, per column: list of point indices (Components::mask_points + composition mask); independent of the challenges
+        std::vector<std::vector<std::vector<u32>>> mask(4);
+        mask[0].assign(trees[0].polys.size(), {});
+        for (int k = 0; k < N_COMPONENTS; k++) mask[0][log_max_rows - bp.log_sizes[k]] = {0};
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
+            u32 ni = 4 * n_logup_cols(k);
+            // last logUp column of a component: offsets {0, -1} (LogupAtRow::finalize); which comes first is Conventions::logup_mask_order
+            for (u32 j = 0; j < ni; j++) {
+                if (j + 4 >= ni) { if (c.conv.logup_mask_order == 1) mask[2].push_back({(u32)(1 + k), 0}); else mask[2].push_back({0, (u32)(1 + k)}); }
+                else mask[2].push_back({0});
+            }
+        }
+        mask[3].assign(4, {0});
+        if (sharded()) commit_tree(trees[3]);
+        else {
+            // the composition tree is enqueued; the sampling jobs (which only need the polynomials' addresses) are listed while it is hashed
+            Hash32* pinned_root3 = reinterpret_cast<Hash32*>(c.h_small + 2368);
+            commit_tree_overlapped(trees[3], pinned_root3);
+            sample_plan = sample_prepare(trees, mask);
+            c.sync();
+            trees[3].mk.root = *pinned_root3;
+            ch.mix_root(trees[3].mk.root);
+        }
         tap("root3");
         tm.composition = now() - t0;
 
@@ -769,21 +809,8 @@ struct HipProver {
         std::vector<PtQ> points(1 + N_COMPONENTS);
         points[0] = oods;
         for (int k = 0; k < N_COMPONENTS; k++) points[1 + k] = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
-        // per tree, per column: list of point indices (Components::mask_points + composition mask)
-        std::vector<std::vector<std::vector<u32>>> mask(4);
-        mask[0].assign(trees[0].polys.size(), {});
-        for (int k = 0; k < N_COMPONENTS; k++) mask[0][log_max_rows - bp.log_sizes[k]] = {0};
-        for (int k = 0; k < N_COMPONENTS; k++) {
-            for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
-            u32 ni = 4 * n_logup_cols(k);
-            // last logUp column of a component: offsets {0, -1} (LogupAtRow::finalize); which comes first is Conventions::logup_mask_order
-            for (u32 j = 0; j < ni; j++) {
-                if (j + 4 >= ni) { if (c.conv.logup_mask_order == 1) mask[2].push_back({(u32)(1 + k), 0}); else mask[2].push_back({0, (u32)(1 + k)}); }
-                else mask[2].push_back({0});
-            }
-        }
-        mask[3].assign(4, {0});
-        sample(trees, mask, points, bp.proof);
+        if (sharded()) sample_plan = sample_prepare(trees, mask);
+        sample(trees, mask, points, bp.proof, sample_plan);
         {
             std::vector<Q31> flat;
             for (auto& t : bp.proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v);
@@ -823,41 +850,53 @@ struct HipProver {
     }
 
     // ComponentProvers::compute_composition_polynomial + DomainEvaluationAccumulator::finalize
-    void compute_composition(std::vector<DTree>& trees, const BrainfuckProof& bp, const size_t* main_off, const size_t* inter_off, const Lookups& el, Q31 random_coeff) {
-        u32 total = 0, max_log = 0;
-        for (int k = 0; k < N_COMPONENTS; k++) { total += n_constraints(k); max_log = std::max(max_log, bp.log_sizes[k] + 1); }
-        std::vector<Q31> powers(total);
-        { Q31 cur = q_one(); for (u32 i = 0; i < total; i++) { powers[i] = cur; cur = q_mul(cur, random_coeff); } }
-        std::vector<DSecure> acc(max_log + 1);
-        std::vector<bool> have(max_log + 1, false);
-        u32 remaining = total;
-        std::vector<ConstraintLaunch> launches(N_COMPONENTS);
+    // Everything about the 13 constraint launches that does not depend on the interaction phase's challenge-side results (random coefficient,
+    // claimed sums): accumulators, column descriptors, vanishing inverses. Built while the GPU is still hashing the interaction tree.
+    struct CompositionPlan { std::vector<ConstraintLaunch> launches; std::vector<DSecure> acc; std::vector<bool> have; u32 total = 0, max_log = 0; };
+    CompositionPlan composition_prepare(std::vector<DTree>& trees, const BrainfuckProof& bp, const size_t* main_off, const size_t* inter_off, const Lookups& el) {
+        CompositionPlan cp;
+        for (int k = 0; k < N_COMPONENTS; k++) { cp.total += n_constraints(k); cp.max_log = std::max(cp.max_log, bp.log_sizes[k] + 1); }
+        cp.acc.resize(cp.max_log + 1); cp.have.assign(cp.max_log + 1, false); cp.launches.resize(N_COMPONENTS);
         for (int k = 0; k < N_COMPONENTS; k++) {
-            u32 log = bp.log_sizes[k], eval_log = log + 1, nc = n_constraints(k);
+            u32 log = bp.log_sizes[k], eval_log = log + 1;
             // shard group: an accumulator of a row-sharded size holds this rank's row range only (its components' interaction LDE columns
             // have the same size and are row-sharded too)
             const bool sl = slice_log(eval_log);
-            if (!have[eval_log]) {
-                acc[eval_log].log_size = eval_log; acc[eval_log].lc = sl ? lc() : 0;
-                for (int w = 0; w < 4; w++) acc[eval_log].c[w] = sl ? alloc_slice(eval_log) : c.alloc_u32(size_t(1) << eval_log);
+            if (!cp.have[eval_log]) {
+                cp.acc[eval_log].log_size = eval_log; cp.acc[eval_log].lc = sl ? lc() : 0;
+                for (int w = 0; w < 4; w++) cp.acc[eval_log].c[w] = sl ? alloc_slice(eval_log) : c.alloc_u32(size_t(1) << eval_log);
             }
             ConstraintLaunch L{};
-            L.overwrite = have[eval_log] ? 0u : 1u;      // the first component of a size writes the accumulator (no zero fill)
-            have[eval_log] = true;
-            // accum.columns(): this component takes the LAST nc remaining powers and uses them reversed (constraint 0 <-> highest)
-            for (u32 j = 0; j < nc; j++) L.coeff[j] = powers[remaining - 1 - j];
-            remaining -= nc;
+            L.overwrite = cp.have[eval_log] ? 0u : 1u;      // the first component of a size writes the accumulator (no zero fill)
+            cp.have[eval_log] = true;
             L.is_first = trees[0].evals[log_max_rows - log].ptr;
             for (u32 j = 0; j < n_main_cols(k); j++) L.trace[j] = trees[1].evals[main_off[k] + j].desc();
             const u32 ni = 4 * n_logup_cols(k);
             for (u32 j = 0; j < ni; j++) L.inter[j] = trees[2].evals[inter_off[k] + j].desc();
             for (int w = 0; w < 4; w++) { const DCol& pv = trees[2].prev[inter_off[k] + ni - 4 + w]; L.inter_prev[w] = pv.ptr; }   // nullptr unless row-sharded
             if (sl) { L.row0 = (u32)slice_first(eval_log); L.n_rows = (u32)slice_cells(eval_log); }
-            for (int w = 0; w < 4; w++) L.acc[w] = acc[eval_log].c[w];
-            L.el = el; L.total_sum = bp.claimed_sums[k]; L.log_size = log;
+            for (int w = 0; w < 4; w++) L.acc[w] = cp.acc[eval_log].c[w];
+            L.el = el; L.log_size = log;
             // denom_inv[i] = 1 / coset_vanishing(CanonicCoset(log).coset, eval_domain.at(i)), i in {0, 1} (bit-reversal of 2 entries = identity)
             for (u32 i = 0; i < 2; i++) L.denom_inv[i] = m_inv(coset_vanishing_m(log, canonic_domain_at(eval_log, i)));
-            launches[k] = L;
+            cp.launches[k] = L;
+        }
+        return cp;
+    }
+    void compute_composition(std::vector<DTree>& trees, const BrainfuckProof& bp, CompositionPlan& cp, Q31 random_coeff) {
+        const u32 total = cp.total, max_log = cp.max_log;
+        std::vector<DSecure>& acc = cp.acc;
+        std::vector<bool>& have = cp.have;
+        std::vector<ConstraintLaunch>& launches = cp.launches;
+        std::vector<Q31> powers(total);
+        { Q31 cur = q_one(); for (u32 i = 0; i < total; i++) { powers[i] = cur; cur = q_mul(cur, random_coeff); } }
+        u32 remaining = total;
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            const u32 nc = n_constraints(k);
+            // accum.columns(): this component takes the LAST nc remaining powers and uses them reversed (constraint 0 <-> highest)
+            for (u32 j = 0; j < nc; j++) launches[k].coeff[j] = powers[remaining - 1 - j];
+            remaining -= nc;
+            launches[k].total_sum = bp.claimed_sums[k];
         }
         c.stage_checkpoint();
         {   // the 13 evaluate_constraint_quotients_on_domain calls as ONE launch (air.hip: k_constraints_batch), one staging copy
@@ -937,8 +976,27 @@ struct HipProver {
         if (cur_owned || (sharded() && slice_log(cur[0].log_size + cfg.log_blowup))) for (int w = 0; w < 4; w++) trees[3].owner[w] = owner_of(w);
     }
 
-    // PolyOps::eval_at_point for every (column, mask point)
-    void sample(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, StarkProof& pf) {
+    // PolyOps::eval_at_point for every (column, mask point).
+    // sample_prepare: the job list (addresses, sizes, which point) — known before the out-of-domain point is drawn.
+    struct SamplePlan { std::vector<EvalJob> jobs; u32 partial_off = 0, n_all = 0; };
+    SamplePlan sample_prepare(const std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask) {
+        // Shard group: a sample is evaluated by ONE rank — the owner of the polynomial's coefficients, or for polynomials every rank holds the
+        // rank (job index mod count), which splits that work — the others leave a zero and one max-reduce completes the array everywhere.
+        SamplePlan sp;
+        for (size_t t = 0; t < trees.size(); t++)
+            for (size_t col = 0; col < trees[t].polys.size(); col++)
+                for (u32 pt : mask[t][col]) {
+                    const u32 ji = sp.n_all++;
+                    const u32 owner = trees[t].owner.empty() ? OWNER_ALL : trees[t].owner[col];
+                    if (sharded() && (owner == OWNER_ALL ? ji % c.shard.count : owner) != c.shard.rank) continue;
+                    const DCol& p = trees[t].polys[col];
+                    EvalJob j{}; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = sp.partial_off; j.out_idx = ji;
+                    sp.partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
+                    sp.jobs.push_back(j);
+                }
+        return sp;
+    }
+    void sample(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, StarkProof& pf, const SamplePlan& sp) {
         // factor tables: F[0] = y, F[1] = x, F[b] = double_x^(b-1)(x); 32 entries per point
         std::vector<uint4> factors(points.size() * 32, make_uint4(0, 0, 0, 0));
         for (size_t p = 0; p < points.size(); p++) {
@@ -947,21 +1005,8 @@ struct HipProver {
             factors[p * 32 + 0] = pk(points[p].y);
             for (u32 b = 1; b < 32; b++) { factors[p * 32 + b] = pk(x); x = q_double_x(x); }
         }
-        // Shard group: a sample is evaluated by ONE rank — the owner of the polynomial's coefficients, or for polynomials every rank holds the
-        // rank (job index mod count), which splits that work — the others leave a zero and one max-reduce completes the array everywhere.
-        std::vector<EvalJob> jobs;
-        u32 partial_off = 0, n_all = 0;
-        for (size_t t = 0; t < trees.size(); t++)
-            for (size_t col = 0; col < trees[t].polys.size(); col++)
-                for (u32 pt : mask[t][col]) {
-                    const u32 ji = n_all++;
-                    const u32 owner = trees[t].owner.empty() ? OWNER_ALL : trees[t].owner[col];
-                    if (sharded() && (owner == OWNER_ALL ? ji % c.shard.count : owner) != c.shard.rank) continue;
-                    const DCol& p = trees[t].polys[col];
-                    EvalJob j{}; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = partial_off; j.out_idx = ji;
-                    partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;
-                    jobs.push_back(j);
-                }
+        const std::vector<EvalJob>& jobs = sp.jobs;
+        const u32 partial_off = sp.partial_off, n_all = sp.n_all;
         c.stage_checkpoint();
         StageBatch sb(c);
         const uint4* d_factors = c.stage(factors.data(), factors.size());     // through the pinned staging ring (no pageable copies)

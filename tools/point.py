@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--conventions", default="0,0,0,0")
+    ap.add_argument("--times", action="store_true", help="also print the sorted per-proof times (host jitter shows as a tail)")
     args = ap.parse_args()
     pkg = bench.load_package()
     conv = tuple(int(v) for v in args.conventions.split(","))
@@ -52,7 +53,8 @@ def main():
                               "ms_per_proof": round(1e3 * sum(times) / len(times), 3), "ms_min": round(1e3 * min(times), 3),
                               "cells_per_s": tr.cells / (sum(times) / len(times)),
                               "phase_ms": {k: round(v * 1e3, 3) for k, v in phases.items()},
-                              "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok), "why": why}))
+                              "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok), "why": why,
+                              **({"ms_sorted": [round(1e3 * t, 3) for t in sorted(times)]} if args.times else {})}))
         finally:
             tr.close()
     finally:
