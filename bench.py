@@ -414,30 +414,50 @@ def run_shard_probe(args, rank, world):
     return result
 
 
+def gpu_local_cpus(device):
+    """The cores next to GPU `device` (sysfs local_cpulist of its PCI function), or None when that cannot be read."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        text = open(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/local_cpulist").read().strip()
+        cpus = set()
+        for part in text.split(","):
+            if "-" in part:
+                a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        return cpus or None
+    except Exception:
+        return None
+
+
 class pinned_host_thread:
-    """The proving thread on ONE core for the duration of a timed region (restored afterwards: the CPU baseline and child processes use every
-    core). A proof is ~10 Fiat-Shamir round trips with the GPU idle in each; a thread that the scheduler migrates while it polls adds a
-    0.3-0.5 ms tail to 10-15 % of the 2^22-row proofs (measured: mean 9.24 -> 9.14 ms, p90 9.50 -> 9.20 ms with the thread pinned) —
-    what any deployment does with numactl / taskset. --no-pin turns it off."""
+    """The proving thread on ONE core next to its GPU for the duration of a timed region (restored afterwards: the CPU baseline and child
+    processes use every core). A proof is ~10 Fiat-Shamir round trips with the GPU idle in each; a thread that the scheduler migrates while it
+    polls adds a 0.3-0.5 ms tail to 10-15 % of the 2^22-row proofs (measured: mean 9.24 -> 9.14 ms, p90 9.50 -> 9.20 ms under taskset) — what
+    any deployment does with numactl. Only a core of the GPU's own NUMA node is taken (a far core costs more than the jitter: measured); when
+    the node cannot be determined nothing is pinned. Opt-in (--pin): on other boxes of the pool the same pinning changed nothing or cost 1 %."""
     cpu = None
 
-    def __init__(self, enabled, local_rank=0, world=1):
-        self.enabled, self.local_rank, self.world, self.old = enabled, local_rank, world, None
+    def __init__(self, enabled, device=0, local_rank=0, world=1):
+        self.enabled, self.device, self.local_rank, self.world, self.old = enabled, device, local_rank, world, None
 
     def __enter__(self):
         if not self.enabled or not hasattr(os, "sched_setaffinity"):
             return self
         try:
-            self.old = os.sched_getaffinity(0)
-            allowed = sorted(self.old)
-            if self.world > 1:                                   # one process per GPU: spread the ranks over the allowed cores
-                cpu = allowed[(self.local_rank * max(1, len(allowed) // self.world)) % len(allowed)]
-            else:
-                import ctypes
-                cpu = ctypes.CDLL(None).sched_getcpu()
-                if cpu not in self.old:
-                    cpu = allowed[0]
+            old = os.sched_getaffinity(0)
+            near = gpu_local_cpus(self.device)
+            cand = sorted(old & near) if near else []
+            if not cand:
+                return self
+            # ranks that share a node take different cores; the first cores of a node are left to interrupt handling
+            cpu = cand[(2 + 2 * self.local_rank) % len(cand)]
             os.sched_setaffinity(0, {cpu})
+            self.old = old
             pinned_host_thread.cpu = cpu
         except OSError:
             self.old = None
@@ -456,7 +476,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-max-rows", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pin", action="store_true", help="do not pin the proving host thread to one core during the timed regions")
+    ap.add_argument("--pin", action="store_true", help="pin the proving host thread to one core of the GPU's NUMA node during the timed regions (default off: the gain "
+                    "is box dependent, profiles/r03_bench_host_pinning_ab.txt)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
                     help="full: time the CPU port on the bench workload itself live on this box (~35 s with 64 threads, ~20 GB of host memory); sample: committed "
                          "full-size measurement + a bounded live sample; auto (default): full when the host has >= 32 cores and >= 48 GB of free memory")
@@ -571,7 +592,7 @@ def main():
             lib.bfhip_profile_reset(ctx._h)
 
     cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
-    pin = lambda: pinned_host_thread(not args.no_pin and args.inflight == 1, local_rank, world)      # noqa: E731
+    pin = lambda: pinned_host_thread(args.pin and args.inflight == 1, device, local_rank, world)      # noqa: E731
     with pin():
         dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync,
                                                     backend_tensor=cuda_t, on_timed_start=start_events)
