@@ -28,6 +28,21 @@ def test_hades_random_states(ctx):
     assert ctx.hades_permutation([ref.P - 1, 1, ref.P - 2]) == ref.hades([ref.P - 1, 1, ref.P - 2])
 
 
+def test_hades_limb_boundary_states(ctx):
+    """States that put the extreme values into the 29-bit limbs of the kernel's field code (poseidon_dev.h): all-ones limbs, single top bits,
+    values just below p and just above the 2^232 / 2^251 boundaries, small values whose upper limbs are all zero, and 200 random states."""
+    P = ref.P
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 29) - 1, 1 << 29, (1 << 232) - 1, 1 << 232, (1 << 251) - 1, 1 << 251, (1 << 251) + 1, P >> 1,
+            sum(((1 << 29) - 1) << (29 * i) for i in range(8)), 17 << 192, (17 << 192) - 1, ((1 << 251) + (17 << 192))]
+    rng = np.random.default_rng(29)
+    states = [[a, b, c] for a in edge[:6] for b in edge[6:12] for c in edge[12:]][:120]
+    states += [[edge[i % len(edge)], edge[(i * 7 + 3) % len(edge)], edge[(i * 5 + 1) % len(edge)]] for i in range(40)]
+    states += [[int.from_bytes(rng.bytes(32), "little") % P for _ in range(3)] for _ in range(200)]
+    for st in states:
+        st = [v % P for v in st]
+        assert ctx.hades_permutation(st) == ref.hades(list(st)), st
+
+
 def _to_int(words):
     return sum(int(w) << (32 * i) for i, w in enumerate(words))
 
