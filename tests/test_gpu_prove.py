@@ -327,6 +327,34 @@ def test_poseidon252_variant_on_a_2_to_22_row_trace(pkg, _oracle):
 
 
 @pytest.mark.single_conv
+def test_poseidon252_variant_on_a_2_to_26_row_trace(pkg, _oracle):
+    """BASELINE config 5 at its own size on the one GPU of the test box: the 2^26-domain-row synthetic trace (bench.py's sweep program) under the
+    Poseidon252MerkleChannel — one proof (~4.5 s, 3.4 G Hades permutations), both verifiers accept, and the SHA-256 equals the one bench.py has
+    reported since round 2 (`poseidon252.proof_sha256`: the field code was rewritten on 29-bit limbs in round 3, the bytes must not move)."""
+    import hashlib
+    code = "+" * 14 + "[>" + "+" * 16000 + "[>+<-]<-]"
+    conv = (0, 0, 0, 1)
+    pkg.set_default_conventions(*conv)
+    _oracle.set_conventions(*conv)
+    try:
+        c = pkg.Context(0, max_log_domain=28)
+        try:
+            tr = pkg.Trace(c, code, b"")
+            assert max(tr.log_sizes) == 26
+            proof, _ = tr.prove(26)
+            tr.close()
+        finally:
+            c.close()
+        assert hashlib.sha256(proof).hexdigest() == "6f4e26cc34a101f77bee86b520882855f37d9646df7f163a59307d06d9264309"
+        assert pkg.verify_brainfuck(proof, 26) == (True, "")
+        ok, err = _oracle.verify(proof, 26)
+        assert ok, err
+    finally:
+        pkg.set_default_conventions(0, 0, 0, 0)
+        _oracle.set_conventions(0, 0, 0, 0)
+
+
+@pytest.mark.single_conv
 def test_poseidon252_variant_on_a_2_to_24_row_trace_and_its_shard_group(pkg, _oracle):
     """BASELINE configs 4/5 on the one GPU of the test box: the 2^24-domain-row synthetic trace under the Poseidon252MerkleChannel (one proof,
     ~1.5 s), accepted by both verifiers, and the same trace proved by a 2-rank shard group (in-process transport) — the bytes must be equal.
