@@ -166,3 +166,73 @@ def test_cpp_poseidon_channel_matches_python_restatement(_oracle):
         L.orc_channel_free(ch)
     finally:
         _oracle.set_conventions(0, 0, 0, 0)
+
+
+def test_limb_level_model_of_the_device_hades():
+    """poseidon_dev.h restated limb by limb (9 limbs of 29 bits, u32 limbs, u64 column accumulators) on the committed round table: every
+    intermediate stays inside the width the kernel gives it — column sums < 2^64, linear-layer limbs in [0, 2^32), nothing negative after the
+    subtraction of (q - 1) p, normalised limbs < 2^29 with the top limb < 2^22, values < 3 p — and the permutation equals the oracle's, for
+    zero, small, near-p and random states entering in weak form (up to + 5 p)."""
+    import random
+    P, R, M29, U32 = ref.P, 2**261, (1 << 29) - 1, 0xffffffff
+    C6 = 17 << 18
+    table = _header_words("POSEIDON_DEV_ROUNDS")
+
+    def limbs9(x): return [(x >> (29 * i)) & M29 for i in range(8)] + [x >> 232]
+    def val(l): return sum(v << (29 * i) for i, v in enumerate(l))
+
+    def f9_mul(a, b):
+        r, m, acc = [0] * 9, [0] * 9, 0
+        for K in range(17):
+            for i in range(0 if K < 9 else K - 8, (K if K < 9 else 8) + 1):
+                acc += a[i] * b[K - i]
+            if 6 <= K < 15: acc += m[K - 6] * C6
+            if K >= 8: acc += m[K - 8] << 19
+            assert acc < 2**64
+            if K < 9:
+                m[K] = (-(acc & U32)) & M29; acc += m[K]
+                assert acc % (1 << 29) == 0
+            else:
+                r[K - 9] = acc & M29
+            acc >>= 29
+        r[8] = acc
+        assert acc < 2**24
+        return r
+
+    def cube(a):
+        assert all(0 <= x < (1 << 30) for x in a) and val(a) < 2**256
+        return f9_mul(f9_mul(a, a), a)
+
+    def reduce(o):
+        assert all(0 <= x <= U32 for x in o)
+        q = ((o[8] + (o[7] >> 29)) & U32) >> 19
+        k = max(q, 1) - 1
+        assert k < (1 << 24)                                     # the kernel multiplies k * C6 with the 24-bit multiplier
+        o = list(o)
+        o[0] -= k; o[6] -= k * C6; o[8] -= k << 19
+        assert all(x >= 0 for x in o)
+        for i in range(8):
+            o[i + 1] += o[i] >> 29; o[i] &= M29
+        assert o[8] < (1 << 22) and val(o) < 3 * P
+        return o
+
+    def hades9(s):
+        for r in range(91):
+            t = table[54 * r:54 * r + 54]
+            K = [t[9 * i:9 * i + 9] for i in range(3)]
+            L = [t[27 + 9 * i:36 + 9 * i] for i in range(3)]
+            full = r < 4 or r >= 87
+            c0, c1 = (cube([a + k for a, k in zip(s[0], K[0])]), cube([a + k for a, k in zip(s[1], K[1])])) if full else (s[0], s[1])
+            c2 = cube([a + k for a, k in zip(s[2], K[2])])
+            s = [reduce([3 * a + b + c + l for a, b, c, l in zip(c0, c1, c2, L[0])]),
+                 reduce([a + c + l - b for a, b, c, l in zip(c0, c1, c2, L[1])]),
+                 reduce([a + b + l - 2 * c for a, b, c, l in zip(c0, c1, c2, L[2])])]
+        return s
+
+    rng = random.Random(29)
+    states = [[0, 0, 0], [1, 2, 3], [P - 1, P - 1, P - 1], [P - 1, 0, 1], [(1 << 232) - 1, 1 << 232, (1 << 29) - 1]] + [[rng.randrange(P) for _ in range(3)] for _ in range(12)]
+    for st in states:
+        want = ref.hades(list(st))
+        for extra in (0, 5):                                  # the sponge hands over states below 6 p
+            out = hades9([limbs9(x * R % P + extra * P) for x in st])
+            assert [val(o) * pow(R, -1, P) % P for o in out] == want
