@@ -1,8 +1,22 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see field.h header).
-// Witness/trace generation for the 13 components, restating the in-repo (verifiable) table builders of
-// crates/brainfuck_prover/src/components/**/table.rs. Pinned by the reference's table-row tests (hand-transcribed
-// fixtures under tests/golden/): memory/table.rs:714-746, instruction/table.rs:611-804, program/table.rs:357-382,
-// processor/table.rs:678-887, processor/instructions/table.rs:653-728, jump/table.rs:665-747.
+//
+// Witness generation for the 13 components, stated the slow and literal way: every reference type is a small struct of field elements,
+// every reference method (`add_entry`, `sort`, `complete_with_dummy_entries`, `pad`, the `From` conversions with their `windows(2)` /
+// `chunks(2)` pairing, `trace_evaluation`) is a function of the same name doing the same thing on a growing vector — no shared helper, no
+// column-major shortcut and no idiom in common with the product's builders (stwo-brainfuck_amd/csrc/host/tables.h writes columns directly
+// with a counting sort; tables.hip does it with segmented scans on the GPU). Three texts, one specification.
+//
+//   MemoryIntermediateTable / MemoryTable            components/memory/table.rs:20-372
+//   InstructionIntermediateTable / InstructionTable  components/instruction/table.rs:100-340
+//   ProgramTable                                     components/program/table.rs:30-175
+//   ProcessorIntermediateTable / ProcessorTable      components/processor/table.rs:100-345
+//   ProcessorInstructionIntermediateTable<N> / ...   components/processor/instructions/table.rs:120-410
+//   JumpIntermediateTable<N> / JumpTable<N>          components/processor/instructions/jump/table.rs:110-372
+//   EndOfExecInstructionTable                        components/processor/instructions/end_of_execution/table.rs:30-172
+//
+// Pinned by the reference's table-row tests, hand-transcribed into tests/golden/reference_vectors.json (memory/table.rs:714-746,
+// instruction/table.rs:611-804, program/table.rs:357-382, processor/table.rs:678-887, instructions/table.rs:653-728, jump/table.rs:665-747,
+// end_of_execution/table.rs:284-503).
 #pragma once
 #include "vm.h"
 #include <algorithm>
@@ -20,204 +34,389 @@ static const u32 N_LOGUP_COLS[N_COMPONENTS] = {1, 1, 1, 3, 1, 1, 1, 1, 1, 1, 1, 
 static const char* const COMPONENT_NAMES[N_COMPONENTS] = {"memory", "instruction", "program", "processor", "jump_if_not_zero", "jump_if_zero",
     "input_instruction", "left_instruction", "minus_instruction", "output_instruction", "plus_instruction", "right_instruction", "end_of_execution"};
 
-// A component table in row granularity: cols[c][r], r < n_rows (power of two). log_size = log2(n_rows) + LOG_N_LANES.
+// What `trace_evaluation` yields before the 16-lane broadcast: cols[c][r] for r < n_rows; log_size = log2(n_rows) + LOG_N_LANES.
 struct Table {
     std::vector<std::vector<u32>> cols;
     size_t n_rows = 0;
-    u32 log_size() const { u32 l = 0; while ((size_t(1) << l) < n_rows) l++; return l + LOG_N_LANES; }
+    u32 log_size() const {
+        u32 log_n_rows = 0;
+        while ((size_t(1) << log_n_rows) < n_rows) log_n_rows++;         // n_rows.ilog2() of a power of two
+        return log_n_rows + LOG_N_LANES;
+    }
     void init(size_t ncols, size_t rows) { n_rows = rows; cols.assign(ncols, std::vector<u32>(rows, 0)); }
 };
 
-static inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }  // usize::next_power_of_two (0 -> 1)
-static inline u32 madd(u32 a, u32 b) { return (M31(a) + M31::from(b)).v; }
+namespace literal {
 
-// --- Memory: memory/table.rs:249-303 (sort, gap-fill, pad), :121-151 (pairing) -------------------------------------
-struct MemEntry { u32 clk, mp, mv, d; };
-static inline std::vector<MemEntry> memory_intermediate(const std::vector<Registers>& trace) {
-    std::vector<MemEntry> t;
-    t.reserve(trace.size());
-    for (auto& r : trace) t.push_back({r.clk, r.mp, r.mv, 0});
-    std::stable_sort(t.begin(), t.end(), [](const MemEntry& a, const MemEntry& b) { return a.mp != b.mp ? a.mp < b.mp : a.clk < b.clk; });
-    std::vector<MemEntry> out;
-    if (!t.empty()) {
-        const MemEntry* prev = &t[0];
-        for (auto& e : t) {
-            u32 next_clk = madd(prev->clk, 1);
-            if (e.mp == prev->mp && e.clk > next_clk)
-                for (u32 clk = next_clk; clk < e.clk; clk++) out.push_back({clk, prev->mp, prev->mv, 1});
-            out.push_back(e);
-            prev = &e;
-        }
-    }
-    if (!out.empty()) {
-        MemEntry last = out.back();
-        size_t pad = next_pow2(out.size()) - out.size();
-        for (size_t i = 1; i <= pad; i++) out.push_back({madd(last.clk, (u32)i), last.mp, last.mv, 1});
-    }
+// usize::next_power_of_two: the smallest power of two >= x, and 1 for x == 0
+inline size_t next_power_of_two(size_t x) {
+    size_t power = 1;
+    while (power < x) power *= 2;
+    return power;
+}
+// `trace_evaluation` checks: EmptyTrace is raised later by the caller (an empty Table), a non power of two cannot come out of pad()
+template <class Row, class Writer>
+Table rows_to_columns(const std::vector<Row>& rows, size_t n_columns, Writer write_row) {
+    Table out;
+    if (rows.empty()) return out;
+    if ((rows.size() & (rows.size() - 1)) != 0) throw std::runtime_error("InvalidTraceLength");
+    out.init(n_columns, rows.size());
+    for (size_t vec_row = 0; vec_row < rows.size(); ++vec_row) write_row(out, vec_row, rows[vec_row]);
     return out;
 }
-static inline Table memory_table(const std::vector<Registers>& trace) {
-    auto e = memory_intermediate(trace);
-    Table t;
-    if (e.empty()) return t;
-    MemEntry last = e.back();
-    e.push_back({madd(last.clk, 1), last.mp, last.mv, 1});
-    t.init(8, e.size() - 1);
-    for (size_t r = 0; r + 1 < e.size(); r++) {
-        t.cols[0][r] = e[r].clk; t.cols[1][r] = e[r].mp; t.cols[2][r] = e[r].mv; t.cols[3][r] = e[r].d;
-        t.cols[4][r] = e[r + 1].clk; t.cols[5][r] = e[r + 1].mp; t.cols[6][r] = e[r + 1].mv; t.cols[7][r] = e[r + 1].d;
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Memory (memory/table.rs)
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct MemoryTableEntry {
+    M31 clk, mp, mv, d;
+    static MemoryTableEntry real(M31 clk, M31 mp, M31 mv) { MemoryTableEntry e; e.clk = clk; e.mp = mp; e.mv = mv; e.d = M31(0); return e; }
+    static MemoryTableEntry new_dummy(M31 clk, M31 mp, M31 mv) { MemoryTableEntry e; e.clk = clk; e.mp = mp; e.mv = mv; e.d = M31(1); return e; }
+};
+struct MemoryTableRow {
+    M31 clk, mp, mv, d, next_clk, next_mp, next_mv, next_d;
+    MemoryTableRow(const MemoryTableEntry& entry_1, const MemoryTableEntry& entry_2)
+        : clk(entry_1.clk), mp(entry_1.mp), mv(entry_1.mv), d(entry_1.d), next_clk(entry_2.clk), next_mp(entry_2.mp), next_mv(entry_2.mv), next_d(entry_2.d) {}
+};
+struct MemoryIntermediateTable {
+    std::vector<MemoryTableEntry> table;
+    void add_entry(const MemoryTableEntry& entry) { table.push_back(entry); }
+    // memory/table.rs:249-251 `sort_by_key(|x| (x.mp, x.clk))` — a stable sort on the pair
+    void sort() {
+        std::stable_sort(table.begin(), table.end(), [](const MemoryTableEntry& x, const MemoryTableEntry& y) {
+            if (x.mp.v != y.mp.v) return x.mp.v < y.mp.v;
+            return x.clk.v < y.clk.v;
+        });
     }
-    return t;
+    // memory/table.rs:259-283
+    void complete_with_dummy_entries() {
+        if (table.empty()) return;
+        std::vector<MemoryTableEntry> new_table;
+        size_t prev_index = 0;                                            // `prev_entry`, starting at the first entry
+        for (size_t index = 0; index < table.size(); ++index) {
+            const MemoryTableEntry& entry = table[index];
+            const MemoryTableEntry& prev_entry = table[prev_index];
+            const M31 next_clk = prev_entry.clk + M31(1);
+            if (entry.mp == prev_entry.mp && entry.clk.v > next_clk.v) {
+                M31 clk = next_clk;
+                while (clk.v < entry.clk.v) {
+                    new_table.push_back(MemoryTableEntry::new_dummy(clk, prev_entry.mp, prev_entry.mv));
+                    clk += M31(1);
+                }
+            }
+            new_table.push_back(entry);
+            prev_index = index;
+        }
+        table.swap(new_table);
+    }
+    // memory/table.rs:291-303
+    void pad() {
+        if (table.empty()) return;
+        const MemoryTableEntry last_entry = table.back();
+        const size_t trace_len = table.size();
+        const u32 padding_offset = (u32)(next_power_of_two(trace_len) - trace_len);
+        for (u32 i = 1; i <= padding_offset; ++i) add_entry(MemoryTableEntry::new_dummy(last_entry.clk + M31::from(i), last_entry.mp, last_entry.mv));
+    }
+    // memory/table.rs:306-320
+    static MemoryIntermediateTable from(const std::vector<Registers>& registers) {
+        MemoryIntermediateTable intermediate_table;
+        for (const Registers& reg : registers) intermediate_table.add_entry(MemoryTableEntry::real(M31(reg.clk), M31(reg.mp), M31(reg.mv)));
+        intermediate_table.sort();
+        intermediate_table.complete_with_dummy_entries();
+        intermediate_table.pad();
+        return intermediate_table;
+    }
+};
+// memory/table.rs:121-151
+inline std::vector<MemoryTableRow> memory_rows(MemoryIntermediateTable intermediate_table) {
+    std::vector<MemoryTableRow> memory_table;
+    if (intermediate_table.table.empty()) return memory_table;
+    const MemoryTableEntry last_entry = intermediate_table.table.back();
+    intermediate_table.add_entry(MemoryTableEntry::new_dummy(last_entry.clk + M31(1), last_entry.mp, last_entry.mv));
+    for (size_t w = 0; w + 2 <= intermediate_table.table.size(); ++w)      // windows(2)
+        memory_table.push_back(MemoryTableRow(intermediate_table.table[w], intermediate_table.table[w + 1]));
+    return memory_table;
 }
 
-// --- Instruction: instruction/table.rs:250-284 (program ∪ trace, stable sort by (ip, clk)), :239-248 (pad), :116-145 --
-struct InsEntry { u32 ip, ci, ni, d; };
-static inline std::vector<Registers> program_registers(const std::vector<u32>& code) {
-    std::vector<Registers> p(code.size());
-    for (size_t i = 0; i < code.size(); i++) { p[i].ip = (u32)i; p[i].ci = code[i]; p[i].ni = (i + 1 == code.size()) ? 0 : code[i + 1]; }
-    return p;
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Instruction (instruction/table.rs) and Program (program/table.rs): both start from the program laid out as register rows
+// ------------------------------------------------------------------------------------------------------------------------------------
+// instruction/table.rs:254-270, program/table.rs:114-130
+inline std::vector<Registers> program_as_registers(const std::vector<u32>& code) {
+    std::vector<Registers> program;
+    for (size_t index = 0; index < code.size(); ++index) {
+        Registers reg;                                                    // ..Default::default()
+        reg.ip = M31::from(index).v;
+        reg.ci = code[index];
+        reg.ni = (index == code.size() - 1) ? 0u : code[index + 1];
+        program.push_back(reg);
+    }
+    return program;
+}
+struct InstructionTableEntry {
+    M31 ip, ci, ni, d;
+    static InstructionTableEntry real(M31 ip, M31 ci, M31 ni) { InstructionTableEntry e; e.ip = ip; e.ci = ci; e.ni = ni; e.d = M31(0); return e; }
+    static InstructionTableEntry new_dummy(M31 ip) { InstructionTableEntry e; e.ip = ip; e.ci = M31(0); e.ni = M31(0); e.d = M31(1); return e; }
+};
+struct InstructionTableRow {
+    M31 ip, ci, ni, d, next_ip, next_ci, next_ni, next_d;
+    InstructionTableRow(const InstructionTableEntry& entry_1, const InstructionTableEntry& entry_2)
+        : ip(entry_1.ip), ci(entry_1.ci), ni(entry_1.ni), d(entry_1.d), next_ip(entry_2.ip), next_ci(entry_2.ci), next_ni(entry_2.ni), next_d(entry_2.d) {}
+};
+struct InstructionIntermediateTable {
+    std::vector<InstructionTableEntry> table;
+    void add_entry(const InstructionTableEntry& entry) { table.push_back(entry); }
+    // instruction/table.rs:239-248
+    void pad() {
+        if (table.empty()) return;
+        const InstructionTableEntry last_entry = table.back();
+        const size_t trace_len = table.size();
+        const u32 padding_offset = (u32)(next_power_of_two(trace_len) - trace_len);
+        for (u32 i = 1; i <= padding_offset; ++i) add_entry(InstructionTableEntry::new_dummy(last_entry.ip));
+    }
+    // instruction/table.rs:250-284: the program followed by the execution trace, sorted by (ip, clk)
+    static InstructionIntermediateTable from(const std::vector<Registers>& execution_trace, const std::vector<u32>& code) {
+        std::vector<Registers> sorted_registers = program_as_registers(code);
+        for (const Registers& reg : execution_trace) sorted_registers.push_back(reg);
+        std::stable_sort(sorted_registers.begin(), sorted_registers.end(), [](const Registers& x, const Registers& y) {
+            if (x.ip != y.ip) return x.ip < y.ip;
+            return x.clk < y.clk;
+        });
+        InstructionIntermediateTable instruction_table;
+        for (const Registers& reg : sorted_registers) instruction_table.add_entry(InstructionTableEntry::real(M31(reg.ip), M31(reg.ci), M31(reg.ni)));
+        instruction_table.pad();
+        return instruction_table;
+    }
+};
+// instruction/table.rs:116-145
+inline std::vector<InstructionTableRow> instruction_rows(InstructionIntermediateTable intermediate_table) {
+    std::vector<InstructionTableRow> instruction_table;
+    if (intermediate_table.table.empty()) return instruction_table;
+    const InstructionTableEntry last_entry = intermediate_table.table.back();
+    intermediate_table.add_entry(InstructionTableEntry::new_dummy(last_entry.ip));
+    for (size_t w = 0; w + 2 <= intermediate_table.table.size(); ++w)
+        instruction_table.push_back(InstructionTableRow(intermediate_table.table[w], intermediate_table.table[w + 1]));
+    return instruction_table;
+}
+
+struct ProgramTableRow {
+    M31 ip, ci, ni, d;
+    static ProgramTableRow real(M31 ip, M31 ci, M31 ni) { ProgramTableRow r; r.ip = ip; r.ci = ci; r.ni = ni; r.d = M31(0); return r; }
+    static ProgramTableRow new_dummy(M31 ip) { ProgramTableRow r; r.ip = ip; r.ci = M31(0); r.ni = M31(0); r.d = M31(1); return r; }
+};
+// program/table.rs:111-141 with pad :62-71
+inline std::vector<ProgramTableRow> program_rows(const std::vector<u32>& code) {
+    std::vector<ProgramTableRow> program_table;
+    for (const Registers& x : program_as_registers(code)) program_table.push_back(ProgramTableRow::real(M31(x.ip), M31(x.ci), M31(x.ni)));
+    if (!program_table.empty()) {
+        const ProgramTableRow last_entry = program_table.back();
+        const size_t trace_len = program_table.size();
+        const u32 padding_offset = (u32)(next_power_of_two(trace_len) - trace_len);
+        for (u32 i = 1; i <= padding_offset; ++i) program_table.push_back(ProgramTableRow::new_dummy(last_entry.ip));
+    }
+    return program_table;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Processor (processor/table.rs)
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct ProcessorTableEntry {
+    M31 clk, ip, ci, ni, mp, mv, mvi, d;
+    static ProcessorTableEntry from(const Registers& r) {
+        ProcessorTableEntry e;
+        e.clk = M31(r.clk); e.ip = M31(r.ip); e.ci = M31(r.ci); e.ni = M31(r.ni); e.mp = M31(r.mp); e.mv = M31(r.mv); e.mvi = M31(r.mvi); e.d = M31(0);
+        return e;
+    }
+    static ProcessorTableEntry new_dummy(M31 clk, M31 ip) { ProcessorTableEntry e; e.clk = clk; e.ip = ip; e.d = M31(1); return e; }   // ..Default::default()
+};
+struct ProcessorTableRow {
+    M31 clk, ip, ci, ni, mp, mv, mvi, d, next_clk;
+    ProcessorTableRow(const ProcessorTableEntry& entry_1, const ProcessorTableEntry& entry_2)
+        : clk(entry_1.clk), ip(entry_1.ip), ci(entry_1.ci), ni(entry_1.ni), mp(entry_1.mp), mv(entry_1.mv), mvi(entry_1.mvi), d(entry_1.d), next_clk(entry_2.clk) {}
+};
+struct ProcessorIntermediateTable {
+    std::vector<ProcessorTableEntry> table;
+    void add_entry(const ProcessorTableEntry& entry) { table.push_back(entry); }
+    // processor/table.rs:241-253
+    void pad() {
+        if (table.empty()) return;
+        const ProcessorTableEntry last_entry = table.back();
+        const size_t trace_len = table.size();
+        const u32 padding_offset = (u32)(next_power_of_two(trace_len) - trace_len);
+        for (u32 i = 1; i <= padding_offset; ++i) add_entry(ProcessorTableEntry::new_dummy(last_entry.clk + M31::from(i), last_entry.ip));
+    }
+    // processor/table.rs:255-265
+    static ProcessorIntermediateTable from(const std::vector<Registers>& registers) {
+        ProcessorIntermediateTable processor_table;
+        for (const Registers& reg : registers) processor_table.add_entry(ProcessorTableEntry::from(reg));
+        processor_table.pad();
+        return processor_table;
+    }
+};
+// processor/table.rs:117-145
+inline std::vector<ProcessorTableRow> processor_rows(ProcessorIntermediateTable intermediate_table) {
+    std::vector<ProcessorTableRow> processor_table;
+    if (intermediate_table.table.empty()) return processor_table;
+    const ProcessorTableEntry last_entry = intermediate_table.table.back();
+    intermediate_table.add_entry(ProcessorTableEntry::new_dummy(last_entry.clk + M31(1), last_entry.ip));
+    for (size_t w = 0; w + 2 <= intermediate_table.table.size(); ++w)
+        processor_table.push_back(ProcessorTableRow(intermediate_table.table[w], intermediate_table.table[w + 1]));
+    return processor_table;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The six single-instruction tables (instructions/table.rs) and the two jump tables (jump/table.rs): an executed instruction of kind N
+// contributes the register row it was fetched in and the row after it; the entries are then taken two by two
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct StepEntry {                        // ProcessorInstructionEntry / JumpEntry: same fields
+    M31 clk, ip, ci, ni, mp, mv, mvi, d;
+    static StepEntry from(const Registers& r) {
+        StepEntry e;
+        e.clk = M31(r.clk); e.ip = M31(r.ip); e.ci = M31(r.ci); e.ni = M31(r.ni); e.mp = M31(r.mp); e.mv = M31(r.mv); e.mvi = M31(r.mvi); e.d = M31(0);
+        return e;
+    }
+    static StepEntry new_dummy(M31 clk, M31 ip) { StepEntry e; e.clk = clk; e.ip = ip; e.d = M31(1); return e; }
+};
+struct StepIntermediateTable {
+    std::vector<StepEntry> table;
+    void add_entry(const StepEntry& entry) { table.push_back(entry); }
+    // instructions/table.rs:293-307, jump/table.rs:264-277: an EMPTY table is padded to one dummy entry (0.next_power_of_two() == 1),
+    // and the dummies count from last_clk + 0
+    void pad() {
+        const size_t trace_len = table.size();
+        M31 last_clk(0), last_ip(0);
+        if (trace_len != 0) { last_clk = table.back().clk; last_ip = table.back().ip; }
+        const u32 padding_offset = (u32)(next_power_of_two(trace_len) - trace_len);
+        for (u32 i = 0; i < padding_offset; ++i) add_entry(StepEntry::new_dummy(last_clk + M31::from(i), last_ip));
+    }
+    // instructions/table.rs:310-328, jump/table.rs:280-297: zip(registers, registers.skip(1)).filter(ci == N).flat_map([reg_0, reg_1])
+    static StepIntermediateTable from(const std::vector<Registers>& registers, u32 n) {
+        StepIntermediateTable intermediate;
+        for (size_t k = 0; k + 1 < registers.size(); ++k) {
+            const Registers& reg_0 = registers[k];
+            const Registers& reg_1 = registers[k + 1];
+            if (M31(reg_0.ci) == M31::from(n)) {
+                intermediate.add_entry(StepEntry::from(reg_0));
+                intermediate.add_entry(StepEntry::from(reg_1));
+            }
+        }
+        intermediate.pad();
+        return intermediate;
+    }
+};
+struct ProcessorInstructionRow {
+    M31 clk, ip, ci, ni, mp, mv, mvi, d, next_ip, next_mp, next_mv;
+    ProcessorInstructionRow(const StepEntry& entry_1, const StepEntry& entry_2)
+        : clk(entry_1.clk), ip(entry_1.ip), ci(entry_1.ci), ni(entry_1.ni), mp(entry_1.mp), mv(entry_1.mv), mvi(entry_1.mvi), d(entry_1.d),
+          next_ip(entry_2.ip), next_mp(entry_2.mp), next_mv(entry_2.mv) {}
+};
+struct JumpRow {
+    M31 clk, ip, ci, ni, mp, mv, mvi, next_clk, next_ip, next_mp, next_mv, d, is_mv_zero;
+    JumpRow(const StepEntry& entry_1, const StepEntry& entry_2)
+        : clk(entry_1.clk), ip(entry_1.ip), ci(entry_1.ci), ni(entry_1.ni), mp(entry_1.mp), mv(entry_1.mv), mvi(entry_1.mvi),
+          next_clk(entry_2.clk), next_ip(entry_2.ip), next_mp(entry_2.mp), next_mv(entry_2.mv), d(entry_1.d), is_mv_zero(M31(1) - entry_1.mv * entry_1.mvi) {
+        if (entry_1.d != entry_2.d) throw std::runtime_error("Both entries should be either real or dummy.");   // jump/table.rs:192
+    }
+};
+// instructions/table.rs:134-161, jump/table.rs:122-146: chunks(2); a lone last entry is paired with a dummy (clk + 1, ip)
+template <class Row>
+std::vector<Row> step_rows(const StepIntermediateTable& intermediate_table) {
+    std::vector<Row> rows;
+    const std::vector<StepEntry>& t = intermediate_table.table;
+    for (size_t first = 0; first < t.size(); first += 2) {
+        if (first + 1 < t.size()) rows.push_back(Row(t[first], t[first + 1]));
+        else rows.push_back(Row(t[first], StepEntry::new_dummy(t[first].clk + M31(1), t[first].ip)));
+    }
+    return rows;
+}
+
+}  // namespace literal
+
+// ---- the entry points the rest of the oracle uses: reference `XTable::from(..)` followed by `trace_evaluation()` minus the broadcast ----
+static inline Table memory_table(const std::vector<Registers>& trace) {
+    using namespace literal;
+    return rows_to_columns(memory_rows(MemoryIntermediateTable::from(trace)), 8, [](Table& t, size_t vec_row, const MemoryTableRow& row) {
+        t.cols[0][vec_row] = row.clk.v; t.cols[1][vec_row] = row.mp.v; t.cols[2][vec_row] = row.mv.v; t.cols[3][vec_row] = row.d.v;
+        t.cols[4][vec_row] = row.next_clk.v; t.cols[5][vec_row] = row.next_mp.v; t.cols[6][vec_row] = row.next_mv.v; t.cols[7][vec_row] = row.next_d.v;
+    });
 }
 static inline Table instruction_table(const std::vector<Registers>& trace, const std::vector<u32>& code) {
-    std::vector<Registers> all = program_registers(code);
-    all.insert(all.end(), trace.begin(), trace.end());
-    std::stable_sort(all.begin(), all.end(), [](const Registers& a, const Registers& b) { return a.ip != b.ip ? a.ip < b.ip : a.clk < b.clk; });
-    std::vector<InsEntry> e;
-    for (auto& r : all) e.push_back({r.ip, r.ci, r.ni, 0});
-    Table t;
-    if (e.empty()) return t;
-    u32 last_ip = e.back().ip;
-    size_t pad = next_pow2(e.size()) - e.size();
-    for (size_t i = 0; i < pad; i++) e.push_back({last_ip, 0, 0, 1});
-    e.push_back({last_ip, 0, 0, 1});
-    t.init(8, e.size() - 1);
-    for (size_t r = 0; r + 1 < e.size(); r++) {
-        t.cols[0][r] = e[r].ip; t.cols[1][r] = e[r].ci; t.cols[2][r] = e[r].ni; t.cols[3][r] = e[r].d;
-        t.cols[4][r] = e[r + 1].ip; t.cols[5][r] = e[r + 1].ci; t.cols[6][r] = e[r + 1].ni; t.cols[7][r] = e[r + 1].d;
-    }
-    return t;
+    using namespace literal;
+    return rows_to_columns(instruction_rows(InstructionIntermediateTable::from(trace, code)), 8, [](Table& t, size_t vec_row, const InstructionTableRow& row) {
+        t.cols[0][vec_row] = row.ip.v; t.cols[1][vec_row] = row.ci.v; t.cols[2][vec_row] = row.ni.v; t.cols[3][vec_row] = row.d.v;
+        t.cols[4][vec_row] = row.next_ip.v; t.cols[5][vec_row] = row.next_ci.v; t.cols[6][vec_row] = row.next_ni.v; t.cols[7][vec_row] = row.next_d.v;
+    });
 }
-
-// --- Program: program/table.rs:111-141, pad :62-71 ------------------------------------------------------------------
 static inline Table program_table(const std::vector<u32>& code) {
-    auto p = program_registers(code);
-    Table t;
-    if (p.empty()) return t;
-    size_t n = next_pow2(p.size());
-    t.init(4, n);
-    for (size_t r = 0; r < n; r++) {
-        if (r < p.size()) { t.cols[0][r] = p[r].ip; t.cols[1][r] = p[r].ci; t.cols[2][r] = p[r].ni; t.cols[3][r] = 0; }
-        else { t.cols[0][r] = p.back().ip; t.cols[3][r] = 1; }
-    }
-    return t;
+    using namespace literal;
+    return rows_to_columns(program_rows(code), 4, [](Table& t, size_t index, const ProgramTableRow& row) {
+        t.cols[0][index] = row.ip.v; t.cols[1][index] = row.ci.v; t.cols[2][index] = row.ni.v; t.cols[3][index] = row.d.v;
+    });
 }
-
-// --- Processor: processor/table.rs:255-265 (entries), :241-253 (pad), :117-145 (pairing) ------------------------------
 static inline Table processor_table(const std::vector<Registers>& trace) {
-    Table t;
-    if (trace.empty()) return t;
-    size_t n = next_pow2(trace.size());
-    t.init(9, n);
-    Registers last = trace.back();
-    auto clk_at = [&](size_t r) { return r < trace.size() ? trace[r].clk : madd(last.clk, (u32)(r - trace.size() + 1)); };
-    for (size_t r = 0; r < n; r++) {
-        if (r < trace.size()) {
-            const Registers& g = trace[r];
-            t.cols[0][r] = g.clk; t.cols[1][r] = g.ip; t.cols[2][r] = g.ci; t.cols[3][r] = g.ni;
-            t.cols[4][r] = g.mp; t.cols[5][r] = g.mv; t.cols[6][r] = g.mvi; t.cols[7][r] = 0;
-        } else {
-            t.cols[0][r] = clk_at(r); t.cols[1][r] = last.ip; t.cols[7][r] = 1;
-        }
-        // next entry: r+1 within the padded list, else the extra dummy (last_padded.clk + 1, last_padded.ip)
-        t.cols[8][r] = (r + 1 < n) ? clk_at(r + 1) : madd(clk_at(n - 1), 1);
-    }
-    return t;
+    using namespace literal;
+    return rows_to_columns(processor_rows(ProcessorIntermediateTable::from(trace)), 9, [](Table& t, size_t vec_row, const ProcessorTableRow& row) {
+        t.cols[0][vec_row] = row.clk.v; t.cols[1][vec_row] = row.ip.v; t.cols[2][vec_row] = row.ci.v; t.cols[3][vec_row] = row.ni.v; t.cols[4][vec_row] = row.mp.v;
+        t.cols[5][vec_row] = row.mv.v; t.cols[6][vec_row] = row.mvi.v; t.cols[7][vec_row] = row.d.v; t.cols[8][vec_row] = row.next_clk.v;
+    });
 }
-
-// --- `< > + - , .` sub-tables: instructions/table.rs:310-328 (selection), :293-307 (pad), :134-161,202-219 (chunks(2)) ---
-// --- `[ ]` jump tables: jump/table.rs:280-297, :264-277, :122-146, :191-208 ---------------------------------------------
-struct SubEntry { u32 clk, ip, ci, ni, mp, mv, mvi, d; };
-static inline std::vector<SubEntry> sub_intermediate(const std::vector<Registers>& trace, u32 opcode) {
-    std::vector<SubEntry> e;
-    for (size_t k = 0; k + 1 < trace.size(); k++)
-        if (trace[k].ci == opcode) {
-            const Registers& a = trace[k]; const Registers& b = trace[k + 1];
-            e.push_back({a.clk, a.ip, a.ci, a.ni, a.mp, a.mv, a.mvi, 0});
-            e.push_back({b.clk, b.ip, b.ci, b.ni, b.mp, b.mv, b.mvi, 0});
-        }
-    u32 last_clk = e.empty() ? 0 : e.back().clk, last_ip = e.empty() ? 0 : e.back().ip;
-    size_t pad = next_pow2(e.size()) - e.size();
-    for (size_t i = 0; i < pad; i++) e.push_back({madd(last_clk, (u32)i), last_ip, 0, 0, 0, 0, 0, 1});
-    return e;
-}
+// column order: instructions/table.rs:410-447
 static inline Table instruction_sub_table(const std::vector<Registers>& trace, u32 opcode) {
-    auto e = sub_intermediate(trace, opcode);
-    Table t;
-    size_t n = (e.size() + 1) / 2;
-    t.init(11, n);
-    for (size_t r = 0; r < n; r++) {
-        const SubEntry& a = e[2 * r];
-        SubEntry dummy{madd(a.clk, 1), a.ip, 0, 0, 0, 0, 0, 1};
-        const SubEntry& b = (2 * r + 1 < e.size()) ? e[2 * r + 1] : dummy;
-        t.cols[0][r] = a.clk; t.cols[1][r] = a.ip; t.cols[2][r] = a.ci; t.cols[3][r] = a.ni; t.cols[4][r] = a.mp;
-        t.cols[5][r] = a.mv; t.cols[6][r] = a.mvi; t.cols[7][r] = a.d; t.cols[8][r] = b.ip; t.cols[9][r] = b.mp; t.cols[10][r] = b.mv;
-    }
-    return t;
+    using namespace literal;
+    return rows_to_columns(step_rows<ProcessorInstructionRow>(StepIntermediateTable::from(trace, opcode)), 11, [](Table& t, size_t vec_row, const ProcessorInstructionRow& row) {
+        t.cols[0][vec_row] = row.clk.v; t.cols[1][vec_row] = row.ip.v; t.cols[2][vec_row] = row.ci.v; t.cols[3][vec_row] = row.ni.v; t.cols[4][vec_row] = row.mp.v;
+        t.cols[5][vec_row] = row.mv.v; t.cols[6][vec_row] = row.mvi.v; t.cols[7][vec_row] = row.d.v;
+        t.cols[8][vec_row] = row.next_ip.v; t.cols[9][vec_row] = row.next_mp.v; t.cols[10][vec_row] = row.next_mv.v;
+    });
 }
+// column order: jump/table.rs:374-415
 static inline Table jump_table(const std::vector<Registers>& trace, u32 opcode) {
-    auto e = sub_intermediate(trace, opcode);
-    Table t;
-    size_t n = (e.size() + 1) / 2;
-    t.init(13, n);
-    for (size_t r = 0; r < n; r++) {
-        const SubEntry& a = e[2 * r];
-        SubEntry dummy{madd(a.clk, 1), a.ip, 0, 0, 0, 0, 0, 1};
-        const SubEntry& b = (2 * r + 1 < e.size()) ? e[2 * r + 1] : dummy;
-        if (a.d != b.d) throw std::runtime_error("Both entries should be either real or dummy.");  // jump/table.rs:192
-        t.cols[0][r] = a.clk; t.cols[1][r] = a.ip; t.cols[2][r] = a.ci; t.cols[3][r] = a.ni; t.cols[4][r] = a.mp;
-        t.cols[5][r] = a.mv; t.cols[6][r] = a.mvi; t.cols[7][r] = b.clk; t.cols[8][r] = b.ip; t.cols[9][r] = b.mp; t.cols[10][r] = b.mv;
-        t.cols[11][r] = a.d; t.cols[12][r] = (M31(1) - M31(a.mv) * M31(a.mvi)).v;
-    }
-    return t;
+    using namespace literal;
+    return rows_to_columns(step_rows<JumpRow>(StepIntermediateTable::from(trace, opcode)), 13, [](Table& t, size_t vec_row, const JumpRow& row) {
+        t.cols[0][vec_row] = row.clk.v; t.cols[1][vec_row] = row.ip.v; t.cols[2][vec_row] = row.ci.v; t.cols[3][vec_row] = row.ni.v; t.cols[4][vec_row] = row.mp.v;
+        t.cols[5][vec_row] = row.mv.v; t.cols[6][vec_row] = row.mvi.v;
+        t.cols[7][vec_row] = row.next_clk.v; t.cols[8][vec_row] = row.next_ip.v; t.cols[9][vec_row] = row.next_mp.v; t.cols[10][vec_row] = row.next_mv.v;
+        t.cols[11][vec_row] = row.d.v; t.cols[12][vec_row] = row.is_mv_zero.v;
+    });
 }
-
-// --- End of execution: end_of_execution/table.rs:100-111, :71-98 (exactly one row; fixed log_size = LOG_N_LANES) ---------
+// end_of_execution/table.rs:100-111 (rows: every register row whose ci is zero), :71-98 (exactly one, or InvalidEndOfExecution)
 static inline Table eoe_table(const std::vector<Registers>& trace) {
-    std::vector<const Registers*> rows;
-    for (auto& r : trace) if (r.ci == 0) rows.push_back(&r);
+    std::vector<Registers> rows;
+    for (const Registers& reg : trace) if (M31(reg.ci).is_zero()) rows.push_back(reg);
     if (rows.size() != 1) throw std::runtime_error("InvalidEndOfExecution");
     Table t;
     t.init(7, 1);
-    const Registers& g = *rows[0];
-    u32 v[7] = {g.clk, g.ip, g.ci, g.ni, g.mp, g.mv, g.mvi};
-    for (int c = 0; c < 7; c++) t.cols[c][0] = v[c];
+    t.cols[0][0] = rows[0].clk; t.cols[1][0] = rows[0].ip; t.cols[2][0] = rows[0].ci; t.cols[3][0] = rows[0].ni;
+    t.cols[4][0] = rows[0].mp; t.cols[5][0] = rows[0].mv; t.cols[6][0] = rows[0].mvi;
     return t;
 }
 
-// All 13 tables in claim/commit order (brainfuck_air/mod.rs:550-562).
+// All 13 tables in claim/commit order (brainfuck_air/mod.rs:511-562); an empty one is TraceError::EmptyTrace (memory/table.rs:83-86 ...)
 static inline std::vector<Table> build_tables(const std::vector<Registers>& trace, const std::vector<u32>& code) {
-    std::vector<Table> t(N_COMPONENTS);
-    t[C_MEMORY] = memory_table(trace);
-    t[C_INSTRUCTION] = instruction_table(trace, code);
-    t[C_PROGRAM] = program_table(code);
-    t[C_PROCESSOR] = processor_table(trace);
-    t[C_JNZ] = jump_table(trace, OP_JNZ);
-    t[C_JZ] = jump_table(trace, OP_JZ);
-    t[C_INPUT] = instruction_sub_table(trace, OP_READCHAR);
-    t[C_LEFT] = instruction_sub_table(trace, OP_LEFT);
-    t[C_MINUS] = instruction_sub_table(trace, OP_MINUS);
-    t[C_OUTPUT] = instruction_sub_table(trace, OP_PUTCHAR);
-    t[C_PLUS] = instruction_sub_table(trace, OP_PLUS);
-    t[C_RIGHT] = instruction_sub_table(trace, OP_RIGHT);
-    t[C_EOE] = eoe_table(trace);
-    for (auto& x : t) if (x.n_rows == 0) throw std::runtime_error("EmptyTrace");
-    return t;
+    std::vector<Table> tables(N_COMPONENTS);
+    tables[C_MEMORY] = memory_table(trace);
+    tables[C_INSTRUCTION] = instruction_table(trace, code);
+    tables[C_PROGRAM] = program_table(code);
+    tables[C_PROCESSOR] = processor_table(trace);
+    tables[C_JNZ] = jump_table(trace, OP_JNZ);
+    tables[C_JZ] = jump_table(trace, OP_JZ);
+    tables[C_INPUT] = instruction_sub_table(trace, OP_READCHAR);
+    tables[C_LEFT] = instruction_sub_table(trace, OP_LEFT);
+    tables[C_MINUS] = instruction_sub_table(trace, OP_MINUS);
+    tables[C_OUTPUT] = instruction_sub_table(trace, OP_PUTCHAR);
+    tables[C_PLUS] = instruction_sub_table(trace, OP_PLUS);
+    tables[C_RIGHT] = instruction_sub_table(trace, OP_RIGHT);
+    tables[C_EOE] = eoe_table(trace);
+    for (const Table& table : tables) if (table.n_rows == 0) throw std::runtime_error("EmptyTrace");
+    return tables;
 }
 
-// trace_evaluation: broadcast each table row into 16 consecutive cells (memory/table.rs:91-104 and analogues).
+// trace_evaluation's `row.x.into()`: a table row fills the 16 lanes of one packed word (memory/table.rs:91-104 and the analogues)
 static inline std::vector<u32> broadcast16(const std::vector<u32>& rows) {
-    std::vector<u32> col(rows.size() << LOG_N_LANES);
-    for (size_t r = 0; r < rows.size(); r++) for (size_t l = 0; l < 16; l++) col[(r << 4) + l] = rows[r];
-    return col;
+    std::vector<u32> column(rows.size() << LOG_N_LANES);
+    for (size_t vec_row = 0; vec_row < rows.size(); ++vec_row)
+        for (size_t lane = 0; lane < (size_t(1) << LOG_N_LANES); ++lane) column[(vec_row << LOG_N_LANES) + lane] = rows[vec_row];
+    return column;
 }
 
 }  // namespace orc

@@ -467,7 +467,8 @@ __global__ void __launch_bounds__(256) k_scan_totals(const LogupBatch* __restric
         if (i < nb) q_st(totals, i, excl);
         carry = q_add(carry, chunk_total);
     }
-    if (threadIdx.x == 0) q_st(totals, nb, carry);
+    // the grand total W and the component's claimed sum (LogupTraceGenerator::finalize_last returns the last cell of the coset-order prefix sum = 8 W)
+    if (threadIdx.x == 0) { q_st(totals, nb, carry); q_st(a.claimed, 0, q_mulm(carry, 8)); }
 }
 // Stage 3 — write the last logUp column (4 coordinate columns of N = 16 M cells) and the claimed sum.
 // cell s = 16 r + l, R = bit_reverse(r), L = bit_reverse4(l):
@@ -494,8 +495,11 @@ __global__ void __launch_bounds__(256) k_logup_last(const LogupBatch* __restrict
         Q31 W = q_add(q_ld(wloc, X), q_ld(totals, X / SCAN_TILE));
         res = q_add(q_mulm(wtot, 15 - L), W);
     }
-    a.out_last[0][s] = res.a.a; a.out_last[1][s] = res.a.b; a.out_last[2][s] = res.b.a; a.out_last[3][s] = res.b.b;
-    if (s == 0) q_st(a.claimed, 0, q_mulm(wtot, 8));
+    // a null coordinate column is not written: in a shard group only the rank that transforms a coordinate column (its owner) needs it
+    if (a.out_last[0]) a.out_last[0][s] = res.a.a;
+    if (a.out_last[1]) a.out_last[1][s] = res.a.b;
+    if (a.out_last[2]) a.out_last[2][s] = res.b.a;
+    if (a.out_last[3]) a.out_last[3][s] = res.b.b;
 }
 
 void logup_batch_init(LogupBatch& b, const Lookups& el, const LogupLaunch* L, u32 n) {
@@ -514,7 +518,9 @@ void logup_batch_init(LogupBatch& b, const Lookups& el, const LogupLaunch* L, u3
         it.nb = (M + SCAN_TILE - 1) / SCAN_TILE;
         b.rows_blk0[k] = rows; rows += (M + 255) / 256;
         b.scan_blk0[k] = scan; scan += it.nb;
-        b.last_blk0[k] = last; last += (16 * M + 255) / 256;
+        // no workgroups for a component none of whose four coordinate columns this rank keeps
+        const bool any_last = it.out_last[0] || it.out_last[1] || it.out_last[2] || it.out_last[3];
+        b.last_blk0[k] = last; last += any_last ? (16 * M + 255) / 256 : 0u;
     }
     b.rows_blk0[n] = rows; b.scan_blk0[n] = scan; b.last_blk0[n] = last;
 }
@@ -523,7 +529,7 @@ void logup_batch_run(hipStream_t stream, const LogupBatch* d_b, const LogupBatch
     hipLaunchKernelGGL(k_logup_rows, dim3(h.rows_blk0[h.n]), dim3(256), 0, stream, d_b);
     hipLaunchKernelGGL(k_logup_scan_local, dim3(h.scan_blk0[h.n]), dim3(256), 0, stream, d_b);
     hipLaunchKernelGGL(k_scan_totals, dim3(h.n), dim3(256), 0, stream, d_b);
-    hipLaunchKernelGGL(k_logup_last, dim3(h.last_blk0[h.n]), dim3(256), 0, stream, d_b);
+    if (h.last_blk0[h.n]) hipLaunchKernelGGL(k_logup_last, dim3(h.last_blk0[h.n]), dim3(256), 0, stream, d_b);
 }
 
 // Broadcast upload helper (a14): rows -> 16 consecutive cells. Only used by the C-ABI when a caller wants the full-size column.

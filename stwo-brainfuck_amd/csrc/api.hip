@@ -35,6 +35,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
     BF_HIP(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
+    BF_HIP(hipEventCreateWithFlags(&block_ev, hipEventDisableTiming | hipEventBlockingSync));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
     BF_HIP(hipHostMalloc((void**)&h_small, h_small_bytes));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
@@ -74,6 +75,7 @@ void Ctx::destroy() {
     if (h_small) (void)hipHostFree(h_small);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (sync_ev) { (void)hipEventDestroy(sync_ev); sync_ev = nullptr; }
+    if (block_ev) { (void)hipEventDestroy(block_ev); block_ev = nullptr; }
     if (stream2) (void)hipStreamDestroy(stream2);
     if (stream) (void)hipStreamDestroy(stream);
 }

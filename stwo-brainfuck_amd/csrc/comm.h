@@ -45,6 +45,8 @@ struct Comm {
     std::vector<hipEvent_t> pool_;
     double ms_[3] = {0, 0, 0};
     hipEvent_t timing_event();
+    void drain_completed();
+    static constexpr size_t MAX_PENDING = 512;
     struct Timed {      // brackets one collective
         Comm& c; hipStream_t s; hipEvent_t e1 = nullptr;
         Timed(Comm& c_, hipStream_t s_, int kind);

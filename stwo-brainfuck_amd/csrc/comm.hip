@@ -21,10 +21,28 @@ hipEvent_t Comm::timing_event() {
     BF_HIP(hipEventCreate(&e));
     return e;
 }
+// Completed pairs at the front of the list are folded into the totals and their events recycled, so a group that proves for ever without
+// anybody asking for bfhip_ctx_group_times holds only the pairs still in flight (a proof's worth at most) and, once warm, creates no event.
+void Comm::drain_completed() {
+    size_t done = 0;
+    while (done < pending_.size() && hipEventQuery(pending_[done].e1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pending_[done].e0, pending_[done].e1) == hipSuccess) ms_[pending_[done].kind] += ms;
+        pool_.push_back(pending_[done].e0); pool_.push_back(pending_[done].e1);
+        done++;
+    }
+    (void)hipGetLastError();          // hipErrorNotReady of the first unfinished pair is not an error
+    if (done) pending_.erase(pending_.begin(), pending_.begin() + (long)done);
+    // a stream that is never synchronised between collectives (not how the prover runs) must not grow the list without bound either
+    while (pending_.size() > MAX_PENDING) { pool_.push_back(pending_.front().e0); pool_.push_back(pending_.front().e1); pending_.erase(pending_.begin()); }
+}
 Comm::Timed::Timed(Comm& c_, hipStream_t s_, int kind) : c(c_), s(s_) {
     if (!s) return;
-    hipEvent_t e0 = c.timing_event(); e1 = c.timing_event();
-    BF_HIP(hipEventRecord(e0, s));
+    c.drain_completed();
+    hipEvent_t e0 = c.timing_event(), e1_ = nullptr;
+    try { e1_ = c.timing_event(); BF_HIP(hipEventRecord(e0, s)); }
+    catch (...) { c.pool_.push_back(e0); if (e1_) c.pool_.push_back(e1_); throw; }
+    e1 = e1_;
     c.pending_.push_back({e0, e1, kind});
 }
 Comm::Timed::~Timed() { if (e1) (void)hipEventRecord(e1, s); }
@@ -68,6 +86,36 @@ struct LocalGroup {
 };
 std::shared_ptr<LocalGroup> local_group_create(u32 count) { return std::make_shared<LocalGroup>(count); }
 
+// Transfers between contexts that share ONE device (how a one-GPU box runs a group, and what tools/shard_local.py times) go through one
+// launch per collective instead of one runtime copy per block: a proof issues ~280 blocks per rank, and every hipMemcpyAsync is a blit
+// dispatch behind a cache write-back with ~15-20 us of idle GPU in front of it (r04: 24 of the 81 ms of an 8-rank fib19 proof on one GPU
+// were such gaps, profiles/r04_shard_timeline_before.txt) — latency of the stand-in transport, not of the proof.
+struct CopyBlock { const void* src; void* dst; unsigned long long bytes; };
+static constexpr u32 COPY_BATCH = 64, COPY_CHUNK_LOG = 16;      // <= 64 blocks per launch (1.8 KiB of kernel arguments), 64 KiB per workgroup
+struct CopyBatch { CopyBlock b[COPY_BATCH]; u32 chunk0[COPY_BATCH + 1]; u32 n; };
+__global__ void __launch_bounds__(256) k_copy_blocks(const CopyBatch a) {
+    u32 k = 0;
+    while (k + 1 < a.n && a.chunk0[k + 1] <= blockIdx.x) k++;           // uniform: scalar loads from the kernel arguments
+    const unsigned long long off = (unsigned long long)(blockIdx.x - a.chunk0[k]) << COPY_CHUNK_LOG;
+    const unsigned long long left = a.b[k].bytes - off;
+    const u32 len = left < (1ull << COPY_CHUNK_LOG) ? (u32)left : (1u << COPY_CHUNK_LOG);
+    const char* src = (const char*)a.b[k].src + off;
+    char* dst = (char*)a.b[k].dst + off;
+    if ((((unsigned long long)src | (unsigned long long)dst | len) & 15ull) == 0) {
+        for (u32 i = threadIdx.x * 16; i < len; i += 256 * 16) *(uint4*)(dst + i) = *(const uint4*)(src + i);
+    } else {
+        for (u32 i = threadIdx.x * 4; i < len; i += 256 * 4) *(u32*)(dst + i) = *(const u32*)(src + i);      // every block is a whole number of words
+    }
+}
+// out[i] = max over the ranks' buffers, read in place (same device)
+struct MaxSources { const u32* p[64]; u32 n; };
+__global__ void __launch_bounds__(256) k_max_u32_direct(u32* __restrict__ out, const MaxSources srcs, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 m = 0;
+    for (u32 b = 0; b < srcs.n; b++) { u32 v = srcs.p[b][i]; m = v > m ? v : m; }
+    out[i] = m;
+}
 // out[i] = max over the nbufs gathered copies (copy b at gathered + b * n)
 __global__ void k_max_u32_n(u32* __restrict__ out, const u32* __restrict__ gathered, u32 nbufs, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,12 +165,43 @@ struct LocalComm : Comm {
             (void)hipGetLastError();
         }
     }
-    // copy `bytes` from rank p's memory into mine on my stream
-    void copy_from(u32 p, void* dst, const void* src, size_t bytes, hipStream_t s) {
-        const int mine = g->slots[rank].device, theirs = g->slots[p].device;
-        if (theirs != mine) BF_HIP(hipMemcpyPeerAsync(dst, mine, src, theirs, bytes, s));
-        else BF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    // Blocks to copy from other ranks' memory into mine on my stream. One device for the whole group: one launch per <= 64 blocks
+    // (k_copy_blocks); several devices: a runtime peer copy per block.
+    bool same_device() const { for (u32 p = 0; p < count; p++) if (g->slots[p].device != g->slots[rank].device) return false; return true; }
+    struct Pending { u32 peer; void* dst; const void* src; size_t bytes; };
+    void run_copies(const std::vector<Pending>& blocks, hipStream_t s) {
+        bool words = true;
+        for (auto& b : blocks) words = words && b.bytes % 4 == 0 && ((uintptr_t)b.dst | (uintptr_t)b.src) % 4 == 0;
+        if (!same_device() || !words) {
+            const int mine = g->slots[rank].device;
+            for (auto& b : blocks) {
+                if (!b.bytes) continue;
+                const int theirs = g->slots[b.peer].device;
+                if (theirs != mine) BF_HIP(hipMemcpyPeerAsync(b.dst, mine, b.src, theirs, b.bytes, s));
+                else BF_HIP(hipMemcpyAsync(b.dst, b.src, b.bytes, hipMemcpyDeviceToDevice, s));
+            }
+            return;
+        }
+        CopyBatch cb{};
+        u32 chunks = 0;
+        auto flush = [&]() {
+            if (!cb.n) return;
+            cb.chunk0[cb.n] = chunks;
+            hipLaunchKernelGGL(k_copy_blocks, dim3(chunks), dim3(256), 0, s, cb);
+            cb.n = 0; chunks = 0;
+        };
+        for (auto& b : blocks) {
+            if (!b.bytes) continue;
+            if (b.bytes >> (COPY_CHUNK_LOG + 30)) throw HipError("shard group: block too large");
+            cb.b[cb.n] = CopyBlock{b.src, b.dst, (unsigned long long)b.bytes};
+            cb.chunk0[cb.n] = chunks;
+            chunks += (u32)((b.bytes + (size_t(1) << COPY_CHUNK_LOG) - 1) >> COPY_CHUNK_LOG);
+            if (++cb.n == COPY_BATCH) flush();
+        }
+        flush();
+        BF_HIP(hipGetLastError());
     }
+    void wait_ready(hipStream_t s, u32 p) { if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0)); }
     void publish(hipStream_t s, void* buf) { g->slots[rank].buf = buf; BF_HIP(hipEventRecord(g->slots[rank].ready, s)); g->barrier(); check_peers(); }
     void finish(hipStream_t s) {
         BF_HIP(hipEventRecord(g->slots[rank].done, s));
@@ -133,28 +212,40 @@ struct LocalComm : Comm {
         n_all_gather++; bytes_sent += bpr * (count - 1);
         Timed tm(*this, s, T_ALL_GATHER);
         publish(s, buf);
+        std::vector<Pending> blocks;
         for (u32 p = 0; p < count; p++) {
             if (p == rank) continue;
-            BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0));
-            copy_from(p, (char*)buf + p * bpr, (const char*)g->slots[p].buf + p * bpr, bpr, s);
+            wait_ready(s, p);
+            blocks.push_back({p, (char*)buf + p * bpr, (const char*)g->slots[p].buf + p * bpr, bpr});
         }
+        run_copies(blocks, s);
         finish(s);
     }
     void all_reduce_max_u32(hipStream_t s, u32* buf, size_t n) override {
         n_all_reduce++; bytes_sent += n * sizeof(u32);
         if (n == 0) { g->barrier(); g->barrier(); return; }
         Timed tm(*this, s, T_ALL_REDUCE);
-        const size_t need = (size_t)(count + 1) * n;
+        const bool direct = same_device() && count <= 64;        // one device: the maximum is taken over the ranks' buffers where they lie
+        const size_t need = direct ? n : (size_t)(count + 1) * n;
         if (scratch_words < need) { BF_HIP(hipStreamSynchronize(s)); (void)hipFree(scratch); scratch = nullptr; scratch_words = 0; BF_HIP(hipMalloc((void**)&scratch, need * sizeof(u32))); scratch_words = need; }
         publish(s, buf);
-        for (u32 p = 0; p < count; p++) {   // gather every rank's (unmodified) input into this rank's scratch, then reduce locally
-            if (p != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[p].ready, 0));
-            copy_from(p, scratch + (size_t)p * n, g->slots[p].buf, n * sizeof(u32), s);
+        for (u32 p = 0; p < count; p++) wait_ready(s, p);
+        u32* result;
+        if (direct) {
+            result = scratch;
+            MaxSources ms{};
+            ms.n = count;
+            for (u32 p = 0; p < count; p++) ms.p[p] = (const u32*)g->slots[p].buf;
+            hipLaunchKernelGGL(k_max_u32_direct, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, result, ms, n);
+        } else {
+            std::vector<Pending> blocks;       // gather every rank's (unmodified) input into this rank's scratch, then reduce locally
+            for (u32 p = 0; p < count; p++) blocks.push_back({p, scratch + (size_t)p * n, g->slots[p].buf, n * sizeof(u32)});
+            run_copies(blocks, s);
+            result = scratch + (size_t)count * n;
+            hipLaunchKernelGGL(k_max_u32_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, result, scratch, count, n);
         }
-        u32* result = scratch + (size_t)count * n;
-        hipLaunchKernelGGL(k_max_u32_n, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, result, scratch, count, n);
         finish(s);                         // every rank has read the unmodified inputs
-        BF_HIP(hipMemcpyAsync(buf, result, n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+        run_copies({Pending{rank, buf, result, n * sizeof(u32)}}, s);
     }
     void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) override {
         n_exchange++; for (auto& x : sends) if (x.peer != rank) bytes_sent += x.bytes;
@@ -162,15 +253,18 @@ struct LocalComm : Comm {
         g->slots[rank].sends = sends;
         publish(s, nullptr);
         std::vector<size_t> next(count, 0);   // per peer: position in that peer's send list of the next block addressed to me
+        std::vector<Pending> blocks;
+        std::vector<bool> waited(count, false);
         for (const Xfer& r : recvs) {
             const std::vector<Xfer>& ps = g->slots[r.peer].sends;
             size_t& k = next[r.peer];
             while (k < ps.size() && ps[k].peer != rank) k++;
             if (k >= ps.size() || ps[k].bytes != r.bytes) { g->fail(); throw HipError("shard group: unmatched send/receive"); }
-            if (r.peer != rank) BF_HIP(hipStreamWaitEvent(s, g->slots[r.peer].ready, 0));
-            if (r.bytes) copy_from(r.peer, r.ptr, ps[k].ptr, r.bytes, s);
+            if (!waited[r.peer]) { wait_ready(s, r.peer); waited[r.peer] = true; }
+            if (r.bytes) blocks.push_back({r.peer, r.ptr, ps[k].ptr, r.bytes});
             k++;
         }
+        run_copies(blocks, s);
         finish(s);
     }
 };
@@ -252,7 +346,11 @@ struct RcclComm : Comm {
             throw HipError(std::string("shard group: RCCL reported an asynchronous error: ") + (rccl().GetErrorString ? rccl().GetErrorString(st) : "?"));
     }
     void abort() override { if (comm && !aborted && rccl().CommAbort) { aborted = true; (void)rccl().CommAbort(comm); } }
-    const char* transport() const override { return "RCCL (one process per GPU, collectives on the context's stream over xGMI)"; }
+    const char* transport() const override {
+        // an overridden library path is visible to whoever asks which transport a group runs on (bfhip_ctx_group_info)
+        static const std::string over = [] { const char* v = getenv("BFHIP_RCCL_LIBRARY"); return v ? std::string("RCCL entry points from BFHIP_RCCL_LIBRARY=") + v : std::string(); }();
+        return over.empty() ? "RCCL (one process per GPU, collectives on the context's stream over xGMI)" : over.c_str();
+    }
     void all_gather(hipStream_t s, void* buf, size_t bpr) override {
         n_all_gather++; bytes_sent += bpr * (count - 1);
         Timed tm(*this, s, T_ALL_GATHER);
@@ -274,7 +372,9 @@ struct RcclComm : Comm {
         for (size_t i = 0; i < self_s.size(); i++) {
             if (self_s[i]->bytes != self_r[i]->bytes) throw HipError("shard group: unmatched self transfer");
             if (!self_s[i]->bytes) continue;
-            if (rccl().MockSelfCopy) { if (rccl().MockSelfCopy(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes) != 0) throw HipError("shard group: self copy failed"); }
+            // host-memory blocks exist only behind the raw test entry (bfhip_rccl_exchange_raw: null stream) with a test double loaded; a
+            // prover's exchange always carries its stream and always copies on the device, whatever library BFHIP_RCCL_LIBRARY named
+            if (!s && rccl().MockSelfCopy) { if (rccl().MockSelfCopy(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes) != 0) throw HipError("shard group: self copy failed"); }
             else BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
         }
         BF_NCCL(rccl().GroupStart());

@@ -94,6 +94,7 @@ struct Ctx {
     // with more waiting contexts than cores. Inside a shard group every wait is BOUNDED: the transport is polled for asynchronous errors and
     // after comm_timeout_seconds() the group is aborted and the wait fails, instead of a stream that hangs on a peer that diverged.
     bool sync_blocking = false;
+    hipEvent_t block_ev = nullptr;   // hipEventBlockingSync: the only event a host thread SLEEPS on (sync_ev is polled)
     void sync() {
         const bool grouped = shard.count > 1 && shard.comm;
         if ((sync_blocking && !grouped) || !sync_ev) { BF_HIP(hipStreamSynchronize(stream)); return; }
@@ -104,14 +105,22 @@ struct Ctx {
             if (e == hipSuccess) return;
             if (e != hipErrorNotReady) BF_HIP(e);
             if (polls < 64) continue;
-            if ((polls & 1023u) == 0) {
+            if ((polls & 255u) == 0) {
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (grouped) {
+                    // Inside a group the wait stays a bounded poll (the transport must be asked for asynchronous errors and a peer that
+                    // diverged must not hang this rank), so set_sync_policy(blocking) does not apply; once the wait is longer than any
+                    // Fiat-Shamir round trip of a sharded proof (4 ms) it backs off with short sleeps instead of spinning — N ranks of one
+                    // process on an oversubscribed host otherwise starve each other. (Shorter waits keep polling: a sleep's wake-up
+                    // latency, ~60 us, would be paid ten times per proof.)
                     try { shard.comm->check_async(); } catch (...) { shard.comm->abort(); throw; }
                     if (waited > comm_timeout_seconds()) { shard.comm->abort(); throw HipError("shard group: the stream did not complete within the communication timeout (a peer failed or diverged)"); }
-                } else if (waited > 200e-6 && !grouped) {
-                    // a long wait (a whole proof, a big trace): stop burning a core
-                    BF_HIP(hipEventSynchronize(sync_ev));
+                    if (waited > 4e-3) { std::this_thread::sleep_for(std::chrono::microseconds(waited > 50e-3 ? 200 : 50)); continue; }
+                } else if (waited > 200e-6) {
+                    // a long wait (a whole proof, a big trace): stop burning a core — sleep on an event created for blocking waits
+                    // (an event without hipEventBlockingSync may be waited for by spinning inside the runtime)
+                    if (block_ev) { BF_HIP(hipEventRecord(block_ev, stream)); BF_HIP(hipEventSynchronize(block_ev)); }
+                    else BF_HIP(hipStreamSynchronize(stream));
                     return;
                 }
             }

@@ -214,10 +214,30 @@ struct HipProver {
         while (fused_top > 0 && mk.shifts[std::min(fused_top, mk.max_log)] != 0) fused_top--;
         if (p.poseidon) fused_top = 0;
         p.fused_top = fused_top;
-        // levels [sub_hi .. 10]: one launch, a workgroup per node of level 10 (one process per proof only: a shard group hashes big layers
-        // share-wise with single-level launches)
-        if (fused_top == 10 && mk.max_log >= 11 && c.shard.count == 1) {
-            u32 hi = std::min<u32>(mk.max_log, 17);
+        // Shard group: the big layers are hashed SHARE-WISE — rank r takes the stored slots [r * stored / count, (r + 1) * stored / count) of
+        // every layer with at least 2^SHARE_MIN_LOG_PER_RANK stored nodes per rank, replicated ones included (a slot's children are slots of
+        // the same rank in the layer below, whether that layer is stored at the same replication or one step finer). log - shift is
+        // non-decreasing in log, so these layers form one band [band_lo, max_log]; the band's lowest layer is completed on every rank by one
+        // all-gather and everything below it is hashed by every rank, redundantly, with the same two launches as a one-GPU proof (subtree +
+        // top): a share of fewer than 2^14 nodes is a launch that costs more than it computes (r04: 155 of a rank's 217 layer launches per
+        // fib19 proof had <= 512 workgroups and took 0.85 ms per rank: profiles/r04_shard_redundancy_before.txt).
+        const ShardGroup& sg = c.shard;
+        if (sg.count > 1) {
+            // (Poseidon252: a node costs ~40x a Blake2s node and there is no multi-level kernel below the band — shares down to 256 nodes)
+            const int share_min = p.poseidon ? 8 : (int)SHARE_MIN_LOG_PER_RANK;
+            int lo = std::max<int>((int)sg.log_count + share_min, (int)fused_top);
+            while (lo <= (int)mk.max_log && (int)lo - (int)mk.shifts[lo] < (int)sg.log_count + share_min) lo++;
+            // a tree with fewer than 2^14 stored leaves per rank is hashed whole by every rank: cheaper than the latency of its all-gather
+            const bool worth = (int)mk.max_log - (int)mk.shifts[mk.max_log] >= (int)sg.log_count + (int)SLICE_MIN_LOG_PER_RANK;
+            if (worth && lo <= (int)mk.max_log) { mk.band_hi = (int)mk.max_log; mk.band_lo = lo; }
+            // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
+            for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
+        }
+        const bool banded = mk.band_hi >= mk.band_lo;
+        // levels [sub_hi .. 9]: one launch, a workgroup per node of level 9 — over complete, un-replicated levels only (below the band of a
+        // shard group's tree); complete levels above sub_hi are single-level launches
+        if (fused_top == 10 && mk.max_log >= 11) {
+            u32 hi = std::min<u32>(banded ? (u32)mk.band_lo - 1 : mk.max_log, 17);
             while (hi > 10 && mk.shifts[hi] != 0) hi--;
             if (hi > 10) { p.sub_hi = hi; p.fused_top = fused_top = MERKLE_SUBTREE_ROOT_LEVEL; }     // the top starts below the subtree roots
         }
@@ -237,22 +257,6 @@ struct HipProver {
             for (u32 lg = 0; lg <= mk.max_log; lg++) { td.layers[lg] = (uint4*)mk.layers[lg]; td.shifts[lg] = mk.shifts[lg]; td.col_off[lg] = (u32)p.off[lg]; }
             td.cols = p.d_all; td.n_cols = (u32)all.size(); td.max_log = mk.max_log;
             p.tree = td;
-        }
-        // Shard group: the un-replicated layers with at least 256 nodes per rank are hashed share-wise; the smallest of them is
-        // completed on every rank by one all-gather, the rest of the tree is computed redundantly (cheap: <= 256 * count nodes).
-        const ShardGroup& sg = c.shard;
-        if (sg.count > 1) {
-            // Share-wise layers: every layer with at least 256 STORED nodes per rank, replicated ones included (rank r takes the slots
-            // [r * stored / count, (r + 1) * stored / count); a slot's children are slots of the same rank in the layer below, whether
-            // that layer is stored at the same replication or one step finer). log - shift is non-decreasing in log, so these layers
-            // form one band [band_lo, max_log]; the band's lowest layer is completed on every rank by one all-gather.
-            int lo = std::max<int>((int)sg.log_count + 8, (int)fused_top);
-            while (lo <= (int)mk.max_log && (int)lo - (int)mk.shifts[lo] < (int)sg.log_count + 8) lo++;
-            // a tree with fewer than 2^14 stored leaves per rank is hashed whole by every rank: cheaper than the latency of its all-gather
-            const bool worth = (int)mk.max_log - (int)mk.shifts[mk.max_log] >= (int)sg.log_count + (int)SLICE_MIN_LOG_PER_RANK;
-            if (worth && lo <= (int)mk.max_log) { mk.band_hi = (int)mk.max_log; mk.band_lo = lo; }
-            // row-sharded columns can only be hashed share-wise: their layers must lie inside the band
-            for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
         return p;
     }
@@ -374,6 +378,8 @@ struct HipProver {
     // (row-granular) columns and the preprocessed / main trees stay complete on every rank.
     // 2^14 rows per rank: below that a transform, a fold or a subtree costs less than the latency of the exchange that would divide it
     static constexpr u32 SLICE_MIN_LOG_PER_RANK = 14;
+    // a Merkle layer is hashed share-wise while a rank's share has at least 2^14 stored nodes (64 workgroups); see merkle_plan
+    static constexpr u32 SHARE_MIN_LOG_PER_RANK = 14;
     bool sharded() const { return c.shard.count > 1; }
     u32 lc() const { return c.shard.log_count; }
     bool slice_log(u32 log) const { return sharded() && log >= lc() + SLICE_MIN_LOG_PER_RANK; }
@@ -461,13 +467,19 @@ struct HipProver {
             }
             c.stage_checkpoint();
             FftPlan pa = fft_prepare(false, sa, da), pb = fft_prepare(false, sb2, db2);
-            fft_launch(pa);
-            exchange_columns(c.aux[0], first_wave, c.next_event());
-            fft_launch(pb);
-            exchange_columns(c.aux[0], second_wave, c.next_event());
-            hipEvent_t done = c.next_event();
-            BF_HIP(hipEventRecord(done, c.aux[0]));
-            BF_HIP(hipStreamWaitEvent(c.stream, done, 0));
+            try {
+                fft_launch(pa);
+                exchange_columns(c.aux[0], first_wave, c.next_event());
+                fft_launch(pb);
+                exchange_columns(c.aux[0], second_wave, c.next_event());
+                hipEvent_t done = c.next_event();
+                BF_HIP(hipEventRecord(done, c.aux[0]));
+                BF_HIP(hipStreamWaitEvent(c.stream, done, 0));
+            } catch (...) {
+                // copies and receives still queued on the partner stream write into arena memory the next proof hands out again
+                (void)hipStreamSynchronize(c.aux[0]);
+                throw;
+            }
         } else {
             fft_cols(false, fsrc, fdst);
             if (sharded()) exchange_columns(c.stream, owned, nullptr);
@@ -701,21 +713,26 @@ struct HipProver {
         SamplePlan sample_plan;
         std::vector<DCol> inter_vals;
         std::vector<LogupLaunch> logups(N_COMPONENTS);
+        // the interaction columns in commit order (mod.rs:690-702): per component its logUp columns but the last row-granular (4 coordinates
+        // each), then the last one full-size
+        for (int k = 0; k < N_COMPONENTS; k++) {
+            const u32 log = bp.log_sizes[k], nl = n_logup_cols(k);
+            for (u32 j = 0; j < 4 * nl; j++) { DCol col; col.log_size = log; col.shift = j + 4 < 4 * nl ? LOG_N_LANES : 0; inter_vals.push_back(col); }
+        }
+        // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner of a
+        // coordinate column keeps, interpolates and extends it, so only the owner has the logUp kernel write it (the others pass a null
+        // pointer: no storage, no store); the row-granular columns and the small ones are written and transformed by every rank.
+        if (sharded()) trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
+        auto kept = [&](size_t i) { return !sharded() || trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank; };
+        for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) inter_vals[i].ptr = c.alloc_u32(inter_vals[i].stored());
         for (int k = 0; k < N_COMPONENTS; k++) {
             u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
             size_t M = size_t(1) << log_rows;
             LogupLaunch L{};
             for (u32 j = 0; j < n_main_cols(k); j++) L.cols[j] = rows[k][j].ptr;
             u32 nl = n_logup_cols(k);
-            for (u32 q = 0; q + 1 < nl; q++)
-                for (int w = 0; w < 4; w++) {
-                    DCol col; col.log_size = log; col.shift = LOG_N_LANES; col.ptr = c.alloc_u32(col.stored());
-                    L.out_rep[4 * q + w] = col.ptr; inter_vals.push_back(col);
-                }
-            for (int w = 0; w < 4; w++) {
-                DCol col; col.log_size = log; col.shift = 0; col.ptr = c.alloc_u32(col.stored());
-                L.out_last[w] = col.ptr; inter_vals.push_back(col);
-            }
+            for (u32 j = 0; j + 4 < 4 * nl; j++) L.out_rep[j] = inter_vals[inter_off[k] + j].ptr;
+            for (int w = 0; w < 4; w++) L.out_last[w] = inter_vals[inter_off[k] + 4 * (nl - 1) + w].ptr;
             L.vrow = c.arena.alloc(sizeof(uint4) * M);
             L.wloc = c.arena.alloc(sizeof(uint4) * M);
             L.totals = c.arena.alloc(sizeof(uint4) * (M / 1024 + 2));
@@ -736,14 +753,11 @@ struct HipProver {
             for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
         };
         if (sharded()) {
-            // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner
-            // interpolates and extends a column; the row-granular ones and the small ones are transformed by every rank.
             uint4 h_claimed[N_COMPONENTS];
             c.read_back(h_claimed, d_claimed, sizeof(h_claimed));
             take_claimed(h_claimed);
-            trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
             std::vector<DCol> mine_cols;
-            for (size_t i = 0; i < inter_vals.size(); i++) if (trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank) mine_cols.push_back(inter_vals[i]);
+            for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) mine_cols.push_back(inter_vals[i]);
             fft_cols(true, mine_cols, mine_cols);
             commit_tree(trees[2], nullptr, /*with_prev=*/true);
         } else {
@@ -1239,7 +1253,8 @@ struct HipProver {
         // size (fold_line, then dst * alpha^2 + fold_circle: both with alpha_{k+1}). Below 2^10 rows the rest of the phase is one launch.
         const u32 TAIL_LOG = 10;
         // layers of 2^11 .. 2^16 rows: fold + tree + channel step in ONE launch (merkle.hip: k_fri_layer) — device channel, one process
-        auto fused = [&](u32 k) { const u32 lg = line_log - k; return !host_channel && !sharded() && k >= 1 && k < n_inner && lg >= 11 && lg <= 16; };
+        // (in a shard group: layers every rank holds whole, folded from a layer every rank holds whole)
+        auto fused = [&](u32 k) { const u32 lg = line_log - k; return !host_channel && k >= 1 && k < n_inner && lg >= 11 && lg <= 16 && layers[k].lc == 0 && layers[k - 1].lc == 0; };
         auto take_quotient = [&](u32 size) -> const DSecure* {
             const DSecure* q = (qi < quotients.size() && quotients[qi].log_size == size) ? &quotients[qi++] : nullptr;
             if (qi < quotients.size() && quotients[qi].log_size == size) throw HipError("FRI: two quotient columns of one size");
@@ -1430,7 +1445,12 @@ extern "C" int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* t, uint
 // A proof that fails on one rank of a shard group must not leave the others waiting for its next collective: the transport is told to give
 // up (in-process: the rendezvous object is marked failed and every waiting rank throws; RCCL: ncclCommAbort). The group is unusable afterwards.
 static void release_group_after_failure(bfhip_ctx* ctx) {
-    if (ctx && ctx->c.shard.count > 1 && ctx->c.shard.comm) { try { ctx->c.shard.comm->abort(); } catch (...) {} (void)hipStreamSynchronize(ctx->c.stream); }
+    if (ctx && ctx->c.shard.count > 1 && ctx->c.shard.comm) {
+        try { ctx->c.shard.comm->abort(); } catch (...) {}
+        // every stream of the context may still carry work of the failed proof (the main stream's handle, the side stream, both partners)
+        Ctx& c = ctx->c;
+        for (hipStream_t st : {c.stream, c.id_main, c.stream2, c.aux[0], c.aux[1]}) if (st) (void)hipStreamSynchronize(st);
+    }
 }
 
 static void fill_outputs(HipProver& pv, const BrainfuckProof& bp, char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds) {

@@ -7,6 +7,7 @@ re-serialises the literals below, so the fixture file and its provenance stay to
 import json
 import os
 
+P31 = (1 << 31) - 1  # stwo_prover::core::fields::m31::P (machine.rs:245)
 INV2 = 1073741824  # BaseField::from(2).inverse() = 2^-1 mod (2^31 - 1)   (machine.rs:427, processor/table.rs:773)
 
 # Trace of "+>,<[>+.<-]" with input [1]: rows (clk, ip, ci, ni, mp, mv, mvi) — crates/brainfuck_prover/src/components/processor/table.rs:698-818
@@ -242,6 +243,19 @@ vectors = {
         {"code": "++", "input": [], "cite": "crates/brainfuck_vm/src/machine.rs:394-431",
          "expected": [[0, 0, 43, 43, 0, 0, 0], [1, 1, 43, 0, 0, 1, 1], [2, 2, 0, 0, 0, 2, INV2]]},
         {"code": "+>,<[>+.<-]", "input": [1], "cite": "crates/brainfuck_prover/src/components/processor/table.rs:698-818", "expected": TRACE_A},
+    ],
+    # The VM's single-instruction unit tests (crates/brainfuck_vm/src/machine.rs:291-392). Each test hands the machine the program WORDS and
+    # asserts a few fields of the final state: `code_words` are those words (they equal what the compiler emits for `code`), `final` the
+    # asserted registers of the last trace row, `ram0` the asserted value of memory cell 0 (observable as `mv` of the last row whose mp is 0),
+    # `output` the asserted output bytes.
+    "vm_unit": [
+        {"cite": "machine.rs:291-301 (test_right_instruction)", "code": ">>", "code_words": [62, 62], "input": [], "final": {"mp": 2}},
+        {"cite": "machine.rs:303-312 (test_left_instruction)", "code": ">><", "code_words": [62, 62, 60], "input": [], "final": {"mp": 1}},
+        {"cite": "machine.rs:314-324 (test_plus_instruction)", "code": "+", "code_words": [43], "input": [], "final": {"mv": 1}, "ram0": 1},
+        {"cite": "machine.rs:326-336 (test_minus_instruction)", "code": "--", "code_words": [45, 45], "input": [], "final": {"mv": P31 - 2}, "ram0": P31 - 2},
+        {"cite": "machine.rs:338-350 (test_read_write_char)", "code": ",.", "code_words": [44, 46], "input": [97], "output": [97]},
+        {"cite": "machine.rs:352-370 (test_skip_loop)", "code": "[-]+", "code_words": [91, 4, 45, 93, 2, 43], "input": [], "final": {"mv": 1}, "ram0": 1},
+        {"cite": "machine.rs:372-392 (test_enter_loop)", "code": "+[+>]", "code_words": [43, 91, 6, 43, 62, 93, 3], "input": [], "final": {"mp": 1, "mv": 0}, "ram0": 2},
     ],
     "vm_outputs": [  # crates/brainfuck_vm/tests/integration.rs:12-104
         {"program": "a-bc.bf", "input": [97], "expected": [98, 99]},

@@ -85,6 +85,22 @@ def test_trace_golden(oracle, host, v):
     assert tr2.tolist() == v["expected"]
 
 
+@pytest.mark.parametrize("v", V["vm_unit"], ids=lambda v: v["cite"].split("(")[1].rstrip(")"))
+def test_vm_unit_cases(oracle, host, v):
+    """The reference's seven single-instruction VM tests (machine.rs:291-392): the words it hands the machine are what both compilers emit,
+    and the asserted fields of the final state hold for both VMs."""
+    for side in (oracle, host):
+        assert side.compile(v["code"]) == v["code_words"]
+        out, tr = side.run(v["code"], bytes(v["input"]))
+        last = dict(zip(("clk", "ip", "ci", "ni", "mp", "mv", "mvi"), tr[-1].tolist()))
+        for reg, want in v.get("final", {}).items():
+            assert last[reg] == want, (reg, last)
+        if "ram0" in v:     # memory cell 0 = mv of the last row recorded with the pointer on it
+            assert [r for r in tr.tolist() if r[4] == 0][-1][5] == v["ram0"]
+        if "output" in v:
+            assert list(out) == v["output"]
+
+
 @pytest.mark.parametrize("v", V["vm_outputs"], ids=lambda v: v["program"])
 def test_vm_outputs_golden(oracle, host, v):
     out, tr = oracle.run(prog(v["program"]), bytes(v["input"]))
