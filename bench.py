@@ -59,6 +59,14 @@ def load_package():
     return mod
 
 
+def kernel_sources_sha256():
+    """SHA-256 over the sources of the dominant kernel (what a committed counter file must have been measured on)."""
+    h = hashlib.sha256()
+    for rel in ("stwo-brainfuck_amd/csrc/merkle.hip", "stwo-brainfuck_amd/csrc/kernels.h", "stwo-brainfuck_amd/csrc/m31.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
+
+
 def committed_digests():
     try:
         return json.load(open(os.path.join(ROOT, "tests", "golden", "fib19_lmr24_oracle_proof.json")))
@@ -116,6 +124,84 @@ def cpu_baseline(cells_per_proof, full=False):
     else:
         out.update(live)
     return out
+
+
+MAIN_COLS = [8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7]      # TraceColumn::count().0 per component, claim order (mod.rs:85-99)
+LOGUP_COLS = [1, 1, 1, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+
+
+def simdbackend_work_counts(log_sizes, lmr):
+    """Blake2s compressions and radix-2 butterflies a SimdBackend-shaped prover performs for one proof of a trace with these component sizes:
+    every column FULL SIZE (the reference broadcasts each table row into 16 lanes and its backend does not know it: memory/table.rs:95-104),
+    mixed-degree Merkle trees with one compression per 64 message bytes (children 64 B, then 16 column words per block), interpolate +
+    evaluate-on-the-blowup-domain per committed column (mod.rs:497,550-583,690-723 and the composition commit inside prover::prove). Only these
+    two loops are counted — a lower bound of the work."""
+    def tree(col_logs):
+        mx, total = max(col_logs), 0
+        for lg in range(mx, -1, -1):
+            ncols = sum(1 for c in col_logs if c == lg)
+            msg = (64 if lg < mx else 0) + 4 * ncols
+            total += (1 << lg) * max(1, -(-msg // 64))
+        return total
+    pre = [l + 1 for l in range(lmr, 3, -1)]
+    main = [l + 1 for l, m in zip(log_sizes, MAIN_COLS) for _ in range(m)]
+    inter = [l + 1 for l, n in zip(log_sizes, LOGUP_COLS) for _ in range(4 * n)]
+    comp_log = max(log_sizes) + 1
+    comp = [comp_log + 1] * 4
+    sizes = sorted(set(pre + main + inter + comp), reverse=True)
+    trees = [pre, main, inter, comp, [sz for sz in sizes for _ in range(4)]] + [[line] * 4 for line in range(sizes[0] - 1, 1, -1)]
+    compressions = sum(tree(t) for t in trees)
+    butterflies = 0
+    for lde in pre + main + inter + comp:      # iFFT on 2^(lde-1) points, FFT on 2^lde points: n/2 butterflies per layer
+        n = lde - 1
+        butterflies += n * (1 << (n - 1)) + lde * (1 << (lde - 1))
+    return compressions, butterflies
+
+
+def simd_bound(gpu_seconds_per_proof, log_sizes, lmr, seconds_each=4.0):
+    """cpu_baseline.simd_bound: the host's vector units on the two loops the reference's SimdBackend + rayon prover cannot avoid (oracle/
+    simd_bound.cpp: 16-lane Blake2s compression, packed M31 butterfly; AVX-512 if the host has it, else AVX2; every hardware thread busy,
+    operands in registers) -> a LOWER bound of the reference's proving time on this host and the speedup the GPU has over that bound."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import Oracle
+    L = Oracle().L
+    L.orc_simd_bound.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = (ctypes.c_double * 4)()
+    L.orc_simd_bound(avail, seconds_each, out)
+    comp_rate, bfly_rate, width, threads = out[0], out[1], int(out[2]), int(out[3])
+    if width == 0 or comp_rate <= 0 or bfly_rate <= 0:
+        return {"error": "the host has neither AVX-512 nor AVX2"}
+    # One thread alone: what a core of this host does when nothing else competes. The all-thread run above is what the box GIVES this process
+    # (cgroup CPU quotas and the other tenants of the host included); `threads x single-thread rate` is what the hardware could do at most
+    # (SMT siblings do not double a vector loop, so it overstates the host) — the stricter of the two bounds decides the north-star sentence.
+    one = (ctypes.c_double * 4)()
+    L.orc_simd_bound(1, min(seconds_each, 2.0), one)
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        cpu_quota = None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 1)
+    except Exception:
+        cpu_quota = None
+    comps, bflies = simdbackend_work_counts(log_sizes, lmr)
+    t_hash, t_fft = comps / comp_rate, bflies / bfly_rate
+    ideal_comp, ideal_bfly = max(comp_rate, one[0] * avail), max(bfly_rate, one[1] * avail)
+    t_ideal = comps / ideal_comp + bflies / ideal_bfly
+    ratio_measured = (t_hash + t_fft) / gpu_seconds_per_proof
+    ratio = t_ideal / gpu_seconds_per_proof
+    return {"instruction_set": "AVX-512 (16 x u32 per register)" if width == 512 else "AVX2 (two 8-lane halves per 16 lanes)", "threads": threads, "host_cores_available": avail,
+            "blake2s_compressions_per_s": comp_rate, "m31_butterflies_per_s": bfly_rate,
+            "single_thread": {"blake2s_compressions_per_s": one[0], "m31_butterflies_per_s": one[1]}, "cgroup_cpu_quota_cores": cpu_quota,
+            "seconds_lower_bound_if_every_hardware_thread_ran_at_the_single_thread_rate": t_ideal,
+            "gpu_over_simd_bound_as_measured_on_all_threads": round(ratio_measured, 2),
+            "work_counted": {"blake2s_compressions": comps, "m31_butterflies": bflies,
+                             "note": "full-size columns (the reference's SimdBackend does not exploit the 16x lane broadcast), Merkle + channel hashing and the column transforms only"},
+            "seconds_lower_bound": {"hashing": t_hash, "transforms": t_fft, "total": t_hash + t_fft},
+            "cells_per_s_upper_bound": None,
+            "gpu_over_simd_bound": round(ratio, 2),       # against the STRICTER bound (hardware threads x single-thread rate, or the all-thread run if faster)
+            "north_star_10x": ("met even against the bound: a SimdBackend-shaped prover on every hardware thread of this host, each at the rate one thread reaches alone, cannot come within 10x" if ratio >= 10.0 else
+                               "not determined by the bound: the GPU proof is %.1fx faster than the fastest the host's vector units could hash and transform this trace; "
+                               "the real reference (constraints, quotients, logUp, memory traffic, rayon) is slower than the bound by an unknown factor" % ratio),
+            "stands_in_for": "brainfuck_prover prove --features parallel (README.md:23-36), 'Proof generation time' (bin/brainfuck_prover.rs:137-139): not buildable here"}
 
 
 def pick_device(local_rank, n_visible, override=None):
@@ -229,13 +315,41 @@ def probe_stages(args):
     return stages
 
 
-def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
+def probe_n1_reference(pkg, device, code, lmr, conv, max_log, steps):
+    """The same workload proved by ONE GPU alone (a context of its own, outside the group), timed right before the group proves it: what
+    `speedup_vs_n1` divides by. Every rank does this on its own GPU at the same time, so it costs the probe one proof's time, not N."""
+    c = pkg.Context(device, max_log_domain=max_log)
+    try:
+        c.set_conventions(*conv)
+        tr = pkg.Trace(c, code, b"")
+        try:
+            tr.prove(lmr); c.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                proof, _ = tr.prove(lmr)
+            c.sync()
+            return (time.perf_counter() - t0) / steps, hashlib.sha256(proof).hexdigest()
+        finally:
+            tr.close()
+    finally:
+        c.close()
+
+
+def probe_run_stages(pkg, members, stages, out, flush, is_rank0, ref_device=None, max_log=26):
     """Runs every stage on `members` (the contexts this process drives: one with RCCL, all N of an in-process group — one host thread
-    each). Results go to out["stages"][name]; a failed stage ends the probe (the other members may be inside its collectives)."""
+    each). Results go to out["stages"][name]; a failed stage ends the probe (the other members may be inside its collectives).
+    ref_device: the GPU this process times the one-GPU reference of every stage on (None: no reference)."""
     import threading
     for name, code, lmr, conv, warm, steps, overlap in stages:
         row = {"log_max_rows": lmr, "conventions": list(conv), "overlap_mask": overlap}
         out["stages"][name] = row
+        if ref_device is not None and not name.endswith("_exchange_overlap"):
+            try:
+                n1_sec, n1_sha = probe_n1_reference(pkg, ref_device, code, lmr, conv, max_log, max(1, min(steps, 3)))
+                row.update({"n1_ms_per_proof": round(n1_sec * 1e3, 3), "n1_proof_sha256": n1_sha})
+            except Exception as e:
+                row["n1_error"] = repr(e)
+            flush()
         n = len(members)
         gate = threading.Barrier(n)
         res, errors = [None] * n, []
@@ -284,12 +398,32 @@ def probe_run_stages(pkg, members, stages, out, flush, is_rank0):
                     "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()},
                     "comm_ms_per_proof_max_rank": {k: round(max(r[6][k] for r in res), 3) for k in comm_ms},
                     "comm_share_of_proof": round(sum(comm_ms.values()) / (dt * 1e3), 3)})
+        if "n1_ms_per_proof" in row:
+            row["speedup_vs_n1"] = round(row["n1_ms_per_proof"] / row["ms_per_proof"], 3)
+            row["identical_to_n1"] = row["n1_proof_sha256"] == row["proof_sha256"]
         if is_rank0:
             row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
         if name.startswith("fib19"):
             want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
             row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
         flush()
+
+
+def strong_scaling_summary(probe, world):
+    """Top-level digest of the shard probe for a SCALE record: per workload {ms_per_proof with all N GPUs on ONE proof, the one-GPU time of the
+    same proof measured in the same run, speedup_vs_n1, comm_share_of_proof, identical_to_n1}; RCCL (one process per GPU) first, the
+    in-process transport (one process driving all GPUs) beside it."""
+    def digest(p):
+        rows = {}
+        for name, st in (p or {}).get("stages", {}).items():
+            if "ms_per_proof" not in st:
+                rows[name] = {"error": st.get("error", "stage did not complete")}
+                continue
+            rows[name] = {k: st[k] for k in ("ms_per_proof", "n1_ms_per_proof", "speedup_vs_n1", "comm_share_of_proof", "identical_to_n1", "all_members_same_proof",
+                                             "cells_per_s", "proof_sha256") if k in st}
+        return {"transport": (p or {}).get("transport"), "error": (p or {}).get("error"), "workloads": rows}
+    return {"n_gpus": world, "what": "ONE proof over all N GPUs (shard group); value / ms_per_step above are the replicas (N independent proofs)",
+            "rccl": digest(probe), "single_process": digest(probe.get("single_process")) if isinstance(probe, dict) and "single_process" in probe else None}
 
 
 def shard_probe(args):
@@ -343,7 +477,8 @@ def shard_probe(args):
                     time.sleep(0.02)
                 members[0].join_rccl_group(open(idf, "rb").read(), rank, world)
         flush()
-        probe_run_stages(pkg, members, stages, out, flush, rank == 0)
+        ref_device = (devices[0] if args.probe_local else pick_device(local_rank, pkg.device_count(), args.device)) if world > 1 else None
+        probe_run_stages(pkg, members, stages, out, flush, rank == 0, ref_device=ref_device, max_log=max_log)
         out["transport"] = members[0].group_info()[2]
         for m in members:
             if world > 1:
@@ -498,7 +633,7 @@ def main():
     ap.add_argument("--no-shard-probe", action="store_true", help="N > 1, replicas mode: skip the extra strong-scaling measurement (one proof over all N GPUs) taken in child "
                     "processes before the timed replicas run")
     ap.add_argument("--probe-steps", type=int, default=8)
-    ap.add_argument("--probe-timeout", type=int, default=150)
+    ap.add_argument("--probe-timeout", type=int, default=240)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
     ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)
@@ -616,8 +751,17 @@ def main():
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # from the separate rocprofv3 --pmc passes of the latest round
         if pmc_files:
-            traffic = json.load(open(pmc_files[-1])).get(name, {}).get("hbm_bytes_per_launch")
-            traffic_src = os.path.relpath(pmc_files[-1], ROOT) + " (separate rocprofv3 --pmc passes of the same command; not collected in this run)"
+            # The counter passes are a separate command (rocprofv3 --pmc serialises the dispatches: it cannot run inside a timed region), so the
+            # figure is read from the latest committed file — and only trusted while the kernel it was taken on is the kernel that ran here:
+            # tools/pmc_traffic.py records the SHA-256 of the kernel sources; a mismatch (or a file without the record) reports null.
+            pmc = json.load(open(pmc_files[-1]))
+            want_src = pmc.get("_kernel_sources_sha256")
+            have_src = kernel_sources_sha256()
+            if want_src == have_src:
+                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(pmc_files[-1], ROOT) + " (separate rocprofv3 --pmc passes of the same command on the same kernel sources; not collected in this run)"
+            else:
+                traffic_src = os.path.relpath(pmc_files[-1], ROOT) + " is STALE: taken on other kernel sources (csrc/merkle.hip, csrc/kernels.h changed since) — traffic not reported; rerun tools/profile_round.sh pmc"
         hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"])}
         common = {"kernel": name, "traffic": traffic, "traffic_source": traffic_src, "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
@@ -703,6 +847,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # BASELINE.json's metric is quoted "at 2^22 rows": that point of the sweep, promoted (value above is the larger fib19 workload)
+            "metric_point": ({"workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')",
+                              "value": headline22["cells_per_s"], "unit": "trace cells/s", "ms_per_proof": headline22["ms_per_proof"], "cells": headline22["cells"],
+                              "proof_sha256": headline22["proof_sha256"], "verified": headline22["verified"]} if headline22 else None),
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
@@ -729,6 +877,7 @@ def main():
         if shard_probe_result is not None:
             # strong scaling beside the weak-scaling value: the same workload proved ONCE by all N GPUs together
             out["shard_group"] = shard_probe_result
+            out["strong_scaling"] = strong_scaling_summary(shard_probe_result, world)
         if world == 1 and not args.no_cpu_baseline:
             full = args.cpu_baseline == "full"
             if args.cpu_baseline == "auto":
@@ -743,6 +892,13 @@ def main():
             out["cpu_baseline"]["gpu_over_port"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
             if full and "proof_sha256" in out["cpu_baseline"]:
                 out["cpu_baseline"]["proof_identical_to_gpu"] = out["cpu_baseline"]["proof_sha256"] == digest
+            try:
+                sb = simd_bound(dt / args.steps, trace.log_sizes, args.log_max_rows)
+                if "seconds_lower_bound" in sb:
+                    sb["cells_per_s_upper_bound"] = cells / sb["seconds_lower_bound"]["total"]
+                out["cpu_baseline"]["simd_bound"] = sb
+            except Exception as e:
+                out["cpu_baseline"]["simd_bound"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if args.reuse_preprocessed:
         lib.bfhip_ctx_reuse_preprocessed(ctx._h, 0)

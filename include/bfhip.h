@@ -72,8 +72,14 @@ int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
  * are VALU-limited on gfx950 and stretch each other when they co-run: measured gain 0-0.3 ms of 31 (profiles/r03_overlap_ab*.txt).
  * bit 2 (shard groups only): the column -> row send-receive of a tree's largest size class is issued on the partner stream and overlaps the
  * transforms of the tree's smaller columns; the rest follows in a second send-receive on the same stream (every rank of the group must use
- * the same mask: it changes the number of collectives). Unmeasured on multi-GPU hardware. */
+ * the same mask: it changes the number of collectives). A context that never called this function (and was not created under BFHIP_OVERLAP)
+ * behaves as if bit 2 were set while it is a member of a group whose ranks sit on DIFFERENT GPUs (RCCL groups; in-process groups over several
+ * devices from their second collective on): there the exchange is an xGMI transfer. Calling it with bit 2 clear switches that default off.
+ * Unmeasured on multi-GPU hardware. */
 int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask);
+/* Device memory of this context in bytes: out[0] = reserved by its per-proof arena (1 GiB chunks, kept until the context is destroyed),
+ * out[1] = the arena's high-water mark over all proofs so far, out[2] = twiddle tree + inverse, out[3] = arena bytes in use now. */
+int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]);
 /* Host waits of this context: 0 (default) = poll briefly, then yield / block; 1 = hipStreamSynchronize at once (hosts with more waiting
  * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s). */
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);

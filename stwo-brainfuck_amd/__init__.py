@@ -128,6 +128,12 @@ class Context:
         groups): the send-receive of a tree's largest size class on the partner stream beside the transforms of the smaller columns."""
         _check(lib().bfhip_ctx_set_overlap(self._h, int(mask)))
 
+    def memory(self):
+        """bfhip_ctx_memory: {arena_reserved, arena_peak, twiddles, arena_in_use} in bytes."""
+        out = (ctypes.c_uint64 * 4)()
+        _check(lib().bfhip_ctx_memory(self._h, out))
+        return dict(zip(("arena_reserved", "arena_peak", "twiddles", "arena_in_use"), [int(v) for v in out]))
+
     def set_table_builder(self, on_gpu=True):
         """Where this context builds the 13 component tables: GPU kernels (default) or the host builders. Identical results."""
         _check(lib().bfhip_ctx_set_table_builder(self._h, int(on_gpu)))

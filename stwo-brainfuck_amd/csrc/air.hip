@@ -385,10 +385,17 @@ __global__ void __launch_bounds__(256) k_logup_rows(const LogupBatch* __restrict
         Q31 d01 = q_mul(d0, d1), inv_all = q_inv(q_mul(d01, d2));
         Q31 i2 = q_mul(inv_all, d01), i01 = q_mul(inv_all, d2);
         Q31 i0 = q_mul(i01, d1), i1 = q_mul(i01, d0);
+        // (a null coordinate column is one this rank of a shard group does not keep: its owner writes it)
         cur = q_mul(num, i0);
-        a.out_rep[0][r] = cur.a.a; a.out_rep[1][r] = cur.a.b; a.out_rep[2][r] = cur.b.a; a.out_rep[3][r] = cur.b.b;
+        if (a.out_rep[0]) a.out_rep[0][r] = cur.a.a;
+        if (a.out_rep[1]) a.out_rep[1][r] = cur.a.b;
+        if (a.out_rep[2]) a.out_rep[2][r] = cur.b.a;
+        if (a.out_rep[3]) a.out_rep[3][r] = cur.b.b;
         cur = q_add(cur, q_mul(num, i1));
-        a.out_rep[4][r] = cur.a.a; a.out_rep[5][r] = cur.a.b; a.out_rep[6][r] = cur.b.a; a.out_rep[7][r] = cur.b.b;
+        if (a.out_rep[4]) a.out_rep[4][r] = cur.a.a;
+        if (a.out_rep[5]) a.out_rep[5][r] = cur.a.b;
+        if (a.out_rep[6]) a.out_rep[6][r] = cur.b.a;
+        if (a.out_rep[7]) a.out_rep[7][r] = cur.b.b;
         cur = q_add(cur, q_mul(num, i2));
     } else {
         int rel, dcol, mode;   // mode 0: d - 1, 1: 1 - d, 2: -1

@@ -30,7 +30,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
-    if (const char* v = getenv("BFHIP_OVERLAP")) overlap = (u32)atoi(v) & 7u;
+    if (const char* v = getenv("BFHIP_OVERLAP")) { overlap = (u32)atoi(v) & 7u; overlap_user_set = true; }
     for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
@@ -230,6 +230,16 @@ int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask) {
     if (mask > 7) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer, bit 2 = shard-group exchanges");
     ctx->c.sync();
     ctx->c.overlap = mask;
+    ctx->c.overlap_user_set = true;      // also switches OFF the default exchange overlap of a multi-GPU shard group when bit 2 is clear
+    return 0;
+    API_CATCH
+}
+int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]) {
+    API_CTX(ctx)
+    if (!out) throw HipError("null argument");
+    uint64_t reserved = 0;
+    for (auto& ch : ctx->c.arena.chunks) reserved += ch.size;
+    out[0] = reserved; out[1] = ctx->c.arena.peak; out[2] = (uint64_t)(2 * sizeof(u32)) << ctx->c.tw_root_log; out[3] = ctx->c.arena.total_used;
     return 0;
     API_CATCH
 }

@@ -29,6 +29,9 @@ struct Comm {
     // Point-to-point blocks. Sends to / receives from one peer are matched in list order. A block to oneself is a plain copy.
     virtual void exchange(hipStream_t s, const std::vector<Xfer>& sends, const std::vector<Xfer>& recvs) = 0;
     virtual const char* transport() const = 0;
+    // true when the ranks of the group sit on more than one GPU (RCCL: always; in-process: known once the first collective has seen every
+    // member's device) — then an exchange is a transfer over xGMI that the prover overlaps with the transforms still to be done
+    virtual bool spans_devices() const { return false; }
     // Asynchronous failure of the transport (RCCL: ncclCommGetAsyncError). Called while the host waits for the stream; throws.
     virtual void check_async() {}
     // Gives up on the group after a failure or a timeout so that blocked peers and streams are released (RCCL: ncclCommAbort).

@@ -147,6 +147,7 @@ struct LocalComm : Comm {
         (void)hipFree(scratch);
     }
     void abort() override { g->fail(); }
+    bool spans_devices() const override { return multi_device; }
     const char* transport() const override {
         return multi_device ? "local (N contexts of one process on one GPU each, peer copies ordered by HIP events)"
                             : "local (N contexts of one process, device-to-device copies ordered by HIP events)";
@@ -346,6 +347,7 @@ struct RcclComm : Comm {
             throw HipError(std::string("shard group: RCCL reported an asynchronous error: ") + (rccl().GetErrorString ? rccl().GetErrorString(st) : "?"));
     }
     void abort() override { if (comm && !aborted && rccl().CommAbort) { aborted = true; (void)rccl().CommAbort(comm); } }
+    bool spans_devices() const override { return count > 1; }
     const char* transport() const override {
         // an overridden library path is visible to whoever asks which transport a group runs on (bfhip_ctx_group_info)
         static const std::string over = [] { const char* v = getenv("BFHIP_RCCL_LIBRARY"); return v ? std::string("RCCL entry points from BFHIP_RCCL_LIBRARY=") + v : std::string(); }();

@@ -56,6 +56,10 @@ struct Ctx {
     // overlap: bit 0 = hash a tree's largest layers beside the transforms of its smaller columns; bit 1 = hash the FRI first-layer tree level by
     // level behind the quotient launches; bit 2 (shard groups) = the send-receive of a tree's largest size class on aux[0] beside the transforms of
     // its smaller columns (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
+    bool overlap_user_set = false;   // bfhip_ctx_set_overlap / BFHIP_OVERLAP decided the mask: no default is applied on top of it
+    // bit 2 is ON BY DEFAULT for a shard group whose ranks sit on different GPUs (exchange_overlapped()): there an exchange is an xGMI transfer
+    // that costs the stream nothing but waiting; on one shared GPU it is a copy competing for the same HBM (r03: 38.5 vs 38.8 ms) and stays off
+    bool exchange_overlapped() const { return (overlap & 4u) != 0 || (!overlap_user_set && shard.count > 1 && shard.comm && shard.comm->spans_devices()); }
     u32 overlap = 0;      // measured (profiles/r03_overlap_ab*.txt): bit 1 gains 0-0.3 ms on fib19 box to box, bit 0 nothing — both sides of either overlap are
                           // VALU-limited (co-running kernels stretch each other), and the dominant kernel's event-timed roofline would include the interference
     hipStream_t aux[2] = {nullptr, nullptr};

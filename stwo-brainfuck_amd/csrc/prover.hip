@@ -202,7 +202,6 @@ struct HipProver {
                 u32 sh = log < (int)mk.max_log ? (mk.shifts[log + 1] ? mk.shifts[log + 1] - 1 : 0) : 32;
                 while (ci < cols.size() && cols[ci].log_size == (u32)log) { sh = std::min(sh, cols[ci].shift); p.bytes[log] += 4.0 * cols[ci].stored(); all.push_back(cols[ci++].desc()); }
                 mk.shifts[log] = std::min<u32>(sh == 32 ? 0 : sh, (u32)log);
-                mk.layers[log] = (u32*)c.arena.alloc((size_t(32) << log) >> mk.shifts[log]);
             }
         }
         p.n_all = all.size();
@@ -234,6 +233,16 @@ struct HipProver {
             for (auto& col : cols) if (col.sliced() && ((int)col.log_size < mk.band_lo || (int)col.log_size > mk.band_hi)) throw HipError("shard group: a row-sharded column lies outside the share-wise Merkle band");
         }
         const bool banded = mk.band_hi >= mk.band_lo;
+        // Storage of the levels. A share-wise level above the band's lowest holds only this rank's nodes (its children and its decommitment
+        // reads are its own), addressed through a virtual base like a row-sharded column: a 2^26-row trace has ~40 GB of hashes, and eight
+        // ranks each reserving all of them would not fit one GPU's — or, on eight GPUs, waste seven eighths of — memory.
+        for (int log = (int)mk.max_log; log >= 0; log--) {
+            const size_t stored = (size_t(1) << log) >> mk.shifts[log];
+            if (banded && log > mk.band_lo && log <= mk.band_hi) {
+                const size_t per_rank = stored >> sg.log_count;
+                mk.layers[log] = reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(c.arena.alloc(32 * per_rank)) - 32 * per_rank * sg.rank);
+            } else mk.layers[log] = (u32*)c.arena.alloc(32 * stored);
+        }
         // levels [sub_hi .. 9]: one launch, a workgroup per node of level 9 — over complete, un-replicated levels only (below the band of a
         // shard group's tree); complete levels above sub_hi are single-level launches
         if (fused_top == 10 && mk.max_log >= 11) {
@@ -383,22 +392,28 @@ struct HipProver {
     bool sharded() const { return c.shard.count > 1; }
     u32 lc() const { return c.shard.log_count; }
     bool slice_log(u32 log) const { return sharded() && log >= lc() + SLICE_MIN_LOG_PER_RANK; }
+    // A 16x-replicated (row-granular, shift = 4) column is cut into row ranges when a rank's range still holds 2^14 STORED words — then every
+    // layer it enters lies inside the share-wise Merkle band (merkle_plan) and its rows' constraint / quotient launches are range-restricted.
+    bool slice_col(u32 log, u32 shift) const { return sharded() && log >= shift + lc() + SLICE_MIN_LOG_PER_RANK; }
     size_t slice_cells(u32 log) const { return size_t(1) << (log - lc()); }
     size_t slice_first(u32 log) const { return (size_t)c.shard.rank << (log - lc()); }
-    // storage for this rank's row range of a 2^log column, returned as a virtual base (see DCol)
-    u32* alloc_slice(u32 log) { return reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(c.alloc_u32(slice_cells(log))) - sizeof(u32) * slice_first(log)); }
+    // storage for this rank's row range of a 2^log column (stored at one word per 2^shift rows), returned as a virtual base (see DCol)
+    u32* alloc_slice(u32 log, u32 shift = 0) {
+        return reinterpret_cast<u32*>(reinterpret_cast<uintptr_t>(c.alloc_u32(slice_cells(log) >> shift)) - sizeof(u32) * (slice_first(log) >> shift));
+    }
     // Column-sharding of the transforms: the biggest column goes to the least loaded rank (greedy by 2^log, deterministic on every rank).
     std::vector<u32> assign_owners(const std::vector<DCol>& polys, u32 log_blowup) const {
         std::vector<u32> owner(polys.size(), OWNER_ALL);
         if (!sharded()) return owner;
         std::vector<size_t> idx;
-        for (size_t i = 0; i < polys.size(); i++) if (polys[i].shift == 0 && slice_log(polys[i].log_size + log_blowup)) idx.push_back(i);
-        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return polys[a].log_size > polys[b].log_size; });
+        for (size_t i = 0; i < polys.size(); i++) if (slice_col(polys[i].log_size + log_blowup, polys[i].shift)) idx.push_back(i);
+        // by transform work = stored words (a replicated column is a 16x smaller transform)
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return polys[a].log_size - polys[a].shift > polys[b].log_size - polys[b].shift; });
         std::vector<u64> load(c.shard.count, 0);
         for (size_t i : idx) {
             u32 best = 0;
             for (u32 r = 1; r < c.shard.count; r++) if (load[r] < load[best]) best = r;
-            owner[i] = best; load[best] += u64(1) << polys[i].log_size;
+            owner[i] = best; load[best] += u64(1) << (polys[i].log_size - polys[i].shift);
         }
         return owner;
     }
@@ -418,10 +433,12 @@ struct HipProver {
             else {
                 if (t.owner[i] == c.shard.rank) {
                     full[i] = e; full[i].ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(full[i]);
-                    if (with_prev) { fullprev[i] = e; fullprev[i].ptr = c.alloc_u32(e.stored()); }
+                    if (with_prev && e.shift == 0) { fullprev[i] = e; fullprev[i].ptr = c.alloc_u32(e.stored()); }
                 }
-                e.lc = lc(); e.ptr = alloc_slice(e.log_size);
-                if (with_prev) { t.prev[i] = e; t.prev[i].ptr = alloc_slice(e.log_size); }
+                e.lc = lc(); e.ptr = alloc_slice(e.log_size, e.shift);
+                // previous-row copies: of the full-size columns only (the last logUp column of each component; a replicated column has no
+                // mask offset -1)
+                if (with_prev && e.shift == 0) { t.prev[i] = e; t.prev[i].ptr = alloc_slice(e.log_size); }
             }
             t.evals[i] = e;
         }
@@ -429,17 +446,18 @@ struct HipProver {
         auto exchange_columns = [&](hipStream_t comm_stream, const std::vector<size_t>& idx, hipEvent_t after_copies) {
             std::vector<Xfer> sends, recvs;
             for (size_t i : idx) {
-                const u32 el = t.evals[i].log_size;
-                const size_t cells = slice_cells(el), bytes = cells * sizeof(u32), first = slice_first(el);
+                const u32 el = t.evals[i].log_size, sh = t.evals[i].shift;
+                const size_t cells = slice_cells(el) >> sh, bytes = cells * sizeof(u32), first = slice_first(el) >> sh;      // in stored words
+                const bool wp = with_prev && sh == 0;
                 if (t.owner[i] == c.shard.rank) {
-                    if (with_prev) prev_row_copy(c.stream, fullprev[i].ptr, full[i].ptr, t.polys[i].log_size);
+                    if (wp) prev_row_copy(c.stream, fullprev[i].ptr, full[i].ptr, t.polys[i].log_size);
                     for (u32 r = 0; r < c.shard.count; r++) {
                         sends.push_back({r, full[i].ptr + r * cells, bytes});
-                        if (with_prev) sends.push_back({r, fullprev[i].ptr + r * cells, bytes});
+                        if (wp) sends.push_back({r, fullprev[i].ptr + r * cells, bytes});
                     }
                 }
                 recvs.push_back({t.owner[i], t.evals[i].ptr + first, bytes});
-                if (with_prev) recvs.push_back({t.owner[i], t.prev[i].ptr + first, bytes});
+                if (wp) recvs.push_back({t.owner[i], t.prev[i].ptr + first, bytes});
             }
             if (recvs.empty()) return;
             if (comm_stream != c.stream) { BF_HIP(hipEventRecord(after_copies, c.stream)); BF_HIP(hipStreamWaitEvent(comm_stream, after_copies, 0)); }
@@ -453,7 +471,7 @@ struct HipProver {
         // bfhip_ctx_set_overlap bit 2 (shard groups): the largest size class is transformed first and travels on the partner stream while the
         // remaining columns are being transformed; the second send-receive follows on the same partner stream (every rank issues the group's
         // collectives in one order), and the main stream resumes behind both. Needs at least two size classes among the owned columns.
-        if (sharded() && (c.overlap & 4u) && !second_wave.empty() && c.aux[0]) {
+        if (sharded() && c.exchange_overlapped() && !second_wave.empty() && c.aux[0]) {
             std::vector<DCol> sa, da, sb2, db2;
             {
                 size_t k = 0;   // fsrc / fdst hold, in index order, every column this rank transforms
@@ -665,16 +683,28 @@ struct HipProver {
             for (int k = 0; k < N_COMPONENTS; k++) {
                 bp.log_sizes[k] = in.log_sizes[k];
                 if (bp.log_sizes[k] > log_max_rows) throw HipError("a component exceeds LOG_MAX_ROWS");
-                for (u32 j = 0; j < n_main_cols(k); j++) {
-                    DCol p = rows[k][j]; p.ptr = c.alloc_u32(p.stored());
-                    trees[1].polys.push_back(p);
-                }
+                for (u32 j = 0; j < n_main_cols(k); j++) { DCol p = rows[k][j]; p.ptr = nullptr; trees[1].polys.push_back(p); }
             }
             {
                 std::vector<DCol> src;
                 for (int k = 0; k < N_COMPONENTS; k++) for (auto& r : rows[k]) src.push_back(r);
-                if (sharded()) { fft_cols(true, src, trees[1].polys); commit_tree(trees[1], pinned_root1); }
-                else commit_tree_overlapped(trees[1], pinned_root1, &src);
+                if (sharded()) {
+                    // Shard group: the main-trace columns are column-sharded like the other trees' — a column of at least 2^14 stored words
+                    // per rank after the extension is interpolated and extended by its owner only, which then hands every rank its row
+                    // range (row-granular: a sixteenth of the bytes of a full-size column); the small ones are transformed by every rank.
+                    trees[1].owner = assign_owners(trees[1].polys, cfg.log_blowup);
+                    std::vector<DCol> s_mine, p_mine;
+                    for (size_t i = 0; i < src.size(); i++) {
+                        if (trees[1].owner[i] != OWNER_ALL && trees[1].owner[i] != c.shard.rank) continue;
+                        trees[1].polys[i].ptr = c.alloc_u32(trees[1].polys[i].stored());
+                        s_mine.push_back(src[i]); p_mine.push_back(trees[1].polys[i]);
+                    }
+                    fft_cols(true, s_mine, p_mine);
+                    commit_tree(trees[1], pinned_root1);
+                } else {
+                    for (auto& p : trees[1].polys) p.ptr = c.alloc_u32(p.stored());
+                    commit_tree_overlapped(trees[1], pinned_root1, &src);
+                }
             }
             BF_HIP(hipEventRecord(c.ev[2], c.stream));
             c.sync();
@@ -1084,7 +1114,8 @@ struct HipProver {
             for (int w = 0; w < 4; w++) q.c[w] = sl ? alloc_slice(log) : c.alloc_u32(size_t(1) << log);
             QuotientArgs a{};
             if (sl) { a.row0 = (u32)slice_first(log); a.n_rows = (u32)slice_cells(log); }
-            for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && flat[k].col.shift == 0) throw HipError("quotients: inconsistent row-sharding in a size group");
+            // a full-size column of the group is row-sharded exactly when the group is; a replicated one may also be complete on every rank
+            for (size_t k = i; k < j; k++) if (flat[k].col.sliced() != sl && (flat[k].col.shift == 0 || flat[k].col.sliced())) throw HipError("quotients: inconsistent row-sharding in a size group");
             a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
             a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
             a.n_batches = (u32)batches.size(); a.log = log; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;

@@ -243,3 +243,42 @@ def test_a_failing_rank_releases_the_group_instead_of_hanging_it(pkg):
         assert tm["all_gather_ms"] > 0 and tm["exchange_ms"] >= 0 and tm["max_reduce_ms"] > 0, tm
         c.leave_group(); c.close()
     group.close()
+
+
+@pytest.mark.single_conv
+def test_config5_literal_shape_eight_ranks_2_to_26_rows_poseidon252(pkg):
+    """BASELINE config 5 as written — a 2^26-row trace, Poseidon252 MerkleOps, 8 ranks — on the one GPU of the test box: eight contexts of this
+    process (in-process transport), ONE proof, every rank's bytes hash to the SHA-256 of the single-GPU proof of the same trace
+    (test_gpu_prove.py::test_poseidon252_variant_on_a_2_to_26_row_trace; bench.py `poseidon252.proof_sha256` since round 2). Also checks that
+    the group divides the MEMORY of the proof: a rank's arena stays below a third of the single-GPU proof's 96 GB (share-wise Merkle levels
+    and row-sharded columns are stored share-wise), which is what lets eight ranks fit one 288 GB device at all."""
+    import hashlib
+    code = "+" * 14 + "[>" + "+" * 16000 + "[>+<-]<-]"
+    n = 8
+    pkg.set_default_conventions(0, 0, 0, 1)
+    try:
+        group = pkg.LocalGroup(n)
+        ctxs = [pkg.Context(0, max_log_domain=28) for _ in range(n)]
+        traces = [pkg.Trace(c, code, b"") for c in ctxs]
+        assert max(traces[0].log_sizes) == 26
+        proofs, errors = [None] * n, []
+
+        def run(r):
+            try:
+                ctxs[r].join_local_group(group, r)
+                proofs[r], _ = traces[r].prove(26)
+            except Exception as e:
+                errors.append(e)
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+        [t.start() for t in th]; [t.join() for t in th]
+        mem = [c.memory() for c in ctxs]
+        for r in range(n):
+            ctxs[r].leave_group(); traces[r].close(); ctxs[r].close()
+        group.close()
+        assert not errors, errors
+        for p in proofs:
+            assert hashlib.sha256(p).hexdigest() == "6f4e26cc34a101f77bee86b520882855f37d9646df7f163a59307d06d9264309"
+        assert max(m["arena_peak"] for m in mem) < 32 * 2**30, [round(m["arena_peak"] / 2**30, 1) for m in mem]
+    finally:
+        pkg.set_default_conventions(0, 0, 0, 0)

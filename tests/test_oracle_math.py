@@ -344,3 +344,33 @@ def test_fold_circle_into_line_matches_the_definition(oracle, log):
     assert oracle.L.orc_fold_circle_into_line(dp, sp, log, (ctypes.c_uint32 * 4)(*alpha)) == 0
     for k in range(4):
         assert np.array_equal(dst[k], want[k]), k
+
+
+# ---- oracle/simd_bound.cpp: the host-vector-unit bound of bench.py's cpu_baseline ---------------------------------------------------------
+def test_simd_bound_compression_is_rfc7693_and_vector_paths_agree(oracle):
+    """The 16-lane Blake2s loop whose rate bounds the reference's CPU path computes the RFC 7693 compression (its scalar instance against the
+    hashlib-pinned Python restatement), the AVX-512 and AVX2 instances agree lane for lane, and the packed M31 butterflies equal plain modular
+    arithmetic (skipped per instruction set on hosts that lack it)."""
+    import ctypes
+    from conftest import py_blake2s_compress, _B2S_IV
+    L = oracle.L
+    L.orc_simd_bound_blake_scalar.restype = ctypes.c_uint32
+    L.orc_simd_bound_blake_scalar.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int]
+    seed, iters = 0xC0FFEE, 5
+    M = 0xFFFFFFFF
+    h = [_B2S_IV[i] ^ ((seed + i) & M) for i in range(8)]
+    m = [(seed * 2654435761 + i) & M for i in range(16)]
+    for _ in range(iters):
+        h = py_blake2s_compress(h, m, t0=64, f0=0)
+        m[0] ^= h[0]; m[5] ^= h[3]; m[10] ^= h[5]; m[15] ^= h[7]
+    assert [L.orc_simd_bound_blake_scalar(iters, seed, w) for w in range(8)] == h
+    assert L.orc_simd_bound_selfcheck(0) in (0, -1) and L.orc_simd_bound_selfcheck(1) in (0, -1)
+
+
+def test_simd_bound_runs_and_reports_rates(oracle):
+    import ctypes
+    L = oracle.L
+    L.orc_simd_bound.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+    out = (ctypes.c_double * 4)()
+    L.orc_simd_bound(2, 0.2, out)
+    assert out[3] == 2 and (out[2] == 0 or (out[0] > 1e6 and out[1] > 1e7)), list(out)
