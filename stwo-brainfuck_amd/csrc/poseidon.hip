@@ -72,7 +72,7 @@ static const u32* poseidon_consts() {
     if (!g_poseidon_consts[dev]) {
         std::vector<u32> h;
         h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_DEV_R1, POSEIDON_DEV_R1 + 9); h.insert(h.end(), POSEIDON_DEV_R2, POSEIDON_DEV_R2 + 9);
-        for (int r = 0; r < 91; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
+        for (int r = 0; r < 92; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
         if (h.size() != POSEIDON_CONSTS_WORDS) throw std::runtime_error("poseidon constants: layout mismatch");
         u32* p = nullptr;
         if (hipMalloc((void**)&p, h.size() * sizeof(u32)) != hipSuccess) throw std::runtime_error("hipMalloc(poseidon constants)");

@@ -20,9 +20,9 @@ struct F9 { u32 l[9]; };          // 29-bit limbs: "normalised" = l[0..7] < 2^29
 
 static constexpr u32 M29 = (1u << 29) - 1;
 static constexpr u32 F9_C6 = 17u << 18;      // p = 1 + F9_C6 * 2^(29*6) + 2^19 * 2^(29*8)
-// round-constant table: per round 6 x 9 words — K0, K1, K2 (added to the S-box inputs; K0 = K1 = 0 in a partial round, whose constants for
-// elements 0 and 1 are folded into L) and L0, L1, L2 (added by the linear layer: folded constants + the multiples of p, spread over the
-// limbs, that keep every limb-wise difference and the reduction non-negative) — tools/gen_poseidon_constants.py
+// round-constant table, 92 rows of 6 x 9 words (tools/gen_poseidon_constants.py). Full rounds: K0, K1, K2 (added to the S-box inputs) and
+// L0, L1, L2 (added by the linear layer: multiples of p, spread over the limbs, that keep every limb-wise difference and the reduction
+// non-negative). Partial rounds: K2 and Lc only (hades_partial). Row 91: the constants of the change of state around the partial rounds.
 static constexpr u32 F9_ROUND_WORDS = 54;
 
 __device__ __forceinline__ Fe fe_load_const(const u32* p) { Fe r; for (int i = 0; i < 8; i++) r.l[i] = p[i]; return r; }
@@ -127,8 +127,8 @@ __device__ __forceinline__ F9 f9_reduce(F9 x) {
 
 // Hades permutation (width 3, x^3, 4 full + 83 partial + 4 full rounds, MDS [[3,1,1],[1,-1,1],[1,1,-2]]) on Montgomery forms.
 // State in: normalised limbs, values < 6 p. State out: normalised, < 3 p.
-// Linear layer per limb: o0 = 3 c0 + c1 + c2 + L0, o1 = c0 + c2 + L1 - c1, o2 = c0 + c1 + L2 - 2 c2 where c_i are the S-box outputs (in a
-// partial round c0, c1 are the state itself: their round constants are inside L). L1 and L2 carry 10 p spread so that limb i of L1 exceeds
+// Linear layer of a FULL round per limb: o0 = 3 c0 + c1 + c2 + L0, o1 = c0 + c2 + L1 - c1, o2 = c0 + c1 + L2 - 2 c2 where c_i are the S-box
+// outputs (the partial rounds run on another state: hades_partial below). L1 and L2 carry 10 p spread so that limb i of L1 exceeds
 // any c1 limb and limb i of L2 any 2 c2 limb, L0 carries 2 p; all three leave f9_reduce its slack. Bounds: tools/gen_poseidon_constants.py.
 template <bool FULL> __device__ __forceinline__ void hades_round(F9 (&s)[3], const u32* __restrict__ t) {
     F9 c0 = s[0], c1 = s[1];
@@ -143,18 +143,87 @@ template <bool FULL> __device__ __forceinline__ void hades_round(F9 (&s)[3], con
     }
     s[0] = f9_reduce(o0); s[1] = f9_reduce(o1); s[2] = f9_reduce(o2);
 }
+// ---- the 83 partial rounds on the state (T1, T2, c) -------------------------------------------------------------------------------------
+// Only element 2 passes the S-box there, so elements 0 and 1 are carried by ONE second-order sequence (derivation and constants:
+// tools/gen_poseidon_constants.py): per round  y = (c + K2)^3,  c' = 2 T1 + Lc - 2 y,  T' = 2 T1 + 4 T2 + y  — two outputs to bring back to
+// normalised limbs instead of three, a linear layer of 2 x 9 x 3 instructions instead of 3 x 9 x 3-4, and no table constant in the T update
+// (r03: 520 instructions per partial round, of which ~220 were the linear layer and its three carry sweeps; r04: ~455).
+// (a << S) + b in ONE instruction. The compiler prefers a shift and an add (or add3) for the two linear forms below — 6 instructions per limb
+// instead of 4; v_lshl_add_u32 is spelled out. _s: b is a table constant (wave-uniform, in an SGPR), _v: b is a lane value.
+template <int S> __device__ __forceinline__ u32 lshl_add_v(u32 a, u32 b) { u32 r; asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(S), "v"(b)); return r; }
+template <int S> __device__ __forceinline__ u32 lshl_add_s(u32 a, u32 b) { u32 r; asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(S), "s"(b)); return r; }
+// x normalised -> x / 2 mod p with limbs < 2^29 + 2^22 (lazily normalised): (x + p) / 2 = (x >> 1) + (p + 1) / 2 for odd x
+__device__ __forceinline__ F9 f9_half(const F9& x) {
+    const u32 odd = 0u - (x.l[0] & 1u);
+    F9 r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = (x.l[i] >> 1) | ((x.l[i + 1] & 1u) << 28);
+    r.l[8] = x.l[8] >> 1;
+    r.l[0] += odd & 1u; r.l[6] += odd & (17u << 17); r.l[8] += odd & (1u << 18);      // (p + 1) / 2 = 2^250 + 17 * 2^191 + 1
+    return r;
+}
+// s[0], s[1] (normalised, < 3 p) -> T1 = (s0 + s1) / 2, T2 = (s0 - s1) / 4, both normalised and < 4 p. S8 = 8 p spread (table row 91).
+__device__ __forceinline__ void hades_partial_begin(const F9 (&s)[3], F9& T1, F9& T2, const u32* __restrict__ S8) {
+    F9 sum, dif;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { sum.l[i] = s[0].l[i] + s[1].l[i]; dif.l[i] = s[0].l[i] + S8[i] - s[1].l[i]; }
+    f9_normalise(sum); f9_normalise(dif);
+    T1 = f9_half(sum); f9_normalise(T1);
+    T2 = f9_half(dif); f9_normalise(T2);
+    T2 = f9_half(T2); f9_normalise(T2);
+}
+// One partial round. T1 (the newer), T2 (the older): normalised (limbs 0..7 < 2^29 EXACTLY — the T update has no spare bit), values < 4 p;
+// c: normalised, < 3 p. The new T replaces the OLDER one in place (T2 becomes the newest): the caller alternates the two arguments
+// instead of moving 18 registers per round.
+__device__ __forceinline__ void hades_partial(const F9& T1, F9& T2, F9& c, const u32* __restrict__ t) {
+    const F9 y = f9_cube(f9_add_const(c, t + 18));
+    F9 cn, Tn;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        // 2 T1 + Lc - 2 y as 2 (T1 - y) + Lc: the difference may wrap, the sum is right mod 2^32 and lies in [0, 2^32) (Lc carries 10 p spread:
+        // every limb >= 2 y_i + 2^29 - 1) — a subtraction and one v_lshl_add per limb, and no 2 T1 shared with the line below
+        cn.l[i] = lshl_add_s<1>(T1.l[i] - y.l[i], t[45 + i]);
+        Tn.l[i] = lshl_add_v<1>(T1.l[i], lshl_add_v<2>(T2.l[i], y.l[i]));      // <= 7 (2^29 - 1) per limb, value < 26 p
+    }
+    c = f9_reduce(cn);
+    // T: subtract (q - 1) p with q = bits 251 and up estimated from limb 8 alone (at most one too small: the limbs below add < 9 to it),
+    // on top of a value-neutral bias — + 2^29 on limb 0, + 2^29 - 1 on limbs 1..7, - 1 on limb 8 — that keeps limbs 0 and 6 positive under
+    // the subtraction and is added where the carry arrives (one v_add3 per step); limbs stay <= 8 * 2^29 - 7 + 7 < 2^32. Result: < 3 * 2^251.
+    const u32 q = Tn.l[8] >> 19;
+    const u32 k = max(q, 1u) - 1u;                                     // <= 25
+    Tn.l[0] += (1u << 29) - k; Tn.l[6] -= __umul24(k, F9_C6); Tn.l[8] -= (k << 19) + 1u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { Tn.l[i + 1] += (Tn.l[i] >> 29) + (i < 7 ? M29 : 0u); Tn.l[i] &= M29; }
+    T2 = Tn;
+}
+// back to (s0, s1): s0 = T1 + 2 T2 + A, s1 = T1 - 2 T2 + B (A, B: table row 91, with their spread multiples of p)
+__device__ __forceinline__ void hades_partial_end(F9 (&s)[3], const F9& T1, const F9& T2, const F9& c, const u32* __restrict__ t) {
+    F9 a, b;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { a.l[i] = T1.l[i] + 2u * T2.l[i] + t[27 + i]; b.l[i] = T1.l[i] + t[36 + i] - 2u * T2.l[i]; }
+    s[0] = f9_reduce(a); s[1] = f9_reduce(b); s[2] = c;
+}
 __device__ __forceinline__ void hades(F9 (&s)[3], const u32* __restrict__ table) {
     for (int r = 0; r < 4; r++) hades_round<true>(s, table + r * F9_ROUND_WORDS);
-    for (int r = 4; r < 87; r++) hades_round<false>(s, table + r * F9_ROUND_WORDS);
+    {
+        F9 T1, T2, c = s[2];
+        hades_partial_begin(s, T1, T2, table + 91 * F9_ROUND_WORDS);
+        for (int r = 4; r < 86; r += 2) {                                   // 41 pairs: after a pair T1 is the newer again
+            hades_partial(T1, T2, c, table + r * F9_ROUND_WORDS);
+            hades_partial(T2, T1, c, table + (r + 1) * F9_ROUND_WORDS);
+        }
+        hades_partial(T1, T2, c, table + 86 * F9_ROUND_WORDS);              // round 86: T2 is the newest (T^_86), T1 = T^_85
+        hades_partial_end(s, T2, T1, c, table + 91 * F9_ROUND_WORDS);
+    }
     for (int r = 87; r < 91; r++) hades_round<true>(s, table + r * F9_ROUND_WORDS);
 }
 
-// device constants block (poseidon.hip uploads it): P[8] (words), R1[9], R2[9] (F9: 2^261 mod p, 2^522 mod p), table[91][54]
+// device constants block (poseidon.hip uploads it): P[8] (words), R1[9], R2[9] (F9: 2^261 mod p, 2^522 mod p), table[92][54]
 struct PoseidonConsts {
     const u32* P; const u32* R1; const u32* R2; const u32* table;
     __device__ __forceinline__ explicit PoseidonConsts(const u32* base) : P(base), R1(base + 8), R2(base + 17), table(base + 26) {}
 };
-static constexpr u32 POSEIDON_CONSTS_WORDS = 26 + 91 * F9_ROUND_WORDS;
+static constexpr u32 POSEIDON_CONSTS_WORDS = 26 + 92 * F9_ROUND_WORDS;
 
 // canonical words -> Montgomery F9 (< 2 p), and back
 __device__ __forceinline__ F9 f9_from_canonical(const Fe& x, const PoseidonConsts& pc) { return f9_mul(to_f9(x), f9_load_const(pc.R2)); }

@@ -39,7 +39,7 @@ int main() {
       double n = (double)blocks * 256 * iters * 64;
       printf("v_mad_u64_u32: %.2f T/s chip-wide (%.2f lanes per clock per CU at 2.4 GHz)\n", n / ms / 1e9, n / (ms * 1e-3) / 256 / 2.4e9); }
     { std::vector<u32> h; h.insert(h.end(), POSEIDON_P, POSEIDON_P + 8); h.insert(h.end(), POSEIDON_DEV_R1, POSEIDON_DEV_R1 + 9); h.insert(h.end(), POSEIDON_DEV_R2, POSEIDON_DEV_R2 + 9);
-      for (int r = 0; r < 91; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
+      for (int r = 0; r < 92; r++) h.insert(h.end(), POSEIDON_DEV_ROUNDS[r], POSEIDON_DEV_ROUNDS[r] + F9_ROUND_WORDS);
       u32* c; hipMalloc(&c, h.size() * 4); hipMemcpy(c, h.data(), h.size() * 4, hipMemcpyHostToDevice);
       int blocks = 2048, iters = 8;
       k_hades<<<blocks, 128>>>(d, c, 1); hipDeviceSynchronize();

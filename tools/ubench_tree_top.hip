@@ -19,7 +19,7 @@ int main() {
     std::vector<uint4*> layers(max_log + 2);
     for (u32 lg = 0; lg <= max_log; lg++) { CK(hipMalloc((void**)&layers[lg], (size_t)32 << lg)); CK(hipMemset(layers[lg], 0x5a, (size_t)32 << lg)); td.layers[lg] = layers[lg]; td.shifts[lg] = 0; td.col_off[lg] = 0; }
     td.cols = nullptr; td.n_cols = 0; td.max_log = max_log;
-    uint4* big; CK(hipMalloc((void**)&big, (size_t)32 << 23)); CK(hipMemset(big, 1, (size_t)32 << 23));
+    uint4* big; CK(hipMalloc((void**)&big, (size_t)32 << 24)); CK(hipMemset(big, 1, (size_t)32 << 24));   // level 22 (128 MiB) followed by its children, level 23 (256 MiB)
     u32* chan; CK(hipMalloc((void**)&chan, 64 * 4)); CK(hipMemset(chan, 0, 64 * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto thrash = [&]() { merkle_layer(s, big, big + ((size_t)2 << 22), nullptr, 0, 22, 0.0, 0, 0, 0); };
