@@ -38,6 +38,8 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipEventCreateWithFlags(&block_ev, hipEventDisableTiming | hipEventBlockingSync));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
     BF_HIP(hipHostMalloc((void**)&h_small, h_small_bytes));
+    BF_HIP(hipHostGetDevicePointer((void**)&d_small_alias, h_small, 0));
+    BF_HIP(hipHostGetDevicePointer((void**)&d_hstage_alias, h_stage, 0));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
     BF_HIP(hipMalloc((void**)&d_counters, 4 * 64 * sizeof(u32)));
     BF_HIP(hipMemset(d_counters, 0, 4 * 64 * sizeof(u32)));

@@ -82,6 +82,12 @@ struct Ctx {
     // state); [4096, h_small_bytes): bounce buffer of read_back(). A pageable destination would make every such copy a blocking,
     // internally staged transfer.
     char* h_small = nullptr; size_t h_small_bytes = 256 << 10;
+    // The same pinned memory as the device sees it (hipHostGetDevicePointer): kernels write small results — roots, claimed sums, sampled
+    // values, decommitment words — straight into it, and the gather kernel reads its request list from the staging ring's host side. A
+    // result that crosses PCIe by the kernel's own stores needs no copy command behind the kernel (r04: ~8 us per Fiat-Shamir round trip:
+    // a blit dispatch and its barrier); the host reads it once the event recorded behind the kernel has completed (system-scope release).
+    char* d_small_alias = nullptr; char* d_hstage_alias = nullptr;
+    template <class T> T* small_alias(T* host_ptr) const { return reinterpret_cast<T*>(d_small_alias + (reinterpret_cast<char*>(host_ptr) - h_small)); }
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
 
     void init(int dev, u32 max_log_domain);
@@ -98,6 +104,10 @@ struct Ctx {
     // with more waiting contexts than cores. Inside a shard group every wait is BOUNDED: the transport is polled for asynchronous errors and
     // after comm_timeout_seconds() the group is aborted and the wait fails, instead of a stream that hangs on a peer that diverged.
     bool sync_blocking = false;
+    // how long a wait polls before it goes to sleep on the blocking event. Outside a proof 200 us; INSIDE a proof every wait is a Fiat-Shamir
+    // round trip with the GPU idle behind it, and the wake-up of a sleeping thread costs 10-15 us each time: the prover raises the limit to
+    // 8 ms for its duration (r04; one core spins while a proof is in flight, which is what a host thread per GPU is there for)
+    double spin_seconds = 200e-6;
     hipEvent_t block_ev = nullptr;   // hipEventBlockingSync: the only event a host thread SLEEPS on (sync_ev is polled)
     void sync() {
         const bool grouped = shard.count > 1 && shard.comm;
@@ -120,7 +130,7 @@ struct Ctx {
                     try { shard.comm->check_async(); } catch (...) { shard.comm->abort(); throw; }
                     if (waited > comm_timeout_seconds()) { shard.comm->abort(); throw HipError("shard group: the stream did not complete within the communication timeout (a peer failed or diverged)"); }
                     if (waited > 4e-3) { std::this_thread::sleep_for(std::chrono::microseconds(waited > 50e-3 ? 200 : 50)); continue; }
-                } else if (waited > 200e-6) {
+                } else if (waited > spin_seconds) {
                     // a long wait (a whole proof, a big trace): stop burning a core — sleep on an event created for blocking waits
                     // (an event without hipEventBlockingSync may be waited for by spinning inside the runtime)
                     if (block_ev) { BF_HIP(hipEventRecord(block_ev, stream)); BF_HIP(hipEventSynchronize(block_ev)); }

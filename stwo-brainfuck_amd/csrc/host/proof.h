@@ -36,7 +36,14 @@ inline void hash(std::string& s, const Hash32& h, bool felt) {
         s += '"';
         return;
     }
-    s += '['; for (int i = 0; i < 32; i++) { if (i) s += ','; num(s, h.b[i]); } s += ']';
+    // 32 byte values as decimal numbers: most of a proof's text (a proof holds ~1000 hashes). One table lookup and one append per byte.
+    struct ByteText { char t[256][4]; u8 n[256]; ByteText() { for (int v = 0; v < 256; v++) { int k = 0; if (v >= 100) t[v][k++] = (char)('0' + v / 100); if (v >= 10) t[v][k++] = (char)('0' + v / 10 % 10); t[v][k++] = (char)('0' + v % 10); n[v] = (u8)k; } } };
+    static const ByteText bt;
+    char buf[32 * 4 + 2]; int n = 0;
+    buf[n++] = '[';
+    for (int i = 0; i < 32; i++) { if (i) buf[n++] = ','; const u8 v = h.b[i]; for (int k = 0; k < bt.n[v]; k++) buf[n++] = bt.t[v][k]; }
+    buf[n++] = ']';
+    s.append(buf, (size_t)n);
 }
 template <class T, class Fn> void arr(std::string& s, const std::vector<T>& v, Fn f) { s += '['; for (size_t i = 0; i < v.size(); i++) { if (i) s += ','; f(v[i]); } s += ']'; }
 inline void decommitment(std::string& s, const MerkleDecommitment& d, bool felt) {

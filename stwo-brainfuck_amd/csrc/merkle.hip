@@ -376,6 +376,7 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32
                 node_hash_quad(ha, hb, has, ka, kb, kc, kd, cols, ncols, qn, rfc, qi);
                 u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
                 u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
+                if (lg == 0 && !chan && root_out) { root_out[qi] = ha; root_out[4 + qi] = hb; }     // the root, straight to where the host reads it
             }
         } else if (qn < n) {
             u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;

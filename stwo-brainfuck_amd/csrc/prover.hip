@@ -61,6 +61,19 @@ struct Gather {
         if (reqs.empty()) return out;
         c.stage_checkpoint();
         if (reqs.size() * sizeof(GatherReq) > c.stage_bytes / 4) throw HipError("decommitment: too many gather requests");
+        if (c.shard.count == 1 && n_words * sizeof(u32) <= c.h_small_bytes - 4096) {
+            // One process per proof: the kernel reads the request list where the host wrote it (the pinned side of the staging ring) and
+            // writes the words into the pinned bounce buffer — two copy commands and their barriers less on the last round trip of a proof.
+            size_t bytes = (reqs.size() * sizeof(GatherReq) + 255) & ~size_t(255);
+            if (c.stage_used + bytes > c.stage_bytes) throw HipError("staging buffer exhausted (call stage_checkpoint() between operations)");
+            memcpy(c.h_stage + c.stage_used, reqs.data(), reqs.size() * sizeof(GatherReq));
+            const GatherReq* d = reinterpret_cast<const GatherReq*>(c.d_hstage_alias + c.stage_used);
+            c.stage_used += bytes;
+            gather_u32(c.stream, d, (u32)reqs.size(), reinterpret_cast<u32*>(c.d_small_alias + 4096));
+            c.sync();
+            memcpy(out.data(), c.h_small + 4096, n_words * sizeof(u32));
+            return out;
+        }
         GatherReq* d = c.stage(reqs.data(), reqs.size());
         u32* dout = c.alloc_u32(n_words);
         gather_u32(c.stream, d, (u32)reqs.size(), dout);
@@ -127,6 +140,17 @@ struct HipProver {
         transcript += '\n';
     }
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    // BFHIP_TRACE_HOST=1: host-side timestamps of the Fiat-Shamir round trips of a proof (label, microseconds since the proof started),
+    // printed to stderr when the proof is done — what the host does while the GPU waits for a challenge (tools: point.py)
+    std::vector<std::pair<const char*, double>> host_marks;
+    bool trace_host = [] { const char* v = getenv("BFHIP_TRACE_HOST"); return v && v[0] == '1'; }();
+    double mark_t0 = 0;
+    void mark(const char* label) { if (trace_host) host_marks.push_back({label, (now() - mark_t0) * 1e6}); }
+    void print_marks() {
+        if (!trace_host) return;
+        double prev = 0;
+        for (auto& m : host_marks) { fprintf(stderr, "[bfhip host] %10.1f us  (+%7.1f)  %s\n", m.second, m.second - prev, m.first); prev = m.second; }
+    }
 
     // ---- batched FFT over heterogeneous columns: group by (size, storage) --------------------------------------------------
     // Two steps so that a caller can put the plan's staging into a batch shared with what follows (fft_prepare inside a StageBatch,
@@ -305,11 +329,13 @@ struct HipProver {
         prof_run_end(c.stream);
         apply_waits(0);
         if (p.sub_hi) merkle_subtree(c.stream, p.tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
-        if (fused_top > 0) merkle_top(c.stream, p.tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : nullptr, p.top_bytes, p.top_comp);
+        // a deferred root goes to its pinned slot by the top kernel's own stores (no copy command behind the tree)
+        u32* root_direct = (fused_top > 0 && !step && pinned_root) ? reinterpret_cast<u32*>(c.small_alias(pinned_root)) : nullptr;
+        if (fused_top > 0) merkle_top(c.stream, p.tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : root_direct, p.top_bytes, p.top_comp);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
-        if (pinned_root) { BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
+        if (pinned_root) { if (!root_direct) BF_HIP(hipMemcpyAsync(pinned_root->b, mk.layers[0], 32, hipMemcpyDeviceToHost, c.stream)); return mk; }
         c.read_back(mk.root.b, mk.layers[0], 32);
         return mk;
     }
@@ -616,6 +642,9 @@ struct HipProver {
     // run the VM and build the tables overlaps that host work with GPU work (bfhip_prove_brainfuck does).
     BrainfuckProof prove(const std::function<const TraceInput&()>& get_input) {
         double t_start = now();
+        mark_t0 = t_start;
+        struct SpinScope { Ctx& c; double saved; ~SpinScope() { c.spin_seconds = saved; } } spin_scope{c, c.spin_seconds};
+        c.spin_seconds = 8e-3;
         c.arena.reset();
         ch = Channel(c.conv);
         if (log_max_rows < LOG_N_LANES) throw HipError("log_max_rows must be at least LOG_N_LANES (4)");
@@ -667,7 +696,14 @@ struct HipProver {
             } catch (...) { if (use_side) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } throw; }
             if (use_side) std::swap(c.stream, c.stream2);
         }
-        auto join_side = [&]() { if (c.side_busy) { (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } };
+        // the side stream's work ends with ev[1]: when the event has completed there is nothing to wait for (a hipStreamSynchronize call
+        // costs ~13 us even then — on the critical path of the first Fiat-Shamir round trip)
+        auto join_side = [&]() {
+            if (!c.side_busy) return;
+            if (reuse || hipEventQuery(c.ev[1]) != hipSuccess) (void)hipStreamSynchronize(c.stream2);
+            (void)hipGetLastError();
+            c.side_busy = false;
+        };
         const TraceInput* in_p = nullptr;
         try { in_p = &get_input(); } catch (...) { join_side(); throw; }
         const TraceInput& in = *in_p;
@@ -679,6 +715,46 @@ struct HipProver {
             size_t mo = 0, io = 0;
             for (int k = 0; k < N_COMPONENTS; k++) { main_off[k] = mo; inter_off[k] = io; mo += n_main_cols(k); io += 4 * n_logup_cols(k); }
         }
+        // Everything the logUp launches need apart from the lookup elements (storage of the 60 interaction columns, the scratch of the scans,
+        // the launch table) is laid out while the GPU still hashes the main-trace tree (r04: 27 us off the first Fiat-Shamir round trip).
+        uint4* d_claimed = nullptr;
+        CompositionPlan composition_plan;
+        SamplePlan sample_plan;
+        std::vector<DCol> inter_vals;
+        std::vector<LogupLaunch> logups(N_COMPONENTS);
+        std::function<bool(size_t)> kept = [](size_t) { return true; };
+        auto prepare_logup = [&]() {
+            for (int k = 0; k < N_COMPONENTS; k++) bp.log_sizes[k] = in.log_sizes[k];
+            // the claimed sums: in HBM for a shard group (read back at once), else written by the scan kernel into their pinned slot
+            d_claimed = sharded() ? (uint4*)c.arena.alloc(sizeof(uint4) * N_COMPONENTS) : c.small_alias(reinterpret_cast<uint4*>(c.h_small + 2048));
+            // the interaction columns in commit order (mod.rs:690-702): per component its logUp columns but the last row-granular (4 coordinates
+            // each), then the last one full-size
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                const u32 log = bp.log_sizes[k], nl = n_logup_cols(k);
+                for (u32 j = 0; j < 4 * nl; j++) { DCol col; col.log_size = log; col.shift = j + 4 < 4 * nl ? LOG_N_LANES : 0; inter_vals.push_back(col); }
+            }
+            // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner of a
+            // coordinate column keeps, interpolates and extends it, so only the owner has the logUp kernel write it (the others pass a null
+            // pointer: no storage, no store); the row-granular columns and the small ones are written and transformed by every rank.
+            if (sharded()) trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
+            kept = [&](size_t i) { return !sharded() || trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank; };
+            for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) inter_vals[i].ptr = c.alloc_u32(inter_vals[i].stored());
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
+                size_t M = size_t(1) << log_rows;
+                LogupLaunch L{};
+                for (u32 j = 0; j < n_main_cols(k); j++) L.cols[j] = rows[k][j].ptr;
+                u32 nl = n_logup_cols(k);
+                for (u32 j = 0; j + 4 < 4 * nl; j++) L.out_rep[j] = inter_vals[inter_off[k] + j].ptr;
+                for (int w = 0; w < 4; w++) L.out_last[w] = inter_vals[inter_off[k] + 4 * (nl - 1) + w].ptr;
+                L.vrow = c.arena.alloc(sizeof(uint4) * M);
+                L.wloc = c.arena.alloc(sizeof(uint4) * M);
+                L.totals = c.arena.alloc(sizeof(uint4) * (M / 1024 + 2));
+                L.claimed = d_claimed + k;
+                L.log_rows = log_rows; L.comp = k;       // L.el: drawn after the main-trace root
+                logups[k] = L;
+            }
+        };
         try {
             for (int k = 0; k < N_COMPONENTS; k++) {
                 bp.log_sizes[k] = in.log_sizes[k];
@@ -707,9 +783,13 @@ struct HipProver {
                 }
             }
             BF_HIP(hipEventRecord(c.ev[2], c.stream));
+            mark("main tree enqueued");
+            prepare_logup();                 // host work under the main tree's kernels: only the lookup elements are missing afterwards
             c.sync();
+            mark("main root arrived");
         } catch (...) { join_side(); throw; }
         join_side();
+        mark("side stream joined");
         if (!reuse) {
             trees[0].mk.root = *pinned_root0;
             if (cache.enabled) {
@@ -738,44 +818,15 @@ struct HipProver {
         { Q31 z, a; ch.draw_two_felts(z, a); el.memory = make_lookup(z, a); }         // MemoryElements::draw
         { Q31 z, a; ch.draw_two_felts(z, a); el.instruction = make_lookup(z, a); }    // InstructionElements::draw
         { Q31 z, a; ch.draw_two_felts(z, a); el.processor = make_lookup(z, a); }      // ProcessorElements::draw
-        uint4* d_claimed = (uint4*)c.arena.alloc(sizeof(uint4) * N_COMPONENTS);
-        CompositionPlan composition_plan;
-        SamplePlan sample_plan;
-        std::vector<DCol> inter_vals;
-        std::vector<LogupLaunch> logups(N_COMPONENTS);
-        // the interaction columns in commit order (mod.rs:690-702): per component its logUp columns but the last row-granular (4 coordinates
-        // each), then the last one full-size
-        for (int k = 0; k < N_COMPONENTS; k++) {
-            const u32 log = bp.log_sizes[k], nl = n_logup_cols(k);
-            for (u32 j = 0; j < 4 * nl; j++) { DCol col; col.log_size = log; col.shift = j + 4 < 4 * nl ? LOG_N_LANES : 0; inter_vals.push_back(col); }
-        }
-        // Shard group: the full-size columns (each component's last logUp column, 4 coordinates) are column-sharded — only the owner of a
-        // coordinate column keeps, interpolates and extends it, so only the owner has the logUp kernel write it (the others pass a null
-        // pointer: no storage, no store); the row-granular columns and the small ones are written and transformed by every rank.
-        if (sharded()) trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
-        auto kept = [&](size_t i) { return !sharded() || trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank; };
-        for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) inter_vals[i].ptr = c.alloc_u32(inter_vals[i].stored());
-        for (int k = 0; k < N_COMPONENTS; k++) {
-            u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
-            size_t M = size_t(1) << log_rows;
-            LogupLaunch L{};
-            for (u32 j = 0; j < n_main_cols(k); j++) L.cols[j] = rows[k][j].ptr;
-            u32 nl = n_logup_cols(k);
-            for (u32 j = 0; j + 4 < 4 * nl; j++) L.out_rep[j] = inter_vals[inter_off[k] + j].ptr;
-            for (int w = 0; w < 4; w++) L.out_last[w] = inter_vals[inter_off[k] + 4 * (nl - 1) + w].ptr;
-            L.vrow = c.arena.alloc(sizeof(uint4) * M);
-            L.wloc = c.arena.alloc(sizeof(uint4) * M);
-            L.totals = c.arena.alloc(sizeof(uint4) * (M / 1024 + 2));
-            L.claimed = d_claimed + k;
-            L.el = el; L.log_rows = log_rows; L.comp = k;
-            logups[k] = L;
-        }
+        mark("lookup elements drawn");
+        for (auto& L : logups) L.el = el;
         {   // the 13 interaction_trace_evaluation calls (mod.rs:596-687) as one batch: four launches
             LogupBatch lb;
             logup_batch_init(lb, el, logups.data(), N_COMPONENTS);
             c.stage_checkpoint();
             logup_batch_run(c.stream, c.stage(&lb, 1), lb);
         }
+        mark("logUp launched");
         BF_HIP(hipGetLastError());
         trees[2].polys = inter_vals;          // interpolate in place
         auto take_claimed = [&](const uint4* h_claimed) {
@@ -796,10 +847,11 @@ struct HipProver {
             // kernels and the transforms).
             uint4* pinned_claimed = reinterpret_cast<uint4*>(c.h_small + 2048);
             Hash32* pinned_root2 = reinterpret_cast<Hash32*>(c.h_small + 2304);
-            BF_HIP(hipMemcpyAsync(pinned_claimed, d_claimed, sizeof(uint4) * N_COMPONENTS, hipMemcpyDeviceToHost, c.stream));
             commit_tree_overlapped(trees[2], pinned_root2, &inter_vals);
             composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);      // host work under the tree's kernels
+            mark("interaction tree enqueued + composition prepared");
             c.sync();
+            mark("interaction root arrived");
             take_claimed(pinned_claimed);
             trees[2].mk.root = *pinned_root2;
             ch.mix_root(trees[2].mk.root);
@@ -812,6 +864,7 @@ struct HipProver {
         Q31 random_coeff = ch.draw_felt();
         if (sharded()) composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);
         compute_composition(trees, bp, composition_plan, random_coeff);
+        mark("constraints + composition transforms launched");
         // per tree, per column: list of point indices (Components::mask_points + composition mask); independent of the challenges
         std::vector<std::vector<std::vector<u32>>> mask(4);
         mask[0].assign(trees[0].polys.size(), {});
@@ -832,7 +885,9 @@ struct HipProver {
             Hash32* pinned_root3 = reinterpret_cast<Hash32*>(c.h_small + 2368);
             commit_tree_overlapped(trees[3], pinned_root3);
             sample_plan = sample_prepare(trees, mask);
+            mark("composition tree enqueued + samples prepared");
             c.sync();
+            mark("composition root arrived");
             trees[3].mk.root = *pinned_root3;
             ch.mix_root(trees[3].mk.root);
         }
@@ -855,6 +910,7 @@ struct HipProver {
         for (int k = 0; k < N_COMPONENTS; k++) points[1 + k] = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
         if (sharded()) sample_plan = sample_prepare(trees, mask);
         sample(trees, mask, points, bp.proof, sample_plan);
+        mark("sampled values arrived");
         {
             std::vector<Q31> flat;
             for (auto& t : bp.proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v);
@@ -870,11 +926,20 @@ struct HipProver {
         std::vector<LevelWait> q_waits;
         std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff, &q_waits);
         BF_HIP(hipEventRecord(c.ev[5], c.stream));
+        mark("quotients launched");
         // no host wait here: the FRI phase is planned (layer storage, 26 tree layouts, one staging copy) while the quotient kernels run;
         // the phase time comes from the two events
 
         // ---- FRI commit (a10), proof of work (a11), decommitment (a12) -------------------------------------------------------------------
-        fri_and_decommit(trees, quotients, bp.proof, q_waits);
+        // Sanity check of prover::prove (composition OODS value == constraints evaluated on the sampled mask values): host arithmetic on values
+        // known since the sampling — done while the GPU runs the FRI commit phase, not after the proof's last kernel (r04)
+        auto sanity_check = [&]() {
+            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff, c.conv);
+            const auto& cv = bp.proof.sampled_values[3];
+            std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
+            if (!q_eq(HostPointEval::combine(ce, 0), want)) throw HipError("ConstraintsNotSatisfied");
+        };
+        fri_and_decommit(trees, quotients, bp.proof, q_waits, sanity_check);
         {
             float ms_q = 0.f;
             BF_HIP(hipEventElapsedTime(&ms_q, c.ev[4], c.ev[5]));      // both completed: fri_and_decommit ends with host waits
@@ -882,14 +947,9 @@ struct HipProver {
             tm.fri = (now() - t0) - tm.quotients;
         }
 
-        // Sanity check of prover::prove: composition OODS value == constraints evaluated on the sampled mask values.
-        {
-            Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff, c.conv);
-            const auto& cv = bp.proof.sampled_values[3];
-            std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
-            if (!q_eq(HostPointEval::combine(ce, 0), want)) throw HipError("ConstraintsNotSatisfied");
-        }
         tm.total = now() - t_start;
+        mark("done");
+        print_marks();
         return bp;
     }
 
@@ -1057,13 +1117,21 @@ struct HipProver {
         const EvalJob* d_jobs = jobs.empty() ? nullptr : c.stage(jobs.data(), jobs.size());
         sb.end();
         void* d_partials = c.arena.alloc(size_t(partial_off ? partial_off : 1) * sizeof(uint4));
-        uint4* d_out = (uint4*)c.arena.alloc(n_all * sizeof(uint4));
-        if (sharded()) BF_HIP(hipMemsetAsync(d_out, 0, n_all * sizeof(uint4), c.stream));
-        eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
-        BF_HIP(hipGetLastError());
-        if (sharded()) c.shard.comm->all_reduce_max_u32(c.stream, reinterpret_cast<u32*>(d_out), size_t(n_all) * 4);
         std::vector<uint4> out(n_all);
-        c.read_back(out.data(), d_out, out.size() * sizeof(uint4));
+        if (!sharded() && n_all * sizeof(uint4) <= c.h_small_bytes - 4096) {
+            // the second stage writes the samples into the pinned bounce buffer itself
+            eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, c.d_small_alias + 4096);
+            BF_HIP(hipGetLastError());
+            c.sync();
+            memcpy(out.data(), c.h_small + 4096, out.size() * sizeof(uint4));
+        } else {
+            uint4* d_out = (uint4*)c.arena.alloc(n_all * sizeof(uint4));
+            if (sharded()) BF_HIP(hipMemsetAsync(d_out, 0, n_all * sizeof(uint4), c.stream));
+            eval_at_points(c.stream, d_jobs, (u32)jobs.size(), partial_off, d_factors, d_partials, d_out);
+            BF_HIP(hipGetLastError());
+            if (sharded()) c.shard.comm->all_reduce_max_u32(c.stream, reinterpret_cast<u32*>(d_out), size_t(n_all) * 4);
+            c.read_back(out.data(), d_out, out.size() * sizeof(uint4));
+        }
         pf.sampled_values.resize(trees.size());
         size_t ji = 0;
         for (size_t t = 0; t < trees.size(); t++) {
@@ -1191,7 +1259,8 @@ struct HipProver {
         return v;
     }
 
-    void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf, const std::vector<LevelWait>& q_waits) {
+    void fri_and_decommit(std::vector<DTree>& trees, std::vector<DSecure>& quotients, StarkProof& pf, const std::vector<LevelWait>& q_waits,
+                          const std::function<void()>& while_the_commit_phase_runs) {
         // FriProver::commit — first layer: one Merkle tree over the coordinate columns of every quotient.
         // The channel is stepped on the device through the whole commit phase (k_channel_mix_root_draw): per layer mix_root(root) and
         // draw_felt() run as a one-lane kernel and the folds read alpha from device memory, so the ~25 layers are enqueued back to back
@@ -1356,7 +1425,17 @@ struct HipProver {
         {
             if (last_log != 1 || cfg.log_last_layer_degree_bound != 0) throw HipError("only the default FRI last-layer configuration is supported");
             std::vector<size_t> pos = {0, 1};
-            auto v = gather_secure(layer, pos);          // synchronises: roots and the device channel state are on the host now
+            mark("FRI commit phase enqueued");
+            Gather gl;
+            for (size_t p : pos) for (int w = 0; w < 4; w++) gl.add(layer.c[w], p, layer.mine(p, c.shard.rank));
+            // the commit phase (~100 launches) is in flight: the host does its own checks now; a failed check waits for the stream before it
+            // unwinds (the arena must not be handed out again under running kernels)
+            try { while_the_commit_phase_runs(); } catch (...) { (void)hipStreamSynchronize(c.stream); throw; }
+            mark("sanity check done");
+            auto dl = gl.run(c);
+            std::vector<Q31> v;
+            for (size_t k = 0; k < pos.size(); k++) v.push_back(q_make(dl[4 * k], dl[4 * k + 1], dl[4 * k + 2], dl[4 * k + 3]));          // synchronises: roots and the device channel state are on the host now
+            mark("FRI last layer arrived");
             if (!host_channel) {
                 first_tree.root = pinned_roots[0];
                 ch.mix_root(first_tree.root); (void)ch.draw_felt();
@@ -1380,6 +1459,14 @@ struct HipProver {
             for (;; nonce++) { Channel t = ch; t.mix_u64(nonce); if (t.trailing_zeros() >= cfg.pow_bits) break; if (nonce > (u64(1) << 32)) throw HipError("grind: no nonce found"); }
             pf.proof_of_work = nonce;
             ch.mix_u64(nonce);
+        } else if (cfg.pow_bits <= 10 && [&]() {
+            // A few bits of work are found faster by the host than by a launch and a read-back (~35 us): 2^pow_bits tries of one compression
+            // each on average. GrindOps asks for the SMALLEST nonce: a linear scan from zero finds it. Larger work goes to the GPU search.
+            for (u64 nonce = 0; nonce < (u64(64) << cfg.pow_bits); nonce++) {
+                Channel t = ch; t.mix_u64(nonce);
+                if (t.trailing_zeros() >= cfg.pow_bits) { pf.proof_of_work = nonce; ch.mix_u64(nonce); return true; }
+            }
+            return false; }()) {
         } else {
             c.stage_checkpoint();
             u32* d_digest = (u32*)c.stage(ch.digest.b, 32);
@@ -1394,6 +1481,7 @@ struct HipProver {
             pf.proof_of_work = best;
             ch.mix_u64(best);
         }
+        mark("nonce found");
 
         // FRI decommit
         double t0 = now();
@@ -1443,7 +1531,9 @@ struct HipProver {
             fin.push_back(decommit(g, trees[ti].mk, trees[ti].evals, positions_by_log, &pf.queried_values[ti], &pf.decommitments[ti]));
             pf.commitments.push_back(trees[ti].mk.root);
         }
+        mark("decommitment planned");
         std::vector<u32> data = g.run(c);
+        mark("decommitment data arrived");
         for (auto& f : fin) f(data);
         tm.decommit = now() - t0;
     }
