@@ -436,6 +436,10 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(const PassArgs* __r
             narrow_task(t + NT, false, true);
         } else {
             narrow_task(t, true, false);
+            // r04 ISA audit (tools/isa_mix.py): left to itself the scheduler hoists the 32 loads of both tasks to the top and the forward
+            // kernel needs 168 VGPRs + 20 bytes of scratch inside the column loop; with the two tasks kept apart it takes 142 and no scratch
+            // (128 x 2^24: 5.17-5.25 -> 5.10-5.14 ms per launch, profiles/r04_fft_isa_audit.txt). Two waves per SIMD instead: slower.
+            __builtin_amdgcn_sched_barrier(0);
             narrow_task(t + NT, true, false);
             __syncthreads();
             u32 r[8][4];

@@ -28,43 +28,44 @@ inline void build_quotient_batches(const std::vector<std::vector<ColumnSample>>&
     std::map<PtQ, std::vector<std::pair<u32, Q31>>, PointLess> by_point;
     for (size_t k = 0; k < samples.size(); k++)
         for (auto& s : samples[k]) by_point[s.point].push_back({(u32)k, s.value});
+    // Weights. Within a batch column k carries alpha^(k+1) (alpha restarts per batch), and the row value is the Horner sum over the batches,
+    // acc = acc * alpha^(n_b) + term_b, i.e. sum_b term_b * w_b with w_b = the product of the LATER batches' coefficients = alpha^(columns of the
+    // later batches). term_b = (sum_k c_k f_k - (A y + B)) / den_b is linear in (c_k, A, B), so w_b is folded into them — and since w_b is itself
+    // a power of alpha, column k of batch b simply gets alpha^(k + 1 + columns of the later batches): ONE run of powers for the whole size group,
+    // no separate weight products (r04; exact field arithmetic, so the constants are the same values as before).
+    size_t total = 0;
+    for (auto& kv : by_point) total += kv.second.size();
+    std::vector<Q31> power(total + 1);
+    power[0] = q_one();
+    for (size_t i = 1; i <= total; i++) power[i] = q_mul(power[i - 1], random_coeff);
+    // a Q31 times a "pure u" element (0, d): (x.a + x.b u) (d u) = x.b d (2 + i) + x.a d u — half the products of a general q_mul
+    auto mul_pure = [](const Q31& x, const C31& d) { return Q31{c_mulR(c_mul(x.b, d)), c_mul(x.a, d)}; };
+    size_t later = total;
     for (auto& kv : by_point) {
         const PtQ& pt = kv.first;
+        later -= kv.second.size();                 // columns of the batches after this one
         QuotientBatch qb{};
         qb.prx = pt.x.a; qb.pry = pt.y.a; qb.pix = pt.x.b; qb.piy = pt.y.b;
         qb.kden = c_sub(c_mul(qb.prx, qb.piy), c_mul(qb.pry, qb.pix));   // constant part of the row denominators
         qb.a_sum = q_zero(); qb.b_sum = q_zero();
-        Q31 alpha = q_one();
+        // complex_conjugate_line_coeffs: a = conj(v) - v, c = conj(P.y) - P.y, b = v*c - a*P.y; all scaled by the column's weight.
+        // conj flips the u half, so a = (0, -2 v.b) and c = (0, -2 P.y.b) are pure-u elements (c is the same for every column of the batch).
+        const C31 cc = c_neg(c_add(pt.y.b, pt.y.b));
+        size_t k = 0;
         for (auto& cv : kv.second) {
-            alpha = q_mul(alpha, random_coeff);
-            // complex_conjugate_line_coeffs: a = conj(v) - v, c = conj(P.y) - P.y, b = v*c - a*P.y; all scaled by alpha
-            Q31 a = q_sub(q_conj(cv.second), cv.second);
-            Q31 cc = q_sub(q_conj(pt.y), pt.y);
-            Q31 b = q_sub(q_mul(cv.second, cc), q_mul(a, pt.y));
-            qb.a_sum = q_add(qb.a_sum, q_mul(alpha, a));
-            qb.b_sum = q_add(qb.b_sum, q_mul(alpha, b));
-            QuotientEntry qe{}; qe.c = q_mul(alpha, cc); qe.col = cv.first;
+            const Q31& wgt = power[++k + later];
+            const C31 a = c_neg(c_add(cv.second.b, cv.second.b));
+            const Q31 b = q_sub(mul_pure(cv.second, cc), mul_pure(pt.y, a));
+            qb.a_sum = q_add(qb.a_sum, mul_pure(wgt, a));
+            qb.b_sum = q_add(qb.b_sum, q_mul(wgt, b));
+            QuotientEntry qe{}; qe.c = mul_pure(wgt, cc); qe.col = cv.first;
             entries.push_back(qe);
         }
-        qb.batch_coeff = q_pow(random_coeff, kv.second.size());
+        qb.batch_coeff = power[kv.second.size()];      // kept for reference: already folded into the weights
         qb.n_cols = (u32)kv.second.size();
         batches.push_back(qb);
     }
-    // The row value is the Horner sum over batches, acc = acc * batch_coeff_b + term_b, i.e. sum_b term_b * w_b with w_b = the product of the
-    // later batches' coefficients. term_b = (sum_k c_k f_k - (A y + B)) / den_b is linear in (c_k, A, B), so the weight is folded into
-    // them here and the kernel only adds the terms (exact field arithmetic: the same values, 16 products less per row and extra batch).
-    Q31 w = q_one();
-    size_t e_end = entries.size();
-    for (size_t b = batches.size(); b-- > b0;) {
-        QuotientBatch& qb = batches[b];
-        const size_t e_begin = e_end - qb.n_cols;
-        if (b + 1 < batches.size()) {
-            qb.a_sum = q_mul(qb.a_sum, w); qb.b_sum = q_mul(qb.b_sum, w);
-            for (size_t e = e_begin; e < e_end; e++) entries[e].c = q_mul(entries[e].c, w);
-        }
-        w = q_mul(w, qb.batch_coeff);
-        e_end = e_begin;
-    }
+    (void)b0;
 }
 
 }  // namespace bf

@@ -922,6 +922,7 @@ struct HipProver {
         // ---- FRI quotients (a9) --------------------------------------------------------------------------------------------------------
         t0 = now();
         Q31 q_coeff = ch.draw_felt();
+        mark("sampled values mixed, quotient coefficient drawn");
         BF_HIP(hipEventRecord(c.ev[4], c.stream));
         std::vector<LevelWait> q_waits;
         std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff, &q_waits);
@@ -1148,6 +1149,7 @@ struct HipProver {
         std::vector<FlatCol> flat;
         for (size_t t = 0; t < trees.size(); t++) for (size_t i = 0; i < trees[t].evals.size(); i++) flat.push_back({trees[t].evals[i], t, i});
         std::stable_sort(flat.begin(), flat.end(), [](const FlatCol& a, const FlatCol& b) { return a.col.log_size > b.col.log_size; });
+        mark("quotient columns sorted");
         std::vector<DSecure> out;
         std::vector<QuotientArgs> launches;
         // Launches: one per size group of >= 2^19 rows, largest first, each followed by an event (q_waits) — the FRI first-layer tree hashes
@@ -1197,6 +1199,7 @@ struct HipProver {
                 const QuotientArgs* d_first = c.stage(&first, 1);
                 sb->end();
                 accumulate_quotients(c.stream, d_first, 1, nblocks);
+                mark("largest quotient group launched");
                 sb = std::make_unique<StageBatch>(c);
                 launched = 1;
             }

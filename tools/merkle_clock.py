@@ -29,7 +29,8 @@ def main():
                     continue
                 k = r["Dispatch_Id"]
                 per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                meta[k] = {"grid": int(r["Grid_Size"]), "start": int(r.get("Start_Timestamp") or 0), "end": int(r.get("End_Timestamp") or 0)}
+                short = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bf::", "")
+                meta[k] = {"grid": int(r["Grid_Size"]), "start": int(r.get("Start_Timestamp") or 0), "end": int(r.get("End_Timestamp") or 0), "name": short}
     if any(m["end"] == 0 for m in meta.values()):
         for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             with open(path) as f:
@@ -39,9 +40,9 @@ def main():
                         meta[k]["start"], meta[k]["end"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     shapes = defaultdict(list)
     for k, c in per.items():
-        shapes[meta[k]["grid"]].append((meta[k]["end"] - meta[k]["start"], c))
+        shapes[(meta[k]["name"], meta[k]["grid"])].append((meta[k]["end"] - meta[k]["start"], c))
     out = []
-    for grid, launches in sorted(shapes.items(), reverse=True):
+    for (kname, grid), launches in sorted(shapes.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
         launches = launches[1:] if len(launches) > 2 else launches      # first launch of a shape: cold
         n = len(launches)
         dur = sum(l[0] for l in launches) / n
@@ -49,7 +50,9 @@ def main():
         if dur <= 0 or "GRBM_GUI_ACTIVE" not in c:
             continue
         cycles = c["GRBM_GUI_ACTIVE"] / 8
-        row = {"grid_lanes": grid, "launches": n, "avg_us": round(dur / 1e3, 1), "effective_clock_GHz": round(cycles / dur, 3)}
+        row = {"kernel": kname, "grid_lanes": grid, "launches": n, "avg_us": round(dur / 1e3, 1), "effective_clock_GHz": round(cycles / dur, 3)}
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_INSTS_LDS"):
+            row["lds_bank_conflict_cycles_per_lds_inst"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"], 3)
         if "SQ_INSTS_VALU" in c:
             row["valu_insts_per_simd_cycle_x4"] = round(c["SQ_INSTS_VALU"] * 4 / (cycles * 1024), 4)
             row["valu_lane_ops_per_s_T"] = round(c["SQ_INSTS_VALU"] * 64 / dur / 1e3, 2)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repository root):
-#   gpurun -- 'bash tools/profile_round.sh r03 [part ...]'      parts: bench trace pmc clock fft poseidon shard misc   (default: all)
+#   gpurun -- 'bash tools/profile_round.sh r04 [part ...]'      parts: bench trace pmc clock fft poseidon shard latency misc   (default: all)
 # Writes into gpurun_out/<round>/ ; copy what should be judged into profiles/.
 set -u
-R=${1:-r03}; shift || true
-PARTS=${*:-bench trace pmc clock fft poseidon shard misc}
+R=${1:-r04}; shift || true
+PARTS=${*:-bench trace pmc clock fft poseidon shard latency misc}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
@@ -65,6 +65,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_fft_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_fft_$C -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_fft_FETCH_SIZE /tmp/prof_fft_WRITE_SIZE > "$OUT/${R}_fft_pmc_traffic.json"
+# issue-slot / LDS counters of the FFT kernels (ISA audit): one counter pass over the same command
+rm -rf /tmp/prof_fft_sq; rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d /tmp/prof_fft_sq -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
+python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_fft_sq k_fft > "$OUT/${R}_fft_clock.json" 2>&1
+( cd "$ROOT" && python3 tools/isa_mix.py stwo-brainfuck_amd/csrc/fft.hip k_fft_tile12 k_fft_strided7 k_fft_stridedK > "$OUT/${R}_fft_isa_mix.txt" 2>&1 )
 for tp in 0 1; do for lg in 20 21 22; do echo "== two_pass=$tp log=$lg"; BFHIP_FFT_TWO_PASS=$tp python3 "$ROOT/tools/fft_roofline.py" $lg 4 32 | python3 -c "
 import sys,json
 for r in json.load(sys.stdin):
@@ -84,8 +88,19 @@ python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_posu k_hades > "$OUT/${R}_ubench
 fi
 
 if has shard; then
-# 6. one proof over N ranks of this one GPU (local shard group): replicated vs divided work, per-collective GPU time
+# 6. one proof over N ranks of this one GPU (local shard group): replicated vs divided work, per-collective GPU time; which kernels every rank
+#    repeats (kernel traces of 1 and 8 ranks: plain, and serialised by a counter pass), idle time of the 8-rank proof; BASELINE config 5 in its
+#    literal shape (8 ranks x 2^26 rows x Poseidon252) beside the same proof by one rank
 python3 "$ROOT/tools/shard_local.py" 5 > "$OUT/${R}_shard_local_one_gpu.json" 2> "$OUT/shard_local.err"
+SHARD_LOCAL_POSEIDON=1 SHARD_LOCAL_LOG=24 python3 "$ROOT/tools/shard_local.py" 1 > "$OUT/${R}_shard_local_poseidon_2p24.json" 2> "$OUT/shard_local_poseidon.err"
+( cd "$ROOT" && bash tools/shard_audit.sh $R 8 fib19 > "$OUT/shard_audit_plain.log" 2>&1; AUDIT_PMC=1 bash tools/shard_audit.sh $R 8 fib19 > "$OUT/shard_audit_pmc.log" 2>&1; bash tools/config5_literal.sh $R > "$OUT/config5_literal.log" 2>&1 )
+cd /tmp
+fi
+
+if has latency; then
+# 7. the latency chains: host-side marks of the Fiat-Shamir round trips (BFHIP_TRACE_HOST), the small end of a tree in isolation
+for w in 20 22 fib19; do echo "== $w"; BFHIP_TRACE_HOST=1 python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 2>&1 >/dev/null | tail -24; done > "$OUT/${R}_host_round_trips.txt" 2>&1
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -I "$ROOT/stwo-brainfuck_amd/csrc" -o /tmp/ubench_tree_top "$ROOT/tools/ubench_tree_top.hip" 2>/dev/null && /tmp/ubench_tree_top > "$OUT/${R}_tree_small_end_ubench.txt" 2>&1
 fi
 
 if has misc; then
