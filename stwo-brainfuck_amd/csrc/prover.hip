@@ -39,7 +39,9 @@ struct DCol {
 };
 // layer k: node i stored at i >> shifts[k]. In a shard group (Ctx::shard.count > 1) the layers k with band_lo < k <= band_hi hold only this
 // rank's contiguous share of the nodes (node i belongs to rank i >> (k - log2 count)); layer band_lo and everything below is complete.
-struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; int band_lo = 0, band_hi = -1; };
+// cols: the tree's columns in descending size order (what the decommitment walks; kept from the commitment so that the last round trip of a
+// proof does not sort 128 descriptors again)
+struct DevMerkle { std::vector<u32*> layers; std::vector<u32> shifts; u32 max_log = 0; Hash32 root; int band_lo = 0, band_hi = -1; std::vector<DCol> cols; };
 // owner[i]: the rank that holds polynomial i (coefficients) and computes its LDE, or OWNER_ALL. prev[i]: previous-row copy of evals[i]
 // (row-sharded last logUp columns only; ptr == nullptr otherwise).
 struct DTree { std::vector<DCol> polys, evals, prev; std::vector<u32> owner; DevMerkle mk; };
@@ -213,6 +215,7 @@ struct HipProver {
         std::vector<DCol>& cols = p.cols;
         std::stable_sort(cols.begin(), cols.end(), [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; });
         DevMerkle& mk = p.mk;
+        mk.cols = cols;
         mk.max_log = cols[0].log_size;
         mk.layers.resize(mk.max_log + 1);
         mk.shifts.assign(mk.max_log + 1, 0);
@@ -356,14 +359,16 @@ struct HipProver {
         // columns already come in descending size order
         auto by_size = [](const DCol& a, const DCol& b) { return a.log_size > b.log_size; };
         std::vector<DCol> sorted_copy;
-        if (!std::is_sorted(cols_in.begin(), cols_in.end(), by_size)) { sorted_copy = cols_in; std::stable_sort(sorted_copy.begin(), sorted_copy.end(), by_size); }
-        const std::vector<DCol>& cols = sorted_copy.empty() ? cols_in : sorted_copy;
+        const bool kept = mk.cols.size() == cols_in.size();          // the sorted list of the commitment (same columns, same stable order)
+        if (!kept && !std::is_sorted(cols_in.begin(), cols_in.end(), by_size)) { sorted_copy = cols_in; std::stable_sort(sorted_copy.begin(), sorted_copy.end(), by_size); }
+        const std::vector<DCol>& cols = kept ? mk.cols : sorted_copy.empty() ? cols_in : sorted_copy;
         struct Slot { int kind; size_t first; };   // kind 0: hash witness (8 words), 1: column witness, 2: queried value
         std::vector<Slot> slots;
-        slots.reserve(256);
+        slots.reserve(64 + 4 * cols.size());
+        std::vector<DCol> lc;
+        lc.reserve(cols.size());
         size_t ci = 0;
         std::vector<size_t> last, total;
-        std::vector<DCol> lc;
         static const std::vector<size_t> empty;
         for (int log = (int)mk.max_log; log >= 0; log--) {
             lc.clear();
@@ -1163,19 +1168,24 @@ struct HipProver {
         u32 launched = 0;
         c.stage_checkpoint();
         auto sb = std::make_unique<StageBatch>(c);
+        std::vector<ColDesc> descs; std::vector<ColSamples> col_samples;        // reused by every size group
+        std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
+        descs.reserve(flat.size()); col_samples.reserve(flat.size()); entries.reserve(2 * flat.size()); batches.reserve(32);
         for (size_t i = 0; i < flat.size();) {
             size_t j = i; u32 log = flat[i].col.log_size;
             while (j < flat.size() && flat[j].col.log_size == log) j++;
             // ColumnSampleBatch::new_vec + quotient_constants (host/quotients.h)
-            std::vector<ColDesc> descs;
-            std::vector<std::vector<ColumnSample>> samples(j - i);
+            descs.clear(); col_samples.clear();
             for (size_t k = i; k < j; k++) {
                 descs.push_back(flat[k].col.desc());
                 const auto& pts = mask[flat[k].tree][flat[k].idx];
-                for (size_t s = 0; s < pts.size(); s++) samples[k - i].push_back({points[pts[s]], pf.sampled_values[flat[k].tree][flat[k].idx][s]});
+                ColSamples cs{};
+                if (pts.size() > 2) throw HipError("quotients: more than two mask points on a column");
+                for (size_t s = 0; s < pts.size(); s++) { cs.point[cs.n] = pts[s]; cs.value[cs.n] = pf.sampled_values[flat[k].tree][flat[k].idx][s]; cs.n++; }
+                col_samples.push_back(cs);
             }
-            std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
-            build_quotient_batches(samples, random_coeff, batches, entries);
+            batches.clear(); entries.clear();
+            build_quotient_batches_indexed(col_samples.data(), col_samples.size(), points, random_coeff, batches, entries);
             quotient_entries_finish(batches.data(), batches.size(), entries.data(), descs.data());
             // shard group: the quotient of a row-sharded size is computed for this rank's row range only (every column of the group is
             // either complete or row-sharded over the same range)
@@ -1503,7 +1513,9 @@ struct HipProver {
         // All decommitment reads (FRI witnesses, Merkle witnesses, queried values) are planned first and fetched by ONE gather launch:
         // the control flow depends only on the query positions.
         Gather g;
+        g.reqs.reserve(4096);
         std::vector<Finisher> fin;
+        fin.reserve(64);
         {
             std::map<u32, std::vector<size_t>> dpos;
             for (auto& q : quotients) {

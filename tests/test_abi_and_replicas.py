@@ -225,3 +225,44 @@ def test_rccl_exchange_bookkeeping_through_a_mock_library(tmp_path):
     env = dict(os.environ, BFHIP_RCCL_LIBRARY=str(mock))
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
+# ---- bench.py host logic (no GPU): the strong-scaling digest, the SimdBackend-shaped work counts, the counter-file guard -------------------
+def _bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_strong_scaling_digest_shapes():
+    """`strong_scaling` of the bench line: per workload ms_per_proof / n1_ms_per_proof / speedup_vs_n1 / comm_share_of_proof lifted out of the
+    probe result, an unfinished stage reported as an error, the in-process transport beside RCCL."""
+    b = _bench()
+    probe = {"transport": "RCCL", "stages": {"fib19": {"ms_per_proof": 10.0, "n1_ms_per_proof": 30.0, "speedup_vs_n1": 3.0, "comm_share_of_proof": 0.2, "identical_to_n1": True,
+                                                       "proof_sha256": "ab", "cells_per_s": 1.0, "all_members_same_proof": True},
+                                             "trace_2p26_poseidon252": {"error": "boom"}},
+             "single_process": {"transport": "local", "stages": {"fib19": {"ms_per_proof": 11.0}}}}
+    d = b.strong_scaling_summary(probe, 8)
+    assert d["n_gpus"] == 8 and d["rccl"]["workloads"]["fib19"]["speedup_vs_n1"] == 3.0 and d["rccl"]["workloads"]["fib19"]["identical_to_n1"] is True
+    assert "error" in d["rccl"]["workloads"]["trace_2p26_poseidon252"]
+    assert d["single_process"]["workloads"]["fib19"] == {"ms_per_proof": 11.0}
+    assert b.strong_scaling_summary({"error": "no gpus"}, 2)["rccl"]["error"] == "no gpus"
+
+
+def test_bench_simdbackend_work_counts_fib19():
+    """What a SimdBackend-shaped prover hashes and transforms for fib19: more than the HIP path's own compression count (it does not know the
+    16x replication: 674 M there), and the butterflies of 213 full-size columns."""
+    b = _bench()
+    comps, bflies = b.simdbackend_work_counts([24, 22, 11, 22, 19, 11, 4, 20, 19, 4, 20, 20, 4], 24)
+    assert 700e6 < comps < 800e6 and 1.5e10 < bflies < 3e10
+    # a single 2^4 component: the tree of its 8 + 4 columns and the 21 IsFirst columns are small numbers one can count by hand
+    c2, b2 = b.simdbackend_work_counts([4] * 13, 4)
+    assert c2 > 0 and b2 > 0 and c2 < 5000
+
+
+def test_bench_kernel_source_digest_is_stable_and_sensitive(tmp_path):
+    b = _bench()
+    h = b.kernel_sources_sha256()
+    assert h == b.kernel_sources_sha256() and len(h) == 64
