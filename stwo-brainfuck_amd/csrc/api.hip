@@ -31,13 +31,18 @@ void Ctx::init(int dev, u32 max_log_domain) {
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
     if (const char* v = getenv("BFHIP_OVERLAP")) { overlap = (u32)atoi(v) & 7u; overlap_user_set = true; }
+    if (const char* v = getenv("BFHIP_MAILBOX")) use_mailbox = atoi(v) != 0;
+    if (const char* v = getenv("BFHIP_MAILBOX_TIMEOUT_MS")) mailbox_timeout = std::max(1, atoi(v)) * 1e-3;
+    if (const char* v = getenv("BFHIP_MAILBOX_TEST_DELAY_MS")) mailbox_test_delay_ms = std::max(0, atoi(v));
     for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : reap_ev) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
     BF_HIP(hipEventCreateWithFlags(&sync_ev, hipEventDisableTiming));
     BF_HIP(hipEventCreateWithFlags(&block_ev, hipEventDisableTiming | hipEventBlockingSync));
     BF_HIP(hipHostMalloc((void**)&h_stage, stage_bytes));
     BF_HIP(hipHostMalloc((void**)&h_small, h_small_bytes));
+    memset(h_small, 0, 4096);       // flags, stamps and the mailbox error word start at zero; proof numbers start at one
     BF_HIP(hipHostGetDevicePointer((void**)&d_small_alias, h_small, 0));
     BF_HIP(hipHostGetDevicePointer((void**)&d_hstage_alias, h_stage, 0));
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
@@ -68,6 +73,7 @@ void Ctx::destroy() {
     if (stream2) (void)hipStreamSynchronize(stream2);
     for (auto& a : aux) if (a) { (void)hipStreamSynchronize(a); prof_forget(a); (void)hipStreamDestroy(a); a = nullptr; }
     for (auto& e : evp) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : reap_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     shard = ShardGroup();
     if (stream) prof_forget(stream);
     if (stream2) prof_forget(stream2);

@@ -89,6 +89,29 @@ struct Ctx {
     char* d_small_alias = nullptr; char* d_hstage_alias = nullptr;
     template <class T> T* small_alias(T* host_ptr) const { return reinterpret_cast<T*>(d_small_alias + (reinterpret_cast<char*>(host_ptr) - h_small)); }
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
+    // ---- mailboxes and stamps (mailbox.hip, r04): the launches behind a Fiat-Shamir point are enqueued before the host knows the challenge ----
+    u32 proof_seq = 0;                // flags and stamps of a proof carry its number (never 0), so a slot needs no reset between proofs
+    bool use_mailbox = true;          // BFHIP_MAILBOX=0 at context creation restores wait -> compute -> copy -> launch
+    int mailboxes_pending = 0;        // armed and not yet posted: the stream must not be waited for as a whole
+    double mailbox_timeout = 10.0;    // seconds a mailbox kernel waits for the host before it gives up (BFHIP_MAILBOX_TIMEOUT_MS)
+    int mailbox_test_delay_ms = 0;    // tests only (BFHIP_MAILBOX_TEST_DELAY_MS): the host sleeps this long before every post — a late host
+    // pinned slots inside h_small's fixed area: flags (host writes, a kernel polls) and stamps (a kernel writes, the host polls), 64 bytes apart
+    u32* flag_host(int k) const { return reinterpret_cast<u32*>(h_small + 3072 + 64 * k); }
+    u32* stamp_host(int k) const { return reinterpret_cast<u32*>(h_small + 3584 + 64 * k); }
+    u32* mailbox_err_host() const { return reinterpret_cast<u32*>(h_small + 3520); }   // behind the six flag slots in use; stamp 7 ends at 4096
+    // Reaping: the runtime releases the bookkeeping of completed launches when the host asks about an event behind them. With stamps the host
+    // never asks, ~170 launches pile up per proof and are then released by the runtime's own handler thread at the worst moment — concurrently
+    // with the host's decommitment planning (measured: planning 36 -> 95 us at 2^20 rows). So the enqueue code drops events along the stream
+    // (reap_point) and every host wait queries them in order while it has nothing else to do (reap_some).
+    hipEvent_t reap_ev[64] = {}; u32 reap_head = 0, reap_tail = 0;        // FIFO over a ring of events; head == tail: empty
+    void reap_point() {
+        if (!use_mailbox || reap_tail - reap_head >= 64 || !reap_ev[0]) return;
+        if (hipEventRecord(reap_ev[reap_tail % 64], stream) == hipSuccess) reap_tail++;
+    }
+    void reap_some() { while (reap_head != reap_tail && hipEventQuery(reap_ev[reap_head % 64]) == hipSuccess) reap_head++; }
+    void reap_reset() { reap_head = reap_tail = 0; }
+    void post_stamp(int k);           // enqueue: "everything before this point on the stream is done" -> stamp k = proof_seq
+    void wait_stamp(int k);           // host: poll stamp k (with the stream's health checked now and then)
 
     void init(int dev, u32 max_log_domain);
     void destroy();
@@ -164,6 +187,10 @@ struct Ctx {
     // in-flight kernel still reads parameter blocks from it).
     void stage_checkpoint() {
         if (stage_batch_depth == 0 && stage_used > stage_bytes / 2) {
+            if (mailboxes_pending) {      // a mailbox kernel is waiting for this very thread: waiting for the stream would never return
+                if (stage_used > stage_bytes - (size_t(1) << 20)) throw HipError("staging buffer exhausted while a mailbox is pending");
+                return;
+            }
             // every stream of the context may still read parameter blocks from the ring (`stream` may currently be a partner stream)
             sync();
             BF_HIP(hipStreamSynchronize(stream2));
@@ -187,6 +214,53 @@ struct Ctx {
 
 // Scope of one staging batch: blocks staged inside are moved by one copy at end(); an exception unwinds the batch without copying.
 void preprocessed_cache_invalidate(Ctx* c);   // prover.hip: called when the context joins or leaves a shard group
+
+void mailbox_launch(hipStream_t s, const u32* d_flag, u32 expect, const void* src_pinned_alias, void* dst, size_t bytes, u32* d_err, double timeout_seconds);
+void post_stamp_launch(hipStream_t s, u32* d_stamp, u32 value);
+inline void Ctx::post_stamp(int k) { post_stamp_launch(stream, small_alias(stamp_host(k)), proof_seq); }
+inline void Ctx::wait_stamp(int k) {
+    u32* p = stamp_host(k);
+    const auto t0 = std::chrono::steady_clock::now();
+    double next_check = 50e-3;
+    for (u32 polls = 1;; polls++) {
+        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == proof_seq) return;
+        if ((polls & 1023u) == 0) {
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            // A queue that faulted never writes the stamp: ask the runtime — but rarely: a stream query makes the runtime put a barrier packet
+            // with a completion signal into the queue (launches carry none), in the middle of whatever latency chain is running. A drained
+            // stream without the stamp is a bug, not a wait.
+            if (waited > next_check) {
+                next_check = waited + 50e-3;
+                hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess) { if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == proof_seq) return; throw HipError("the stream drained without writing the stamp the host waits for"); }
+                if (e != hipErrorNotReady) BF_HIP(e);
+            }
+            if (waited > spin_seconds) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+}
+
+// One staging batch whose copy is made by a mailbox kernel (mailbox.hip): begin(), stage the phase's parameter blocks (structurally complete,
+// challenge words still empty), arm() — enqueues the kernel; the phase's launches follow it on the stream —, later patch the blocks in the
+// ring through host() and post(). Going out of scope posts (an abandoned proof must not leave the queue waiting).
+struct Mailbox {
+    Ctx& c; int slot; size_t lo = 0, hi = 0; bool open = false, armed = false, posted = false;
+    Mailbox(Ctx& c_, int slot_) : c(c_), slot(slot_) {}
+    Mailbox(const Mailbox&) = delete; Mailbox& operator=(const Mailbox&) = delete;
+    void begin() {
+        if (c.stage_batch_depth != 0) throw HipError("mailbox: opened inside a staging batch");
+        c.stage_begin(); open = true; lo = c.stage_used;
+    }
+    void arm() {
+        hi = c.stage_used; open = false; c.stage_batch_depth = 0;
+        // err word of this slot: [0] gave up, [1] ticks waited — slot k reports at mailbox_err_host() + 2 k (slot 0 is the proof's error word)
+        mailbox_launch(c.stream, c.small_alias(c.flag_host(slot)), c.proof_seq, c.d_hstage_alias + lo, c.d_stage + lo, hi - lo, c.small_alias(c.mailbox_err_host()) + 2 * slot, c.mailbox_timeout);
+        armed = true; c.mailboxes_pending++;
+    }
+    template <class T> T* host(const T* dev) const { return reinterpret_cast<T*>(c.h_stage + (reinterpret_cast<const char*>(dev) - c.d_stage)); }
+    void post() { if (armed && !posted) { if (c.mailbox_test_delay_ms) std::this_thread::sleep_for(std::chrono::milliseconds(c.mailbox_test_delay_ms)); __atomic_store_n(c.flag_host(slot), c.proof_seq, __ATOMIC_RELEASE); posted = true; c.mailboxes_pending--; } }
+    ~Mailbox() { if (open) c.stage_batch_depth = 0; post(); }
+};
 
 struct StageBatch {
     Ctx& c; bool open = true;

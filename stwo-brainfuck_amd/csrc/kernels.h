@@ -118,7 +118,8 @@ static constexpr u32 MERKLE_SUBTREE_ROOT_LEVEL = 9;
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 node_conv, double bytes, double compressions);
 // levels [top_hi .. 0] by one workgroup, top_hi <= 9 (children of level top_hi from level top_hi + 1 in HBM unless top_hi == max_log);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
-void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions);
+void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions,
+                u32* d_stamp = nullptr, u32 stamp_value = 0);
 // The FRI commit phase below 2^10 rows as ONE single-workgroup launch (merkle.hip: k_fri_tail): per layer the Merkle tree of its 4 coordinate
 // columns, the channel step (mix_root, draw alpha), the fold into the next layer (+ fold-in of the quotient of that size), all through LDS;
 // evaluations, hashes, roots and alphas also go to HBM for the decommitment and the host's channel replay.

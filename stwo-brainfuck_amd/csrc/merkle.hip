@@ -336,7 +336,9 @@ __global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc td,
 }
 
 // chan != nullptr: Blake2sChannel::mix_root(root) and draw_felt() follow the root as two more quad steps (levels -1 and -2 of the loop).
-__global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc) {
+// stamp_out != nullptr (with root_out in pinned host memory): behind the root the kernel writes stamp_value there — the host polls that word
+// instead of an event behind the kernel (ctx.h: wait_stamp).
+__global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32 top_hi, u32* chan, u32* alpha_out, u32* root_out, u32 rfc, u32* stamp_out, u32 stamp_value) {
     // The levels form a dependent chain (one compression of latency each): a level's nodes stay in LDS for the next level (two buffers,
     // alternating) besides going to HBM for the decommitment, so only the first level pays a global-memory round trip.
     __shared__ uint4 s_lv[2][2 * 512];
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32
                 node_hash_quad(ha, hb, has, ka, kb, kc, kd, cols, ncols, qn, rfc, qi);
                 u32* o = reinterpret_cast<u32*>(td.layers[lg]) + 8 * qn; o[qi] = ha; o[4 + qi] = hb;
                 u32* l = reinterpret_cast<u32*>(s_lv[lg & 1]) + 8 * qn; l[qi] = ha; l[4 + qi] = hb;
-                if (lg == 0 && !chan && root_out) { root_out[qi] = ha; root_out[4 + qi] = hb; }     // the root, straight to where the host reads it
+                if (lg == 0 && !chan && root_out) { root_out[qi] = ha; root_out[4 + qi] = hb; if (stamp_out) __threadfence_system(); }     // the root, straight to where the host reads it
             }
         } else if (qn < n) {
             u32 m[16], ha, hb, t0 = 64u, f0 = 0xFFFFFFFFu;
@@ -409,7 +411,10 @@ __global__ void __launch_bounds__(256) k_merkle_top(const MerkleTreeDesc td, u32
             __syncthreads();     // every lane has read the rejected draw before it is overwritten
         } else {
             lg--;
-            if (lg < 0 && !chan) return;
+            if (lg < 0 && !chan) {
+                if (stamp_out && t == 0) __hip_atomic_store(stamp_out, stamp_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // behind the barrier: the four root stores are out
+                return;
+            }
         }
     }
     if (t == 0) {
@@ -685,9 +690,10 @@ void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 
     ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
     hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
 }
-void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions) {
+void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions,
+                u32* d_stamp, u32 stamp_value) {
     ProfScope ps(stream, "k_merkle_top", bytes, compressions);
-    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, tree, top_hi, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(256), 0, stream, tree, top_hi, d_chan, d_alpha8, d_root_copy, node_conv ? 0xFFFFFFFFu : 0u, d_stamp, stamp_value);
 }
 
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy) {

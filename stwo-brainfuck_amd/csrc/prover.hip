@@ -58,7 +58,8 @@ struct Gather {
     size_t add(const u32* base, u64 idx, bool mine = true) { reqs.push_back({mine ? base : nullptr, idx, n_words, 1u}); n_words += 1; return n_words - 1; }
     size_t add_hash(const u32* layer, u64 node_slot, bool mine) { reqs.push_back({mine ? layer : nullptr, node_slot * 8, n_words, 8u}); n_words += 8; return n_words - 8; }
     size_t add_col(const DCol& col, u64 cell, u32 rank) { return add(col.ptr, cell >> col.shift, col.mine(cell, rank)); }
-    std::vector<u32> run(Ctx& c) {
+    // stamp_slot >= 0 (inside a proof, one process per proof): the host polls a stamp word written behind the gather instead of an event
+    std::vector<u32> run(Ctx& c, int stamp_slot = -1) {
         std::vector<u32> out(n_words);
         if (reqs.empty()) return out;
         c.stage_checkpoint();
@@ -72,7 +73,8 @@ struct Gather {
             const GatherReq* d = reinterpret_cast<const GatherReq*>(c.d_hstage_alias + c.stage_used);
             c.stage_used += bytes;
             gather_u32(c.stream, d, (u32)reqs.size(), reinterpret_cast<u32*>(c.d_small_alias + 4096));
-            c.sync();
+            if (stamp_slot >= 0 && c.use_mailbox && c.proof_seq) { c.post_stamp(stamp_slot); c.wait_stamp(stamp_slot); }
+            else c.sync();
             memcpy(out.data(), c.h_small + 4096, n_words * sizeof(u32));
             return out;
         }
@@ -145,13 +147,28 @@ struct HipProver {
     // BFHIP_TRACE_HOST=1: host-side timestamps of the Fiat-Shamir round trips of a proof (label, microseconds since the proof started),
     // printed to stderr when the proof is done — what the host does while the GPU waits for a challenge (tools: point.py)
     std::vector<std::pair<const char*, double>> host_marks;
-    bool trace_host = [] { const char* v = getenv("BFHIP_TRACE_HOST"); return v && v[0] == '1'; }();
+    bool trace_host = [] { const char* v = getenv("BFHIP_TRACE_HOST"); return v && (v[0] == '1' || v[0] == '2'); }();
+    bool trace_host_mean = [] { const char* v = getenv("BFHIP_TRACE_HOST"); return v && v[0] == '2'; }();      // 2: means over every 20 proofs instead of every proof
     double mark_t0 = 0;
     void mark(const char* label) { if (trace_host) host_marks.push_back({label, (now() - mark_t0) * 1e6}); }
     void print_marks() {
         if (!trace_host) return;
+        if (trace_host_mean) {
+            static std::mutex mu; static std::vector<std::pair<const char*, double>> sum; static int n = 0;
+            std::lock_guard<std::mutex> g(mu);
+            if (sum.size() != host_marks.size()) { sum.assign(host_marks.size(), {nullptr, 0.0}); n = 0; }
+            double prev = 0;
+            for (size_t i = 0; i < host_marks.size(); i++) { sum[i].first = host_marks[i].first; sum[i].second += host_marks[i].second - prev; prev = host_marks[i].second; }
+            if (++n == 20) {
+                double at = 0;
+                for (auto& m : sum) { at += m.second / n; fprintf(stderr, "[bfhip host mean of 20] %10.1f us  (+%7.1f)  %s\n", at, m.second / n, m.first); }
+                sum.clear(); n = 0;
+            }
+            return;
+        }
         double prev = 0;
         for (auto& m : host_marks) { fprintf(stderr, "[bfhip host] %10.1f us  (+%7.1f)  %s\n", m.second, m.second - prev, m.first); prev = m.second; }
+        fprintf(stderr, "[bfhip host] staging ring: %zu bytes in use after this proof\n", c.stage_used);
     }
 
     // ---- batched FFT over heterogeneous columns: group by (size, storage) --------------------------------------------------
@@ -299,7 +316,10 @@ struct HipProver {
     // waits: before the level `level` (and everything below it) is hashed the stream waits for `ev` — the columns of that size are produced
     // on another stream while the larger layers are being hashed. Sorted by descending level.
     struct LevelWait { int level; hipEvent_t ev; };
-    DevMerkle merkle_run(MerklePlan& p, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr, const std::vector<LevelWait>* waits = nullptr) {
+    // stamp_slot >= 0 (with a pinned root written by the top kernel itself): the top kernel also writes the proof's number into that stamp slot
+    // behind the root; *stamped tells the caller whether it did (a tree without a fused top needs a k_post_stamp launch instead)
+    DevMerkle merkle_run(MerklePlan& p, Hash32* pinned_root = nullptr, bool no_readback = false, const ChannelStep* step = nullptr, const std::vector<LevelWait>* waits = nullptr,
+                         int stamp_slot = -1, bool* stamped = nullptr) {
         DevMerkle& mk = p.mk;
         const ShardGroup& sg = c.shard;
         const bool poseidon = p.poseidon;
@@ -334,7 +354,10 @@ struct HipProver {
         if (p.sub_hi) merkle_subtree(c.stream, p.tree, p.sub_hi, c.conv.merkle_node_hash, p.sub_bytes, p.sub_comp);
         // a deferred root goes to its pinned slot by the top kernel's own stores (no copy command behind the tree)
         u32* root_direct = (fused_top > 0 && !step && pinned_root) ? reinterpret_cast<u32*>(c.small_alias(pinned_root)) : nullptr;
-        if (fused_top > 0) merkle_top(c.stream, p.tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : root_direct, p.top_bytes, p.top_comp);
+        const bool stamp_here = root_direct && stamp_slot >= 0;
+        if (stamped) *stamped = stamp_here;
+        if (fused_top > 0) merkle_top(c.stream, p.tree, fused_top - 1, c.conv.merkle_node_hash, step ? step->chan : nullptr, step ? step->alpha8 : nullptr, step ? step->root_copy : root_direct, p.top_bytes, p.top_comp,
+                                      stamp_here ? c.small_alias(c.stamp_host(stamp_slot)) : nullptr, c.proof_seq);
         else if (step) channel_mix_root_draw(c.stream, step->chan, mk.layers[0], step->alpha8, step->root_copy);
         BF_HIP(hipGetLastError());
         if (no_readback) return mk;
@@ -542,7 +565,8 @@ struct HipProver {
     // VALU-bound, and layer L of a mixed-degree tree needs only the columns of size L and layer L + 1 — so the largest size class is
     // transformed first and its layers are hashed on the partner stream while the smaller classes are still being transformed.
     // interp_src (optional, one entry per polynomial): evaluations still to be interpolated into t.polys (extend_evals), wave by wave.
-    void commit_tree_overlapped(DTree& t, Hash32* pinned_root, const std::vector<DCol>* interp_src = nullptr) {
+    // stamp_slot >= 0: behind the root (in its pinned slot) the proof's number is written into that stamp slot (ctx.h: wait_stamp)
+    void commit_tree_overlapped(DTree& t, Hash32* pinned_root, const std::vector<DCol>* interp_src = nullptr, int stamp_slot = -1) {
         const size_t n = t.polys.size();
         t.owner.assign(n, OWNER_ALL);
         t.evals.resize(n); t.prev.assign(n, DCol());
@@ -579,7 +603,9 @@ struct HipProver {
         if (!overlap) {
             if (interp_src) fft_launch(fi[1]);
             fft_launch(fe[1]);
-            t.mk = merkle_run(mp, pinned_root);
+            bool stamped = false;
+            t.mk = merkle_run(mp, pinned_root, false, nullptr, nullptr, stamp_slot, &stamped);
+            if (stamp_slot >= 0 && !stamped) c.post_stamp(stamp_slot);
         } else {
             hipEvent_t e1 = c.next_event(), e2 = c.next_event(), e3 = c.next_event();
             BF_HIP(hipEventRecord(e1, main));
@@ -595,6 +621,7 @@ struct HipProver {
             BF_HIP(hipStreamWaitEvent(main, e3, 0));      // joined: whatever follows on this stream sees the tree
             if (pinned_root) BF_HIP(hipMemcpyAsync(pinned_root->b, t.mk.layers[0], 32, hipMemcpyDeviceToHost, main));
             else c.read_back(t.mk.root.b, t.mk.layers[0], 32);
+            if (stamp_slot >= 0) c.post_stamp(stamp_slot);
         }
         if (!pinned_root) ch.mix_root(t.mk.root);
     }
@@ -651,6 +678,17 @@ struct HipProver {
         struct SpinScope { Ctx& c; double saved; ~SpinScope() { c.spin_seconds = saved; } } spin_scope{c, c.spin_seconds};
         c.spin_seconds = 8e-3;
         c.arena.reset();
+        // Mailboxes (mailbox.hip): one process per proof only — a shard group's exchanges are rendezvous points of their own. The ring must
+        // not need recycling while a mailbox kernel waits for this thread, so it is recycled here, where nothing of this context is in flight.
+        const bool mb = c.use_mailbox && !sharded() && !(c.overlap & 2u);
+        if (++c.proof_seq == 0) c.proof_seq = 1;
+        c.reap_some();
+        if (mb && c.stage_used > c.stage_bytes / 4) {
+            c.sync(); BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a));
+            c.stage_used = 0;
+        }
+        for (int k = 0; k <= 5; k++) c.mailbox_err_host()[2 * k] = 0;
+        Mailbox mb_logup(c, 1), mb_constraints(c, 2), mb_samples(c, 3), mb_quot0(c, 4), mb_quot1(c, 5);
         ch = Channel(c.conv);
         if (log_max_rows < LOG_N_LANES) throw HipError("log_max_rows must be at least LOG_N_LANES (4)");
         if (log_max_rows + cfg.log_blowup + 1 > c.tw_root_log + 1) throw HipError("context twiddle tree too small for log_max_rows");
@@ -760,6 +798,22 @@ struct HipProver {
                 logups[k] = L;
             }
         };
+        uint4* pinned_claimed = reinterpret_cast<uint4*>(c.h_small + 2048);
+        Hash32* pinned_root2 = reinterpret_cast<Hash32*>(c.h_small + 2304);
+        LogupBatch* h_lb = nullptr;           // the logUp batch in the staging ring (mailbox mode): its `el` is filled in after the draw
+        auto enqueue_interaction = [&]() {
+            LogupBatch lb;
+            logup_batch_init(lb, Lookups{}, logups.data(), N_COMPONENTS);
+            c.stage_checkpoint();
+            mb_logup.begin();
+            const LogupBatch* d_lb = c.stage(&lb, 1);
+            mb_logup.arm();
+            h_lb = mb_logup.host(d_lb);
+            logup_batch_run(c.stream, d_lb, lb);          // the 13 interaction_trace_evaluation calls (mod.rs:596-687) as one batch: four launches
+            BF_HIP(hipGetLastError());
+            trees[2].polys = inter_vals;                  // interpolate in place
+            commit_tree_overlapped(trees[2], pinned_root2, &inter_vals, 2);
+        };
         try {
             for (int k = 0; k < N_COMPONENTS; k++) {
                 bp.log_sizes[k] = in.log_sizes[k];
@@ -784,13 +838,18 @@ struct HipProver {
                     commit_tree(trees[1], pinned_root1);
                 } else {
                     for (auto& p : trees[1].polys) p.ptr = c.alloc_u32(p.stored());
-                    commit_tree_overlapped(trees[1], pinned_root1, &src);
+                    commit_tree_overlapped(trees[1], pinned_root1, &src, mb ? 1 : -1);
                 }
             }
             BF_HIP(hipEventRecord(c.ev[2], c.stream));
             mark("main tree enqueued");
             prepare_logup();                 // host work under the main tree's kernels: only the lookup elements are missing afterwards
-            c.sync();
+            if (mb) {
+                // the whole interaction phase goes onto the stream now, behind a mailbox that will deliver the lookup elements
+                enqueue_interaction();
+                mark("interaction phase enqueued behind its mailbox");
+                c.wait_stamp(1);
+            } else c.sync();
             mark("main root arrived");
         } catch (...) { join_side(); throw; }
         join_side();
@@ -808,14 +867,9 @@ struct HipProver {
         for (int k = 0; k < N_COMPONENTS; k++) ch.mix_u64(bp.log_sizes[k]);   // claim.mix_into (mod.rs:102-116)
         ch.mix_root(trees[1].mk.root);
         tap("root1");
-        {   // GPU-side durations of the two overlapped phases; the host wall time of the pair is split in that proportion
-            float ms0 = 0.f, ms1 = 0.f;
-            if (!reuse) BF_HIP(hipEventElapsedTime(&ms0, c.ev[0], c.ev[1]));
-            BF_HIP(hipEventElapsedTime(&ms1, c.ev[0], c.ev[2]));
-            double wall = now() - t0, tot = (double)ms0 + (double)ms1;
-            tm.preprocessed = tot > 0 ? wall * ms0 / tot : 0.0;
-            tm.main_trace = wall - tm.preprocessed;
-        }
+        // the host wall time of the two overlapped phases; split in proportion to their GPU-side durations once the events behind them have
+        // certainly completed (at the end of the proof: a stamp can arrive before the event recorded behind the kernel that wrote it)
+        const double wall_phase01 = now() - t0;
 
         // ---- Phase 2: interaction trace (mod.rs:589-723) ------------------------------------------------------------------------
         t0 = now();
@@ -825,116 +879,186 @@ struct HipProver {
         { Q31 z, a; ch.draw_two_felts(z, a); el.processor = make_lookup(z, a); }      // ProcessorElements::draw
         mark("lookup elements drawn");
         for (auto& L : logups) L.el = el;
-        {   // the 13 interaction_trace_evaluation calls (mod.rs:596-687) as one batch: four launches
-            LogupBatch lb;
-            logup_batch_init(lb, el, logups.data(), N_COMPONENTS);
-            c.stage_checkpoint();
-            logup_batch_run(c.stream, c.stage(&lb, 1), lb);
-        }
-        mark("logUp launched");
-        BF_HIP(hipGetLastError());
-        trees[2].polys = inter_vals;          // interpolate in place
         auto take_claimed = [&](const uint4* h_claimed) {
             for (int k = 0; k < N_COMPONENTS; k++) bp.claimed_sums[k] = q_make(h_claimed[k].x, h_claimed[k].y, h_claimed[k].z, h_claimed[k].w);
             for (int k = 0; k < N_COMPONENTS; k++) ch.mix_felts(&bp.claimed_sums[k], 1);   // interaction_claim.mix_into (mod.rs:189-203)
         };
-        if (sharded()) {
-            uint4 h_claimed[N_COMPONENTS];
-            c.read_back(h_claimed, d_claimed, sizeof(h_claimed));
-            take_claimed(h_claimed);
-            std::vector<DCol> mine_cols;
-            for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) mine_cols.push_back(inter_vals[i]);
-            fft_cols(true, mine_cols, mine_cols);
-            commit_tree(trees[2], nullptr, /*with_prev=*/true);
-        } else {
-            // Nothing on the GPU waits for the claimed sums: they travel to their pinned slot behind the logUp kernels, the interaction tree is
-            // enqueued right away, and the host mixes claim and root in protocol order after ONE synchronisation (no idle gap between the logUp
-            // kernels and the transforms).
-            uint4* pinned_claimed = reinterpret_cast<uint4*>(c.h_small + 2048);
-            Hash32* pinned_root2 = reinterpret_cast<Hash32*>(c.h_small + 2304);
-            commit_tree_overlapped(trees[2], pinned_root2, &inter_vals);
-            composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);      // host work under the tree's kernels
-            mark("interaction tree enqueued + composition prepared");
-            c.sync();
+        // per tree, per column: list of point indices (Components::mask_points + composition mask); independent of the challenges
+        std::vector<std::vector<std::vector<u32>>> mask(4);
+        auto build_mask = [&]() {
+            mask[0].assign(trees[0].polys.size(), {});
+            for (int k = 0; k < N_COMPONENTS; k++) mask[0][log_max_rows - bp.log_sizes[k]] = {0};
+            for (int k = 0; k < N_COMPONENTS; k++) {
+                for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
+                u32 ni = 4 * n_logup_cols(k);
+                // last logUp column of a component: offsets {0, -1} (LogupAtRow::finalize); which comes first is Conventions::logup_mask_order
+                for (u32 j = 0; j < ni; j++) {
+                    if (j + 4 >= ni) { if (c.conv.logup_mask_order == 1) mask[2].push_back({(u32)(1 + k), 0}); else mask[2].push_back({0, (u32)(1 + k)}); }
+                    else mask[2].push_back({0});
+                }
+            }
+            mask[3].assign(4, {0});
+        };
+        Hash32* pinned_root3 = reinterpret_cast<Hash32*>(c.h_small + 2368);
+        Q31 random_coeff;
+        if (mb) {
+            // The logUp kernels and the interaction tree are already on the stream, behind their mailbox: hand over the lookup elements.
+            h_lb->el = el;
+            mb_logup.post();
+            mark("lookup elements posted");
+            // ---- prover::prove (mod.rs:732): the composition phase goes onto the stream behind ITS mailbox while the GPU works on the
+            // interaction phase: the 13 constraint launches (coefficient powers and claimed sums still empty), the composition transforms,
+            // the composition tree, a stamp
+            composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);
+            compute_composition(trees, bp, composition_plan, q_zero(), &mb_constraints);
+            build_mask();
+            commit_tree_overlapped(trees[3], pinned_root3, nullptr, 3);
+            sample_plan = sample_prepare(trees, mask);
+            mark("composition phase enqueued behind its mailbox");
+            c.wait_stamp(2);
             mark("interaction root arrived");
             take_claimed(pinned_claimed);
             trees[2].mk.root = *pinned_root2;
             ch.mix_root(trees[2].mk.root);
-        }
-        tap("root2");
-        tm.interaction = now() - t0;
+            tap("root2");
+            tm.interaction = now() - t0;
+            t0 = now();
+            random_coeff = ch.draw_felt();
+            composition_fill(bp, composition_plan, random_coeff);
+            mb_constraints.post();
+            mark("random coefficient posted");
+        } else {
+            {   // the 13 interaction_trace_evaluation calls (mod.rs:596-687) as one batch: four launches
+                LogupBatch lb;
+                logup_batch_init(lb, el, logups.data(), N_COMPONENTS);
+                c.stage_checkpoint();
+                logup_batch_run(c.stream, c.stage(&lb, 1), lb);
+            }
+            mark("logUp launched");
+            BF_HIP(hipGetLastError());
+            trees[2].polys = inter_vals;          // interpolate in place
+            if (sharded()) {
+                uint4 h_claimed[N_COMPONENTS];
+                c.read_back(h_claimed, d_claimed, sizeof(h_claimed));
+                take_claimed(h_claimed);
+                std::vector<DCol> mine_cols;
+                for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) mine_cols.push_back(inter_vals[i]);
+                fft_cols(true, mine_cols, mine_cols);
+                commit_tree(trees[2], nullptr, /*with_prev=*/true);
+            } else {
+                // Nothing on the GPU waits for the claimed sums: they travel to their pinned slot behind the logUp kernels, the interaction tree is
+                // enqueued right away, and the host mixes claim and root in protocol order after ONE synchronisation (no idle gap between the logUp
+                // kernels and the transforms).
+                commit_tree_overlapped(trees[2], pinned_root2, &inter_vals);
+                composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);      // host work under the tree's kernels
+                mark("interaction tree enqueued + composition prepared");
+                c.sync();
+                mark("interaction root arrived");
+                take_claimed(pinned_claimed);
+                trees[2].mk.root = *pinned_root2;
+                ch.mix_root(trees[2].mk.root);
+            }
+            tap("root2");
+            tm.interaction = now() - t0;
 
-        // ---- prover::prove (mod.rs:732): composition polynomial -----------------------------------------------------------------
-        t0 = now();
-        Q31 random_coeff = ch.draw_felt();
-        if (sharded()) composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);
-        compute_composition(trees, bp, composition_plan, random_coeff);
-        mark("constraints + composition transforms launched");
-        // per tree, per column: list of point indices (Components::mask_points + composition mask); independent of the challenges
-        std::vector<std::vector<std::vector<u32>>> mask(4);
-        mask[0].assign(trees[0].polys.size(), {});
-        for (int k = 0; k < N_COMPONENTS; k++) mask[0][log_max_rows - bp.log_sizes[k]] = {0};
-        for (int k = 0; k < N_COMPONENTS; k++) {
-            for (u32 j = 0; j < n_main_cols(k); j++) mask[1].push_back({0});
-            u32 ni = 4 * n_logup_cols(k);
-            // last logUp column of a component: offsets {0, -1} (LogupAtRow::finalize); which comes first is Conventions::logup_mask_order
-            for (u32 j = 0; j < ni; j++) {
-                if (j + 4 >= ni) { if (c.conv.logup_mask_order == 1) mask[2].push_back({(u32)(1 + k), 0}); else mask[2].push_back({0, (u32)(1 + k)}); }
-                else mask[2].push_back({0});
+            // ---- prover::prove (mod.rs:732): composition polynomial -------------------------------------------------------------
+            t0 = now();
+            random_coeff = ch.draw_felt();
+            if (sharded()) composition_plan = composition_prepare(trees, bp, main_off, inter_off, el);
+            compute_composition(trees, bp, composition_plan, random_coeff);
+            mark("constraints + composition transforms launched");
+            build_mask();
+            if (sharded()) commit_tree(trees[3]);
+            else {
+                // the composition tree is enqueued; the sampling jobs (which only need the polynomials' addresses) are listed while it is hashed
+                commit_tree_overlapped(trees[3], pinned_root3);
+                sample_plan = sample_prepare(trees, mask);
+                mark("composition tree enqueued + samples prepared");
             }
         }
-        mask[3].assign(4, {0});
-        if (sharded()) commit_tree(trees[3]);
-        else {
-            // the composition tree is enqueued; the sampling jobs (which only need the polynomials' addresses) are listed while it is hashed
-            Hash32* pinned_root3 = reinterpret_cast<Hash32*>(c.h_small + 2368);
-            commit_tree_overlapped(trees[3], pinned_root3);
-            sample_plan = sample_prepare(trees, mask);
-            mark("composition tree enqueued + samples prepared");
-            c.sync();
-            mark("composition root arrived");
-            trees[3].mk.root = *pinned_root3;
-            ch.mix_root(trees[3].mk.root);
-        }
-        tap("root3");
-        tm.composition = now() - t0;
 
         // ---- OODS sampling (a8) ------------------------------------------------------------------------------------------------------
-        t0 = now();
+        // sample points: index 0 = P, 1 + k = P - trace_step(component k)
+        std::vector<PtQ> points(1 + N_COMPONENTS);
         PtQ oods;
-        {
+        auto draw_oods = [&]() {
             Q31 t = ch.draw_felt();
             Q31 t2 = q_mul(t, t);
             Q31 d = q_inv(q_addm(t2, 1));
             oods.x = q_mul(q_sub(q_one(), t2), d);
             oods.y = q_mul(q_add(t, t), d);
-        }
-        // sample points: index 0 = P, 1 + k = P - trace_step(component k)
-        std::vector<PtQ> points(1 + N_COMPONENTS);
-        points[0] = oods;
-        for (int k = 0; k < N_COMPONENTS; k++) points[1 + k] = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
-        if (sharded()) sample_plan = sample_prepare(trees, mask);
-        sample(trees, mask, points, bp.proof, sample_plan);
-        mark("sampled values arrived");
-        {
+            points[0] = oods;
+            for (int k = 0; k < N_COMPONENTS; k++) points[1 + k] = pq_add(oods, pq_neg(to_q(index_to_point(subgroup_gen(bp.log_sizes[k])))));
+        };
+        auto mix_samples = [&]() {
             std::vector<Q31> flat;
             for (auto& t : bp.proof.sampled_values) for (auto& col : t) for (auto& v : col) flat.push_back(v);
             ch.mix_felts(flat.data(), flat.size());
-        }
-        tap("sampled");
-        tm.oods = now() - t0;
-
-        // ---- FRI quotients (a9) --------------------------------------------------------------------------------------------------------
-        t0 = now();
-        Q31 q_coeff = ch.draw_felt();
-        mark("sampled values mixed, quotient coefficient drawn");
-        BF_HIP(hipEventRecord(c.ev[4], c.stream));
+        };
         std::vector<LevelWait> q_waits;
-        std::vector<DSecure> quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff, &q_waits);
-        BF_HIP(hipEventRecord(c.ev[5], c.stream));
-        mark("quotients launched");
+        std::vector<DSecure> quotients;
+        if (mb) {
+            // the sampling kernels behind their mailbox (the point's factor tables still empty) while the GPU evaluates the constraints
+            SampleRun sr = sample_enqueue(sample_plan, points.size(), &mb_samples);
+            c.post_stamp(4);
+            mark("sampling enqueued behind its mailbox");
+            c.wait_stamp(3);
+            mark("composition root arrived");
+            trees[3].mk.root = *pinned_root3;
+            ch.mix_root(trees[3].mk.root);
+            tap("root3");
+            tm.composition = now() - t0;
+            t0 = now();
+            draw_oods();
+            sample_fill(sr, points);
+            mb_samples.post();
+            mark("out-of-domain point posted");
+            // the quotient kernels behind two mailboxes (largest size group; the rest): batch structure from the points, sampled values still empty
+            QuotientRun qr = quotients_enqueue(trees, mask, points, &mb_quot0, &mb_quot1);
+            BF_HIP(hipEventRecord(c.ev[5], c.stream));
+            quotients = qr.out;
+            mark("quotients enqueued behind their mailboxes");
+            c.wait_stamp(4);
+            sample_finish(trees, mask, bp.proof, sr);
+            mark("sampled values arrived");
+            mix_samples();
+            tap("sampled");
+            tm.oods = now() - t0;
+            t0 = now();
+            Q31 q_coeff = ch.draw_felt();
+            mark("sampled values mixed, quotient coefficient drawn");
+            quotients_fill(qr, mask, points, bp.proof, q_coeff, &mb_quot0, &mb_quot1);
+            mark("quotient constants posted");
+        } else {
+            if (!sharded()) {
+                c.sync();
+                mark("composition root arrived");
+                trees[3].mk.root = *pinned_root3;
+                ch.mix_root(trees[3].mk.root);
+            }
+            tap("root3");
+            tm.composition = now() - t0;
+            t0 = now();
+            draw_oods();
+            if (sharded()) sample_plan = sample_prepare(trees, mask);
+            sample(trees, mask, points, bp.proof, sample_plan);
+            mark("sampled values arrived");
+            mix_samples();
+            tap("sampled");
+            tm.oods = now() - t0;
+
+            // ---- FRI quotients (a9) ----------------------------------------------------------------------------------------------------
+            t0 = now();
+            Q31 q_coeff = ch.draw_felt();
+            mark("sampled values mixed, quotient coefficient drawn");
+            BF_HIP(hipEventRecord(c.ev[4], c.stream));
+            quotients = compute_quotients(trees, mask, points, bp.proof, q_coeff, &q_waits);
+            BF_HIP(hipEventRecord(c.ev[5], c.stream));
+            mark("quotients launched");
+        }
         // no host wait here: the FRI phase is planned (layer storage, 26 tree layouts, one staging copy) while the quotient kernels run;
         // the phase time comes from the two events
+
 
         // ---- FRI commit (a10), proof of work (a11), decommitment (a12) -------------------------------------------------------------------
         // Sanity check of prover::prove (composition OODS value == constraints evaluated on the sampled mask values): host arithmetic on values
@@ -946,6 +1070,23 @@ struct HipProver {
             if (!q_eq(HostPointEval::combine(ce, 0), want)) throw HipError("ConstraintsNotSatisfied");
         };
         fri_and_decommit(trees, quotients, bp.proof, q_waits, sanity_check);
+        for (int k = 1; k <= 5; k++) if (c.mailbox_err_host()[2 * k]) *c.mailbox_err_host() = c.mailbox_err_host()[2 * k];
+        if (mb) {
+            mark("mailbox 1 waited for the host (GPU clock, 10 ns ticks):"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[3] * 0.01;
+            mark("mailbox 2 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[5] * 0.01;
+            mark("mailbox 3 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[7] * 0.01;
+            mark("mailbox 4 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[9] * 0.01;
+            mark("mailbox 5 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[11] * 0.01;
+        }
+        if (*c.mailbox_err_host()) throw HipError("a mailbox kernel gave up waiting for the host (BFHIP_MAILBOX_TIMEOUT_MS): the proof was computed from stale challenge words");
+        {
+            float ms0 = 0.f, ms1 = 0.f;
+            if (!reuse) BF_HIP(hipEventElapsedTime(&ms0, c.ev[0], c.ev[1]));
+            BF_HIP(hipEventElapsedTime(&ms1, c.ev[0], c.ev[2]));
+            const double tot = (double)ms0 + (double)ms1;
+            tm.preprocessed = tot > 0 ? wall_phase01 * ms0 / tot : 0.0;
+            tm.main_trace = wall_phase01 - tm.preprocessed;
+        }
         {
             float ms_q = 0.f;
             BF_HIP(hipEventElapsedTime(&ms_q, c.ev[4], c.ev[5]));      // both completed: fri_and_decommit ends with host waits
@@ -962,7 +1103,10 @@ struct HipProver {
     // ComponentProvers::compute_composition_polynomial + DomainEvaluationAccumulator::finalize
     // Everything about the 13 constraint launches that does not depend on the interaction phase's challenge-side results (random coefficient,
     // claimed sums): accumulators, column descriptors, vanishing inverses. Built while the GPU is still hashing the interaction tree.
-    struct CompositionPlan { std::vector<ConstraintLaunch> launches; std::vector<DSecure> acc; std::vector<bool> have; u32 total = 0, max_log = 0; };
+    struct CompositionPlan {
+        std::vector<ConstraintLaunch> launches; std::vector<DSecure> acc; std::vector<bool> have; u32 total = 0, max_log = 0;
+        ConstraintLaunch* h_staged = nullptr;      // mailbox mode: the launch table in the staging ring, completed by composition_fill
+    };
     CompositionPlan composition_prepare(std::vector<DTree>& trees, const BrainfuckProof& bp, const size_t* main_off, const size_t* inter_off, const Lookups& el) {
         CompositionPlan cp;
         for (int k = 0; k < N_COMPONENTS; k++) { cp.total += n_constraints(k); cp.max_log = std::max(cp.max_log, bp.log_sizes[k] + 1); }
@@ -993,11 +1137,8 @@ struct HipProver {
         }
         return cp;
     }
-    void compute_composition(std::vector<DTree>& trees, const BrainfuckProof& bp, CompositionPlan& cp, Q31 random_coeff) {
-        const u32 total = cp.total, max_log = cp.max_log;
-        std::vector<DSecure>& acc = cp.acc;
-        std::vector<bool>& have = cp.have;
-        std::vector<ConstraintLaunch>& launches = cp.launches;
+    // the challenge-side fields of the 13 launches: coefficient powers and claimed sums
+    static void composition_challenge_fields(const BrainfuckProof& bp, u32 total, Q31 random_coeff, ConstraintLaunch* launches) {
         std::vector<Q31> powers(total);
         { Q31 cur = q_one(); for (u32 i = 0; i < total; i++) { powers[i] = cur; cur = q_mul(cur, random_coeff); } }
         u32 remaining = total;
@@ -1008,14 +1149,36 @@ struct HipProver {
             remaining -= nc;
             launches[k].total_sum = bp.claimed_sums[k];
         }
+    }
+    // mailbox mode: the launch table is already in the ring and the kernels are on the stream; complete it (the caller posts)
+    void composition_fill(const BrainfuckProof& bp, CompositionPlan& cp, Q31 random_coeff) {
+        if (!cp.h_staged) throw HipError("composition_fill without a staged launch table");
+        composition_challenge_fields(bp, cp.total, random_coeff, cp.h_staged);
+    }
+    // mbx != nullptr: the launches go onto the stream behind that mailbox with their challenge-side fields empty (composition_fill completes them)
+    void compute_composition(std::vector<DTree>& trees, const BrainfuckProof& bp, CompositionPlan& cp, Q31 random_coeff, Mailbox* mbx = nullptr) {
+        const u32 max_log = cp.max_log;
+        std::vector<DSecure>& acc = cp.acc;
+        std::vector<bool>& have = cp.have;
+        std::vector<ConstraintLaunch>& launches = cp.launches;
+        if (!mbx) composition_challenge_fields(bp, cp.total, random_coeff, launches.data());
         c.stage_checkpoint();
         {   // the 13 evaluate_constraint_quotients_on_domain calls as ONE launch (air.hip: k_constraints_batch), one staging copy
             ConstraintBatch cb;
             constraint_batch_init(cb, launches.data(), N_COMPONENTS);
-            StageBatch sb(c);
-            const ConstraintLaunch* d_launches = c.stage(launches.data(), launches.size());
-            const ConstraintBatch* d_cb = c.stage(&cb, 1);
-            sb.end();
+            const ConstraintLaunch* d_launches; const ConstraintBatch* d_cb;
+            if (mbx) {
+                mbx->begin();
+                d_launches = c.stage(launches.data(), launches.size());
+                d_cb = c.stage(&cb, 1);
+                mbx->arm();
+                cp.h_staged = mbx->host(d_launches);
+            } else {
+                StageBatch sb(c);
+                d_launches = c.stage(launches.data(), launches.size());
+                d_cb = c.stage(&cb, 1);
+                sb.end();
+            }
             eval_constraints_batch(c.stream, d_cb, cb, d_launches);
         }
         BF_HIP(hipGetLastError());
@@ -1106,15 +1269,48 @@ struct HipProver {
                 }
         return sp;
     }
-    void sample(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, StarkProof& pf, const SamplePlan& sp) {
-        // factor tables: F[0] = y, F[1] = x, F[b] = double_x^(b-1)(x); 32 entries per point
-        std::vector<uint4> factors(points.size() * 32, make_uint4(0, 0, 0, 0));
+    // factor tables: F[0] = y, F[1] = x, F[b] = double_x^(b-1)(x); 32 entries per point
+    static void sample_factors(const std::vector<PtQ>& points, uint4* factors) {
         for (size_t p = 0; p < points.size(); p++) {
             Q31 x = points[p].x;
             auto pk = [](Q31 q) { return make_uint4(q.a.a, q.a.b, q.b.a, q.b.b); };
             factors[p * 32 + 0] = pk(points[p].y);
             for (u32 b = 1; b < 32; b++) { factors[p * 32 + b] = pk(x); x = q_double_x(x); }
         }
+    }
+    // Mailbox mode (one process per proof): the sampling kernels go onto the stream before the point is drawn — jobs staged, factor tables
+    // empty —, sample_fill writes the tables into the ring (the caller posts), sample_finish reads the values from their pinned slot.
+    struct SampleRun { uint4* h_factors = nullptr; u32 n_all = 0; };
+    SampleRun sample_enqueue(const SamplePlan& sp, size_t n_points, Mailbox* mbx) {
+        SampleRun sr; sr.n_all = sp.n_all;
+        if (sp.n_all * sizeof(uint4) > c.h_small_bytes - 4096) throw HipError("sampling: too many samples for the pinned result buffer");
+        std::vector<uint4> factors(n_points * 32, make_uint4(0, 0, 0, 0));
+        c.stage_checkpoint();
+        mbx->begin();
+        const uint4* d_factors = c.stage(factors.data(), factors.size());
+        const EvalJob* d_jobs = sp.jobs.empty() ? nullptr : c.stage(sp.jobs.data(), sp.jobs.size());
+        mbx->arm();
+        sr.h_factors = mbx->host(d_factors);
+        void* d_partials = c.arena.alloc(size_t(sp.partial_off ? sp.partial_off : 1) * sizeof(uint4));
+        eval_at_points(c.stream, d_jobs, (u32)sp.jobs.size(), sp.partial_off, d_factors, d_partials, c.d_small_alias + 4096);
+        BF_HIP(hipGetLastError());
+        return sr;
+    }
+    void sample_fill(const SampleRun& sr, const std::vector<PtQ>& points) { sample_factors(points, sr.h_factors); }
+    void sample_finish(const std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, StarkProof& pf, const SampleRun& sr) {
+        const uint4* out = reinterpret_cast<const uint4*>(c.h_small + 4096);
+        pf.sampled_values.resize(trees.size());
+        size_t ji = 0;
+        for (size_t t = 0; t < trees.size(); t++) {
+            pf.sampled_values[t].resize(trees[t].polys.size());
+            for (size_t col = 0; col < trees[t].polys.size(); col++)
+                for (size_t k = 0; k < mask[t][col].size(); k++, ji++) pf.sampled_values[t][col].push_back(q_make(out[ji].x, out[ji].y, out[ji].z, out[ji].w));
+        }
+        if (ji != sr.n_all) throw HipError("sampling: job count mismatch");
+    }
+    void sample(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, StarkProof& pf, const SamplePlan& sp) {
+        std::vector<uint4> factors(points.size() * 32, make_uint4(0, 0, 0, 0));
+        sample_factors(points, factors.data());
         const std::vector<EvalJob>& jobs = sp.jobs;
         const u32 partial_off = sp.partial_off, n_all = sp.n_all;
         c.stage_checkpoint();
@@ -1145,6 +1341,93 @@ struct HipProver {
             for (size_t col = 0; col < trees[t].polys.size(); col++)
                 for (size_t k = 0; k < mask[t][col].size(); k++, ji++) pf.sampled_values[t][col].push_back(q_make(out[ji].x, out[ji].y, out[ji].z, out[ji].w));
         }
+    }
+
+    // Mailbox mode of compute_quotients (one process per proof). quotients_enqueue: the size groups, their storage, the batch STRUCTURE (which
+    // depends on the sample points, known by now, not on the sampled values) and the launches — the largest group behind mailbox mb0, the other
+    // groups behind mb1. quotients_fill: the same constants as compute_quotients, written over the staged blocks; mb0 is posted as soon as the
+    // largest group's constants are in place, mb1 after the rest (computed while the first launch runs).
+    struct QuotientGroup {
+        u32 log = 0; std::vector<ColDesc> descs; std::vector<ColSamples> cols; std::vector<std::pair<size_t, size_t>> src;   // (tree, column) per column
+        QuotientBatch* h_batches = nullptr; QuotientEntry* h_entries = nullptr; size_t n_batches = 0, n_entries = 0;
+    };
+    struct QuotientRun { std::vector<QuotientGroup> groups; std::vector<DSecure> out; };
+    QuotientRun quotients_enqueue(std::vector<DTree>& trees, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, Mailbox* mb0, Mailbox* mb1) {
+        struct FlatCol { DCol col; size_t tree, idx; };
+        std::vector<FlatCol> flat;
+        for (size_t t = 0; t < trees.size(); t++) for (size_t i = 0; i < trees[t].evals.size(); i++) flat.push_back({trees[t].evals[i], t, i});
+        std::stable_sort(flat.begin(), flat.end(), [](const FlatCol& a, const FlatCol& b) { return a.col.log_size > b.col.log_size; });
+        QuotientRun qr;
+        for (size_t i = 0; i < flat.size();) {
+            size_t j = i; const u32 log = flat[i].col.log_size;
+            while (j < flat.size() && flat[j].col.log_size == log) j++;
+            QuotientGroup g; g.log = log;
+            for (size_t k = i; k < j; k++) {
+                g.descs.push_back(flat[k].col.desc());
+                const auto& pts = mask[flat[k].tree][flat[k].idx];
+                if (pts.size() > 2) throw HipError("quotients: more than two mask points on a column");
+                ColSamples cs{};
+                for (size_t s = 0; s < pts.size(); s++) { cs.point[cs.n] = pts[s]; cs.value[cs.n] = q_zero(); cs.n++; }
+                g.cols.push_back(cs); g.src.push_back({flat[k].tree, flat[k].idx});
+            }
+            qr.groups.push_back(std::move(g));
+            i = j;
+        }
+        std::vector<QuotientArgs> launches;
+        std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
+        c.stage_checkpoint();
+        auto stage_group = [&](QuotientGroup& g, Mailbox* m) {
+            batches.clear(); entries.clear();
+            build_quotient_batches_indexed(g.cols.data(), g.cols.size(), points, q_one(), batches, entries);
+            quotient_entries_finish(batches.data(), batches.size(), entries.data(), g.descs.data());
+            DSecure q; q.log_size = g.log; q.lc = 0;
+            for (int w = 0; w < 4; w++) q.c[w] = c.alloc_u32(size_t(1) << g.log);
+            QuotientArgs a{};
+            a.batches = batches.empty() ? nullptr : c.stage(batches.data(), batches.size());
+            a.entries = entries.empty() ? nullptr : c.stage(entries.data(), entries.size());
+            g.n_batches = batches.size(); g.n_entries = entries.size();
+            g.h_batches = a.batches ? m->host(a.batches) : nullptr; g.h_entries = a.entries ? m->host(a.entries) : nullptr;
+            a.n_batches = (u32)batches.size(); a.log = g.log; a.tw = c.d_tw; a.tw_total = 1u << c.tw_root_log;
+            for (int w = 0; w < 4; w++) a.out[w] = q.c[w];
+            launches.push_back(a);
+            qr.out.push_back(q);
+        };
+        // the largest group behind its own mailbox
+        mb0->begin();
+        stage_group(qr.groups[0], mb0);
+        QuotientArgs first = launches[0];
+        const u32 nblocks0 = quotient_groups_layout(&first, 1);
+        const QuotientArgs* d_first = c.stage(&first, 1);
+        mb0->arm();
+        BF_HIP(hipEventRecord(c.ev[4], c.stream));       // the quotient phase's GPU time starts behind the mailbox, not in front of it
+        accumulate_quotients(c.stream, d_first, 1, nblocks0);
+        if (qr.groups.size() > 1) {
+            mb1->begin();
+            for (size_t g = 1; g < qr.groups.size(); g++) stage_group(qr.groups[g], mb1);
+            const u32 nblocks = quotient_groups_layout(launches.data() + 1, (u32)launches.size() - 1);
+            const QuotientArgs* d_groups = c.stage(launches.data() + 1, launches.size() - 1);
+            mb1->arm();
+            accumulate_quotients(c.stream, d_groups, (u32)launches.size() - 1, nblocks);
+        }
+        BF_HIP(hipGetLastError());
+        return qr;
+    }
+    void quotients_fill(QuotientRun& qr, const std::vector<std::vector<std::vector<u32>>>& mask, const std::vector<PtQ>& points, const StarkProof& pf, Q31 random_coeff,
+                        Mailbox* mb0, Mailbox* mb1) {
+        std::vector<QuotientBatch> batches; std::vector<QuotientEntry> entries;
+        for (size_t gi = 0; gi < qr.groups.size(); gi++) {
+            QuotientGroup& g = qr.groups[gi];
+            for (size_t k = 0; k < g.cols.size(); k++)
+                for (u32 s = 0; s < g.cols[k].n; s++) g.cols[k].value[s] = pf.sampled_values[g.src[k].first][g.src[k].second][s];
+            batches.clear(); entries.clear();
+            build_quotient_batches_indexed(g.cols.data(), g.cols.size(), points, random_coeff, batches, entries);
+            quotient_entries_finish(batches.data(), batches.size(), entries.data(), g.descs.data());
+            if (batches.size() != g.n_batches || entries.size() != g.n_entries) throw HipError("quotients: the batch structure changed between enqueue and fill");
+            if (g.n_batches) memcpy(g.h_batches, batches.data(), batches.size() * sizeof(QuotientBatch));
+            if (g.n_entries) memcpy(g.h_entries, entries.data(), entries.size() * sizeof(QuotientEntry));
+            if (gi == 0) mb0->post();
+        }
+        mb1->post();
     }
 
     // compute_fri_quotients: one secure column per distinct LDE size, descending.
@@ -1445,7 +1728,8 @@ struct HipProver {
             // unwinds (the arena must not be handed out again under running kernels)
             try { while_the_commit_phase_runs(); } catch (...) { (void)hipStreamSynchronize(c.stream); throw; }
             mark("sanity check done");
-            auto dl = gl.run(c);
+            static const bool tail_stamp = [] { const char* v = getenv("BFHIP_MB_TAIL"); return !v || v[0] != '0'; }();
+            auto dl = gl.run(c, tail_stamp ? 6 : -1);
             std::vector<Q31> v;
             for (size_t k = 0; k < pos.size(); k++) v.push_back(q_make(dl[4 * k], dl[4 * k + 1], dl[4 * k + 2], dl[4 * k + 3]));          // synchronises: roots and the device channel state are on the host now
             mark("FRI last layer arrived");
@@ -1547,7 +1831,8 @@ struct HipProver {
             pf.commitments.push_back(trees[ti].mk.root);
         }
         mark("decommitment planned");
-        std::vector<u32> data = g.run(c);
+        static const bool tail_stamp2 = [] { const char* v = getenv("BFHIP_MB_TAIL"); return !v || v[0] != '0'; }();
+        std::vector<u32> data = g.run(c, tail_stamp2 ? 7 : -1);
         mark("decommitment data arrived");
         for (auto& f : fin) f(data);
         tm.decommit = now() - t0;

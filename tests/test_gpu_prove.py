@@ -475,3 +475,36 @@ def test_overlap_modes_do_not_change_the_proof(pkg, oracle):
             c.set_overlap(8)
     finally:
         c.close()
+
+
+@pytest.mark.single_conv
+def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pkg, oracle, monkeypatch):
+    """csrc/mailbox.hip: by default the launches behind a Fiat-Shamir point are on the stream before the host knows the challenge (a one-workgroup
+    kernel waits for the host's flag and copies the challenge-dependent tables); BFHIP_MAILBOX=0 restores wait -> compute -> copy -> launch.
+    Same bytes either way. A host that is later than the kernel's patience (1 ms of patience, 30 ms of test delay before every post) must end
+    in an ERROR — the kernels ran on stale challenge words — never in a hang or in a proof, and the context proves correctly afterwards."""
+    code = _prog("collatz.bf")
+    want, _, _ = oracle.prove(code, b"7\n", log_max_rows=21)
+    for env in ("1", "0"):
+        monkeypatch.setenv("BFHIP_MAILBOX", env)
+        c = pkg.Context(0, max_log_domain=23)
+        try:
+            for _ in range(3):
+                assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want, f"BFHIP_MAILBOX={env}"
+        finally:
+            c.close()
+    monkeypatch.setenv("BFHIP_MAILBOX", "1")
+    monkeypatch.setenv("BFHIP_MAILBOX_TIMEOUT_MS", "1")
+    monkeypatch.setenv("BFHIP_MAILBOX_TEST_DELAY_MS", "30")
+    c = pkg.Context(0, max_log_domain=23)
+    try:
+        with pytest.raises(pkg.BfhipError):
+            pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21)
+    finally:
+        c.close()
+    monkeypatch.delenv("BFHIP_MAILBOX_TIMEOUT_MS"); monkeypatch.delenv("BFHIP_MAILBOX_TEST_DELAY_MS")
+    c = pkg.Context(0, max_log_domain=23)
+    try:
+        assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
+    finally:
+        c.close()
