@@ -64,6 +64,31 @@ __device__ __forceinline__ void node_init(u32 (&h)[8], u32 rfc) {
     for (int k = 0; k < 8; k++) h[k] = B2S_IV[k] & rfc;
     h[0] ^= 0x01010020u & rfc;
 }
+// One message block of column words: m[w] = column (c0 + w) at row i, zero beyond the last column. The descriptors are wave-uniform and
+// come through scalar loads (s_load, one wait for all of them), then the N cells are in flight together (one wait): two memory latencies
+// per block. The loop this replaces paid a descriptor -> cell round trip per group of four columns (k_merkle_layer) or per COLUMN (the
+// one-workgroup kernels of the small end, where nothing else hides the latency: 75 us for the main-trace subtree against 23 us for a
+// column-less one, profiles/r04_2p22_timeline.txt). A partial group re-reads the last column (valid addresses, no branches).
+template <int N>
+__device__ __forceinline__ void load_col_words(u32 (&m)[16], const ColDesc* __restrict__ cols, u32 c0, u32 ncols, u32 i) {
+    const u32 lastc = ncols - 1;
+    ColDesc d[N];
+#pragma unroll
+    for (u32 w = 0; w < N; w++) d[w] = ld_constant(cols + min(c0 + w, lastc));
+    u32 v[N];
+#pragma unroll
+    for (u32 w = 0; w < N; w++) v[w] = ld_col(d[w], i);
+#pragma unroll
+    for (u32 w = 0; w < 16; w++) m[w] = (w < N && c0 + w < ncols) ? v[w < N ? w : 0] : 0u;
+}
+// c0 < ncols
+__device__ __forceinline__ void load_col_block(u32 (&m)[16], const ColDesc* __restrict__ cols, u32 c0, u32 ncols, u32 i) {
+    const u32 left = ncols - c0;
+    if (left > 12) load_col_words<16>(m, cols, c0, ncols, i);
+    else if (left > 8) load_col_words<12>(m, cols, c0, ncols, i);
+    else if (left > 4) load_col_words<8>(m, cols, c0, ncols, i);
+    else load_col_words<4>(m, cols, c0, ncols, i);
+}
 // Hash of node i: the two child hashes (a, b = left, c, d = right) when has_children, then the LE-u32 values of the ncols columns at row i.
 __device__ __forceinline__ void merkle_node_hash(u32 (&h)[8], bool has_children, uint4 a, uint4 b, uint4 c, uint4 d, const ColDesc* __restrict__ cols, u32 ncols, u32 i, u32 rfc) {
     node_init(h, rfc);
@@ -80,26 +105,24 @@ __device__ __forceinline__ void merkle_node_hash(u32 (&h)[8], bool has_children,
         if (last) return;
     }
     // remaining message: column values, 16 words per block (zero padded)
-    for (;;) {
+    // the next block's words are requested before the current block is compressed (two message buffers): the loads of a many-column leaf
+    // fly under ~1000 instructions of hashing instead of being waited for once per block
+    if (c0 < ncols) load_col_block(m, cols, c0, ncols, i);
+    else {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            // columns are absorbed 4 at a time: one uniform branch, four descriptor loads and four value loads issued back to back
-            // (a branch + scalar-load round trip per column serialises the latency); a partial group re-reads its last column
-            const u32 cb = c0 + 4 * g;
-            if (cb < ncols) {
-                const u32 lastc = ncols - 1;
-                const ColDesc d0 = cols[cb], d1 = cols[min(cb + 1, lastc)], d2 = cols[min(cb + 2, lastc)], d3 = cols[min(cb + 3, lastc)];
-                // 32-bit byte offsets (columns hold < 2^30 cells) on a uniform base pointer: SGPR-base + VGPR-offset addressing, no
-                // 64-bit VALU address arithmetic per column
-                const u32 v0 = ld_col(d0, i), v1 = ld_col(d1, i), v2 = ld_col(d2, i), v3 = ld_col(d3, i);
-                m[4 * g] = v0; m[4 * g + 1] = cb + 1 < ncols ? v1 : 0u; m[4 * g + 2] = cb + 2 < ncols ? v2 : 0u; m[4 * g + 3] = cb + 3 < ncols ? v3 : 0u;
-            } else { m[4 * g] = 0; m[4 * g + 1] = 0; m[4 * g + 2] = 0; m[4 * g + 3] = 0; }
-        }
+        for (u32 w = 0; w < 16; w++) m[w] = 0;              // a node with neither children nor columns: one empty block
+    }
+    for (;;) {
+        u32 mn[16];
+        const bool more = c0 + 16 < ncols;
+        if (more) load_col_block(mn, cols, c0 + 16, ncols, i);
         u32 take = min(64u, total_bytes - done);
         done += take; c0 += 16;
         bool last = done == total_bytes;
         blake2s_compress(h, m, done & rfc, last ? rfc : 0u);
         if (last) break;
+#pragma unroll
+        for (u32 w = 0; w < 16; w++) m[w] = mn[w];
     }
 }
 __device__ __forceinline__ void merkle_node(u32 st, uint4* __restrict__ out, const uint4* __restrict__ prev, const ColDesc* __restrict__ cols, u32 ncols,
@@ -259,12 +282,10 @@ __device__ __forceinline__ void node_hash_lean(u32 (&h)[8], bool has, uint4 ka, 
             done += 16;
         } else {
             const u32 c0 = 16 * (blk - (has ? 1u : 0u));
+            if (c0 < ncols) load_col_block(m, cols, c0, ncols, i);
+            else {
 #pragma unroll
-            for (u32 w = 0; w < 16; w++) {
-                const u32 cc = c0 + w;
-                u32 v = 0;
-                if (cc < ncols) v = ld_col(cols[cc], i);
-                m[w] = v;
+                for (u32 w = 0; w < 16; w++) m[w] = 0;      // the empty message of a column-less leaf
             }
             done += min(64u, 4u * (ncols - min(ncols, c0)));
         }
@@ -285,12 +306,10 @@ __device__ __forceinline__ void node_hash_quad(u32& ha, u32& hb, bool has, uint4
         if (blk == 0 && has) { kids_to_m(m, ka, kb, kc, kd); done = 64; }
         else {
             const u32 c0 = 16 * (blk - (has ? 1u : 0u));
+            if (c0 < ncols) load_col_block(m, cols, c0, ncols, i);
+            else {
 #pragma unroll
-            for (u32 w = 0; w < 16; w++) {
-                const u32 cc = c0 + w;
-                u32 v = 0;
-                if (cc < ncols) v = ld_col(cols[cc], i);
-                m[w] = v;
+                for (u32 w = 0; w < 16; w++) m[w] = 0;      // the empty message of a column-less leaf
             }
             done += min(64u, 4u * (ncols - min(ncols, c0)));
         }
