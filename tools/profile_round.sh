@@ -34,12 +34,12 @@ for w in 22 20; do
   python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_$w) 15 > "$OUT/${R}_2p${w}_timeline_gaps.txt" 2>&1
   python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) --summary > "$OUT/${R}_2p${w}_timeline_summary.txt" 2>&1
   python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) > "$OUT/${R}_2p${w}_timeline.txt" 2>&1
-  # the same with the launches enqueued AFTER each challenge (BFHIP_MAILBOX=0): under the profiler the host is ~3x slower at launching, so in
-  # the default order the mailbox kernels wait for it far longer than they do in an un-profiled run; this variant shows the plain gaps
-  export BFHIP_MAILBOX=0
-  rm -rf /tmp/prof_${w}_off; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${w}_off -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
+  # the same with the launches enqueued BEFORE each challenge (BFHIP_MAILBOX=1, opt-in): under the profiler the host is ~3x slower at
+  # launching, so the mailbox kernels wait for it far longer than they do in an un-profiled run (r04_host_round_trips.txt has those waits)
+  export BFHIP_MAILBOX=1
+  rm -rf /tmp/prof_${w}_mb; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${w}_mb -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
   unset BFHIP_MAILBOX
-  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_${w}_off) 15 > "$OUT/${R}_2p${w}_mailbox_off_timeline_gaps.txt" 2>&1
+  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_${w}_mb) 15 > "$OUT/${R}_2p${w}_mailbox_on_timeline_gaps.txt" 2>&1
 done
 for w in 20 21 22 23 24 25 26 fib19; do python3 "$ROOT/tools/point.py" $w --steps 10; done > "$OUT/${R}_points.jsonl" 2>/dev/null
 # overlap switches on this box (A/B), concurrent k_merkle_layer + k_quotients visible in the timeline with bit 1
@@ -97,16 +97,16 @@ if has shard; then
 # 6. one proof over N ranks of this one GPU (local shard group): replicated vs divided work, per-collective GPU time; which kernels every rank
 #    repeats (kernel traces of 1 and 8 ranks: plain, and serialised by a counter pass), idle time of the 8-rank proof; BASELINE config 5 in its
 #    literal shape (8 ranks x 2^26 rows x Poseidon252) beside the same proof by one rank
-python3 "$ROOT/tools/shard_local.py" 5 > "$OUT/${R}_shard_local_one_gpu.json" 2> "$OUT/shard_local.err"
-SHARD_LOCAL_POSEIDON=1 SHARD_LOCAL_LOG=24 python3 "$ROOT/tools/shard_local.py" 1 > "$OUT/${R}_shard_local_poseidon_2p24.json" 2> "$OUT/shard_local_poseidon.err"
+python3 "$ROOT/tools/shard_local.py" 10 > "$OUT/${R}_shard_local_one_gpu.json" 2> "$OUT/shard_local.err"
+SHARD_LOCAL_POSEIDON=1 SHARD_LOCAL_LOG=24 python3 "$ROOT/tools/shard_local.py" 2 > "$OUT/${R}_shard_local_poseidon_2p24.json" 2> "$OUT/shard_local_poseidon.err"
 ( cd "$ROOT" && bash tools/shard_audit.sh $R 8 fib19 > "$OUT/shard_audit_plain.log" 2>&1; AUDIT_PMC=1 bash tools/shard_audit.sh $R 8 fib19 > "$OUT/shard_audit_pmc.log" 2>&1; bash tools/config5_literal.sh $R > "$OUT/config5_literal.log" 2>&1 )
 cd /tmp
 fi
 
 if has latency; then
 # 7. the latency chains: host-side marks of the Fiat-Shamir round trips (BFHIP_TRACE_HOST), the small end of a tree in isolation
-# (means over 20 proofs; the last five lines of the default order: microseconds each mailbox kernel waited for the host, on the GPU's clock)
-for w in 20 22 fib19; do for m in 1 0; do echo "== $w BFHIP_MAILBOX=$m"; BFHIP_MAILBOX=$m BFHIP_TRACE_HOST=2 python3 "$ROOT/tools/point.py" $w --steps 41 --warmup 2 2>&1 >/dev/null | grep "mean of 20" | tail -32; done; done > "$OUT/${R}_host_round_trips.txt" 2>&1
+# (means over 20 proofs; the last five lines of the mailbox order: microseconds each mailbox kernel waited for the host, on the GPU's clock)
+for w in 20 22 fib19; do for m in 0 1; do echo "== $w BFHIP_MAILBOX=$m"; BFHIP_MAILBOX=$m BFHIP_TRACE_HOST=2 python3 "$ROOT/tools/point.py" $w --steps 41 --warmup 2 2>&1 >/dev/null | grep "mean of 20" | tail -32; done; done > "$OUT/${R}_host_round_trips.txt" 2>&1
 # mailboxes on/off on this box, alternating (ms per proof: loop mean, fastest proof)
 for rep in 1 2 3; do for m in 0 1; do for w in 20 22 fib19; do echo -n "BFHIP_MAILBOX=$m $w: "; BFHIP_MAILBOX=$m python3 "$ROOT/tools/point.py" $w --steps 40 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_proof'], d['ms_min'], d['proof_sha256'][:12])"; done; done; done > "$OUT/${R}_mailbox_ab.txt" 2>&1
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -o /tmp/ubench_mailbox "$ROOT/tools/ubench_mailbox.hip" 2>/dev/null && timeout 120 /tmp/ubench_mailbox > "$OUT/${R}_ubench_mailbox.txt" 2>&1

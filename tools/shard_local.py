@@ -27,6 +27,7 @@ def run(pkg, n, steps, lmr=24):
     traces = [pkg.Trace(c, FIB19, b"") for c in ctxs]
     proofs, stats, times, phases = [None] * n, [None] * n, [0.0] * n, [None] * n
     barrier = threading.Barrier(n)
+    step_times = [[0.0] * steps for _ in range(n)]
 
     def work(r):
         if group:
@@ -39,8 +40,10 @@ def run(pkg, n, steps, lmr=24):
         base = (ctxs[r].group_stats(), ctxs[r].group_times()) if group else None
         barrier.wait()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for k in range(steps):
+            tk = time.perf_counter()
             proofs[r], phases[r] = traces[r].prove(lmr)
+            step_times[r][k] = time.perf_counter() - tk
         ctxs[r].sync()
         times[r] = (time.perf_counter() - t0) / steps
         if group:
@@ -56,17 +59,20 @@ def run(pkg, n, steps, lmr=24):
     if group:
         group.close()
     assert all(p == proofs[0] for p in proofs)
-    return max(times) * 1e3, proofs[0], stats, phases[0]
+    # the fastest proof: N host threads of one process time-sharing one GPU are at the mercy of the host's scheduler (box to box the mean of
+    # T(8) moves by 10 %); a proof is done when its slowest rank is
+    fastest = min(max(step_times[r][k] for r in range(n)) for k in range(steps))
+    return max(times) * 1e3, proofs[0], stats, phases[0], fastest * 1e3
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     pkg = load_package()
     out, ref = [], None
     for n in (1, 2, 4, 8):
-        ms, proof, stats, ph = run(pkg, n, steps)
+        ms, proof, stats, ph, fastest = run(pkg, n, steps)
         ref = ref or proof
-        row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "identical_to_single": proof == ref,
+        row = {"ranks_on_one_gpu": n, "ms_per_proof": round(ms, 2), "ms_fastest_proof": round(fastest, 2), "identical_to_single": proof == ref,
                "rank0_phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in ph.items()}}
         if stats[0]:
             per_proof = {k: v / steps for k, v in stats[0].items() if k != "times_ms"}
@@ -85,6 +91,8 @@ def main():
         n = row["ranks_on_one_gpu"]
         s = (row["ms_per_proof"] - t1) / (n - 1)          # T(N) = N S + P, T(1) = S + P
         row["replicated_ms_S"] = round(s, 2); row["divided_ms_P"] = round(t1 - s, 2); row["projected_ms_with_one_gpu_per_rank"] = round(s + (t1 - s) / n, 2)
+        f1 = out[0]["ms_fastest_proof"]; sf = (row["ms_fastest_proof"] - f1) / (n - 1)
+        row["from_the_fastest_proofs"] = {"replicated_ms_S": round(sf, 2), "divided_ms_P": round(f1 - sf, 2), "projected_ms_with_one_gpu_per_rank": round(sf + (f1 - sf) / n, 2)}
     print(json.dumps({"workload": (f"synthetic 2^{SYN_LOG}-row trace" if SYN_LOG else "fib19.bf") + (", Poseidon252MerkleChannel" if POSEIDON else ", Blake2sMerkleChannel"),
                       "runs": out}, indent=1))
 
