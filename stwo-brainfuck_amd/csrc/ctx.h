@@ -39,6 +39,7 @@ struct Arena {
 // One proof over several GPUs (include/bfhip.h: bfhip_ctx_join_*_group): this rank's place in the group and its transport (comm.h).
 struct ShardGroup {
     u32 rank = 0, count = 1, log_count = 0;
+    bool band_fusion = [] { const char* v = getenv("BFHIP_BAND_FUSION"); return !v || v[0] != '0'; }();   // A/B switch (every rank the same)
     std::shared_ptr<Comm> comm;
 };
 

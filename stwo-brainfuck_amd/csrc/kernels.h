@@ -116,6 +116,7 @@ struct MerkleTreeDesc { uint4* layers[32]; u32 shifts[32]; u32 col_off[32]; cons
 // levels [hi .. MERKLE_SUBTREE_ROOT_LEVEL] in one launch, 11 <= hi <= 17, all of them un-replicated; bytes / compressions: profiler accounting
 static constexpr u32 MERKLE_SUBTREE_ROOT_LEVEL = 9;
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 node_conv, double bytes, double compressions);
+void merkle_subtree_share(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 stop, u32 lo, u32 wg0, u32 n_wg, u32 node_conv, double bytes, double compressions);
 // levels [top_hi .. 0] by one workgroup, top_hi <= 9 (children of level top_hi from level top_hi + 1 in HBM unless top_hi == max_log);
 // d_chan != nullptr: the kernel also performs channel_mix_root_draw on the root it has just computed
 void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions,

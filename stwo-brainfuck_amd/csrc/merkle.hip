@@ -313,10 +313,15 @@ __device__ __forceinline__ void node_hash_quad(u32& ha, u32& hb, bool has, uint4
     }
 }
 
-__global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc td, u32 hi, u32 rfc) {
+// General form: workgroup b (= blockIdx.x + wg0) owns the nodes [b << (lg - lo), (b + 1) << (lg - lo)) of every level lg in [stop, hi] — the
+// subtree(s) under what would be node b of level lo. The small end of a tree: lo = stop = 9, wg0 = 0, 512 workgroups. The bottom of a shard
+// group's share-wise band (r04): stop = the band's lowest level, lo = stop - r (a workgroup takes 2^r roots: 256 nodes of level hi), wg0 = the
+// rank's first workgroup — the band's last four levels, 64..512 workgroups each as single launches, in one launch. At most 512 nodes per level
+// and workgroup (LDS).
+__global__ void __launch_bounds__(256) k_merkle_subtree(const MerkleTreeDesc td, u32 hi, u32 rfc, u32 lo, u32 stop, u32 wg0) {
     __shared__ uint4 s_lv[2][2 * 256];
-    const u32 lo = MERKLE_SUBTREE_ROOT_LEVEL, b = blockIdx.x, t = threadIdx.x, qi = t & 3, qn = t >> 2;
-    for (u32 lg = hi; lg >= lo; lg--) {
+    const u32 b = blockIdx.x + wg0, t = threadIdx.x, qi = t & 3, qn = t >> 2;
+    for (u32 lg = hi; lg >= stop; lg--) {
         const u32 n = 1u << (lg - lo);
         const ColDesc* cols = td.cols + td.col_off[lg];
         const u32 ncols = td.col_off[lg - 1] - td.col_off[lg];      // col_off is indexed by level; levels are laid out descending
@@ -702,7 +707,14 @@ void merkle_layer(hipStream_t stream, void* out, const void* prev, const ColDesc
 }
 void merkle_subtree(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 node_conv, double bytes, double compressions) {
     ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
-    hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, tree, hi, node_conv ? 0xFFFFFFFFu : 0u);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(1u << MERKLE_SUBTREE_ROOT_LEVEL), dim3(256), 0, stream, tree, hi, node_conv ? 0xFFFFFFFFu : 0u,
+                       (u32)MERKLE_SUBTREE_ROOT_LEVEL, (u32)MERKLE_SUBTREE_ROOT_LEVEL, 0u);
+}
+// levels [stop, hi] of a rank's share: workgroups [wg0, wg0 + n_wg), each over 2^(hi - lo) nodes of level hi (<= 512)
+void merkle_subtree_share(hipStream_t stream, const MerkleTreeDesc& tree, u32 hi, u32 stop, u32 lo, u32 wg0, u32 n_wg, u32 node_conv, double bytes, double compressions) {
+    if (hi < stop || stop < lo || hi - lo > 9 || !n_wg) throw std::runtime_error("merkle_subtree_share: bad level range");
+    ProfScope ps(stream, "k_merkle_subtree", bytes, compressions);
+    hipLaunchKernelGGL(k_merkle_subtree, dim3(n_wg), dim3(256), 0, stream, tree, hi, node_conv ? 0xFFFFFFFFu : 0u, lo, stop, wg0);
 }
 void merkle_top(hipStream_t stream, const MerkleTreeDesc& tree, u32 top_hi, u32 node_conv, u32* d_chan, u32* d_alpha8, u32* d_root_copy, double bytes, double compressions,
                 u32* d_stamp, u32 stamp_value) {

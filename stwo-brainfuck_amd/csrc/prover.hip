@@ -224,6 +224,9 @@ struct HipProver {
         // single-level launches go down to fused_top), [fused_top - 1 .. 0] one (k_merkle_top; fused_top == 0: none)
         u32 fused_top = 0, sub_hi = 0;
         double top_bytes = 0, top_comp = 0, sub_bytes = 0, sub_comp = 0;
+        // shard group: the band's last levels [band_lo .. band_fuse_hi] as ONE launch over this rank's share (k_merkle_subtree in its general
+        // form, a workgroup per 2^band_fuse_r nodes of level band_lo); band_fuse_hi < 0: single-level launches all the way down
+        int band_fuse_hi = -1; u32 band_fuse_r = 0; double band_bytes = 0, band_comp = 0;
     };
     MerklePlan merkle_plan(const std::vector<DCol>& cols_in) {
         if (cols_in.empty()) throw HipError("merkle_commit: no columns");
@@ -301,6 +304,19 @@ struct HipProver {
             bytes += nodes * ((has ? 64.0 : 0.0) + 32.0) + p.bytes[log];
             comp += nodes * ((has ? 1.0 : 0.0) + (double)(((u32)nc + 15) / 16) + ((!has && nc == 0) ? 1.0 : 0.0));
         };
+        if (banded && !p.poseidon && fused_top > 0 && mk.band_hi > mk.band_lo && c.shard.band_fusion) {
+            // The shares of the band's last levels are 2^14..2^17 nodes: 64..512 workgroups each, four launches of ~6-10 us for ~2 us of work
+            // each (r04: 50 such launches per rank and fib19 proof, 0.35 ms per rank). Levels band_lo + 3 .. band_lo go into one launch.
+            const int hi = std::min(mk.band_hi, mk.band_lo + 3);
+            bool plain = true;
+            for (int lg = mk.band_lo; lg <= std::min(hi + 1, (int)mk.max_log); lg++) plain = plain && mk.shifts[lg] == 0;
+            const u32 r = 8 - (u32)(hi - mk.band_lo);
+            if (plain && (u32)mk.band_lo >= sg.log_count + r) {
+                p.band_fuse_hi = hi; p.band_fuse_r = r;
+                for (int lg = hi; lg >= mk.band_lo; lg--) level_cost(lg, p.band_bytes, p.band_comp);
+                p.band_bytes /= sg.count; p.band_comp /= sg.count;
+            }
+        }
         for (int log = (int)fused_top - 1; log >= 0; log--) level_cost(log, p.top_bytes, p.top_comp);
         if (p.sub_hi) for (int log = (int)p.sub_hi; log >= (int)MERKLE_SUBTREE_ROOT_LEVEL; log--) level_cost(log, p.sub_bytes, p.sub_comp);
         p.d_all = all.empty() ? nullptr : c.stage(all.data(), all.size());
@@ -332,6 +348,16 @@ struct HipProver {
         auto apply_waits = [&](int log) { while (waits && wi < waits->size() && (*waits)[wi].level >= log) BF_HIP(hipStreamWaitEvent(c.stream, (*waits)[wi++].ev, 0)); };
         for (int log = (int)mk.max_log; log >= single_lo; log--) {
             apply_waits(log);
+            if (log == p.band_fuse_hi) {
+                // the rest of the band in one launch over this rank's share, then the all-gather of its lowest level
+                prof_run_end(c.stream);
+                const u32 n_wg = ((1u << mk.band_lo) >> sg.log_count) >> p.band_fuse_r;
+                merkle_subtree_share(c.stream, p.tree, (u32)log, (u32)mk.band_lo, (u32)mk.band_lo - p.band_fuse_r, sg.rank * n_wg, n_wg, c.conv.merkle_node_hash, p.band_bytes, p.band_comp);
+                sg.comm->all_gather(c.stream, mk.layers[mk.band_lo], (size_t(32) << mk.band_lo) >> sg.log_count);
+                prof_run_begin(c.stream, layer_kernel);
+                log = mk.band_lo;
+                continue;
+            }
             size_t n = (log > 0 ? p.off[log - 1] : p.n_all) - p.off[log];
             const bool share = log >= mk.band_lo && log <= mk.band_hi;
             const u32 per_rank = share ? ((1u << (log - mk.shifts[log])) >> sg.log_count) : 0u;   // in stored slots
