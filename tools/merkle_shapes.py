@@ -15,7 +15,7 @@ pkg = importlib.util.module_from_spec(spec); sys.modules["stwo_brainfuck_amd"] =
 PEAK = 39.9e9
 
 
-def run(ctx, log, has_prev, ncols, shift=0, reps=10):
+def run(ctx, log, has_prev, ncols, shift=0, reps=30):
     n = 1 << log
     cols = [ctx.malloc(4 * max(1, n >> shift)) for _ in range(ncols)]
     for p in cols:
@@ -42,7 +42,7 @@ if __name__ == "__main__":
     rows = []
     for name, log, prev, ncols, shift in [
         ("leaf 4 cols (composition / FRI leaf)", 25, False, 4, 0), ("leaf 4 cols", 22, False, 4, 0), ("leaf 1 col (IsFirst)", 25, False, 1, 0),
-        ("inner, no cols", 24, True, 0, 0), ("inner, no cols", 20, True, 0, 0), ("inner, no cols", 16, True, 0, 0), ("inner, no cols", 13, True, 0, 0),
+        ("inner, no cols", 24, True, 0, 0), ("inner, no cols", 22, True, 0, 0), ("inner, no cols", 21, True, 0, 0), ("inner, no cols", 20, True, 0, 0), ("inner, no cols", 19, True, 0, 0), ("inner, no cols", 18, True, 0, 0), ("inner, no cols", 16, True, 0, 0), ("inner, no cols", 13, True, 0, 0),
         ("inner + 1 col (IsFirst)", 24, True, 1, 0), ("inner + 4 cols (FRI first layer)", 24, True, 4, 0), ("inner + 16 cols", 22, True, 16, 0),
         ("leaf 16 cols", 24, False, 16, 0), ("leaf 64 cols", 22, False, 64, 0), ("leaf 128 cols", 21, False, 128, 0),
     ]:
