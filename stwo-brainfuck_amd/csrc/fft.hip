@@ -217,9 +217,10 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __rest
 //                  registers on the 16-byte accesses, layers lo+3..lo+6 as one radix-16 round with 4-byte coalesced row accesses.
 // LDS index padding p(i) = i + 4*(i >> 6) keeps the stride-4 round conflict-free and the 16-byte accesses aligned.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool INV> __device__ __forceinline__ void bfly(u32& x, u32& y, u32 t) {
-    if (INV) { u32 s = m_add(x, y); y = m_mul(m_sub(x, y), t); x = s; }
-    else { u32 w = m_mul(y, t); y = m_sub(x, w); x = m_add(x, w); }
+// t2 = TWICE the twiddle (the kernels below stage their twiddles doubled in LDS, once per workgroup and batch of columns): m31.h m_mul_pre2
+template <bool INV> __device__ __forceinline__ void bfly(u32& x, u32& y, u32 t2) {
+    if (INV) { u32 s = m_add(x, y); y = m_mul_pre2(m_sub(x, y), t2); x = s; }
+    else { u32 w = m_mul_pre2(y, t2); y = m_sub(x, w); x = m_add(x, w); }
 }
 // radix-16 over the 4 local bits of v[16]; tw(jl, idx) returns the twiddle of local layer jl for pair index (e >> (jl+1)).
 template <bool INV, class TW> __device__ __forceinline__ void radix16(u32 (&v)[16], u32 nlayers, TW tw) {
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__
             tw_r[s] = v;
         }
 #pragma unroll
-        for (int s = 0; s < 16; s++) s_tw[256u * s + t] = tw_r[s];
+        for (int s = 0; s < 16; s++) s_tw[256u * s + t] = 2u * tw_r[s];     // doubled: bfly
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[4096u - (4096u >> layer) + idx]; };
     for (u32 col = col0; col < col1; col++) {
@@ -386,7 +387,7 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(const PassArgs* __r
     if (t < 127) {
         u32 j = __clz(~(t << 25));
         u32 q = t - (128u - (128u >> j));
-        s_tw[t] = layer_table(a, lo + j)[(H << (6 - j)) + q];
+        s_tw[t] = 2u * layer_table(a, lo + j)[(H << (6 - j)) + q];          // doubled: bfly
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[128u - (128u >> layer) + idx]; };
     const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
@@ -486,7 +487,7 @@ __global__ void __launch_bounds__((1 << (K + CL)) / 32) k_fft_stridedK(const Pas
     for (u32 e = t; e < ROWS - 1; e += NT) {
         const u32 j = __clz(~(e << (32 - K)));
         const u32 q = e - (ROWS - (ROWS >> j));
-        s_tw[e] = layer_table(a, lo + j)[(H << (K - 1 - j)) + q];
+        s_tw[e] = 2u * layer_table(a, lo + j)[(H << (K - 1 - j)) + q];      // doubled: bfly
     }
     auto TW = [&](u32 layer, u32 idx) -> u32 { return s_tw[ROWS - (ROWS >> layer) + idx]; };
     const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
