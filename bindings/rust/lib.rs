@@ -85,6 +85,12 @@ impl Context {
     pub fn reuse_preprocessed(&self, on: bool) {
         unsafe { sys::bfhip_ctx_reuse_preprocessed(self.0, on as i32) };
     }
+
+    /// Device memory of this context in bytes: [reserved by the per-proof arena, its peak use, the twiddle trees, in use now] (`bfhip_ctx_memory`).
+    pub fn memory(&self) -> Result<[u64; 4], String> {
+        let mut out = [0u64; 4];
+        if unsafe { sys::bfhip_ctx_memory(self.0, out.as_mut_ptr()) } != 0 { Err(last_error()) } else { Ok(out) }
+    }
 }
 
 impl Drop for Context {
