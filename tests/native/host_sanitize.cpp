@@ -2,6 +2,7 @@
 // AddressSanitizer on this pool, the host half can. Built by tests/test_host_sanitize.py with g++ -fsanitize=address,undefined.
 //   host_sanitize run    <code-file> <input-file>          : compile + execute + build the 13 tables, print step count
 //   host_sanitize verify <proof.json> <log_max_rows>       : parse and verify, print "ok" or the rejection reason
+//   host_sanitize field  <count> <seed>                    : M31 products (plain and by a doubled constant), add, sub against wide arithmetic
 #include "../../stwo-brainfuck_amd/csrc/host/verifier.h"
 #include <cstdio>
 #include <fstream>
@@ -28,6 +29,26 @@ int main(int argc, char** argv) {
             size_t cells = 0;
             for (auto& t : tables) cells += t.cols.size() * t.n_rows;
             printf("steps %zu tables %zu cells %zu\n", m.trace.size(), tables.size(), cells);
+            return 0;
+        }
+        if (mode == "field") {
+            // m31.h: the product by a doubled constant (the FFT butterflies' twiddles, r04) against the plain product and against 128-bit
+            // arithmetic, on the edge values and on <count> pseudo-random pairs; the modular add/sub against their definitions
+            const u64 count = strtoull(argv[2], nullptr, 10);
+            const u32 edges[] = {0u, 1u, 2u, 3u, 0xFFFFu, 0x10000u, 0x3FFFFFFFu, 0x40000000u, 0x40000001u, P31 - 2, P31 - 1};
+            u64 checked = 0, x = strtoull(argv[3], nullptr, 10) | 1;
+            auto check = [&](u32 a, u32 w) {
+                const u32 want = (u32)(((unsigned __int128)a * w) % P31);
+                if (m_mul(a, w) != want || m_mul_pre2(a, 2u * w) != want) { printf("mismatch a=%u w=%u\n", a, w); exit(1); }
+                if (m_add(a, w) != (u32)(((u64)a + w) % P31) || m_sub(a, w) != (u32)(((u64)a + P31 - w) % P31)) { printf("add/sub mismatch a=%u w=%u\n", a, w); exit(1); }
+                checked++;
+            };
+            for (u32 a : edges) for (u32 w : edges) check(a, w);
+            for (u64 i = 0; i < count; i++) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                check((u32)(x % P31), (u32)((x >> 32) % P31));
+            }
+            printf("ok %llu\n", (unsigned long long)checked);
             return 0;
         }
         if (mode == "verify") {

@@ -72,3 +72,10 @@ def test_verifier_is_clean_on_valid_and_mutated_proofs(harness, oracle, tmp_path
         out = _run(harness, "verify", str(q), str(lmr)).stdout.strip()
         rejected += out != "ok"
     assert rejected >= 140          # a mutation inside a key name or whitespace may leave the proof valid; nearly all must be rejected
+
+
+def test_m31_product_by_a_doubled_constant(harness):
+    """m31.h m_mul_pre2 (the FFT butterflies take their twiddles doubled and fold the 64-bit product from its two words, r04) equals the plain
+    product and 128-bit arithmetic on every pair of edge values and on 2 million pseudo-random pairs; so do m_add / m_sub their definitions."""
+    r = _run(harness, "field", "2000000", "12345")
+    assert r.returncode == 0 and r.stdout.startswith("ok 2000121"), r.stdout + r.stderr
