@@ -12,7 +12,7 @@ SUF=""; PMC=""
 if [ "${AUDIT_PMC:-0}" = "1" ]; then SUF="_serialised"; PMC="--pmc SQ_INSTS_VALU"; fi
 for n in 1 $N; do
   rm -rf /tmp/sk_$n
-  rocprofv3 --kernel-trace $PMC --output-format csv -d /tmp/sk_$n -- python3 $ROOT/tools/shard_kernels.py $n $WHAT --steps 3 "$@" > $OUT/sk_${WHAT}_$n$SUF.json 2> $OUT/sk_${WHAT}_$n$SUF.err
+  timeout 420 rocprofv3 --kernel-trace $PMC --output-format csv -d /tmp/sk_$n -- python3 $ROOT/tools/shard_kernels.py $n $WHAT --steps 3 "$@" > $OUT/sk_${WHAT}_$n$SUF.json 2> $OUT/sk_${WHAT}_$n$SUF.err
   tail -1 $OUT/sk_${WHAT}_$n$SUF.json | cut -c1-300
 done
 python3 $ROOT/tools/shard_redundancy.py $(ls /tmp/sk_1/*/*kernel_trace.csv | head -1) $OUT/sk_${WHAT}_1$SUF.json $(ls /tmp/sk_$N/*/*kernel_trace.csv | head -1) $OUT/sk_${WHAT}_$N$SUF.json > $OUT/shard_redundancy_${WHAT}_N$N$SUF.txt 2>&1
