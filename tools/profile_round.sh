@@ -11,25 +11,28 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 kt() { ls $1/*/*kernel_trace.csv | head -1; }
+# every profiled command is bounded: rocprofv3 with a multi-threaded program can hang (it did, once, with eight rank threads) and a call that
+# runs into gpurun's own limit costs the whole budget of that call
+RP="timeout 900 rocprofv3"
 
 if has bench; then
 # 1. headline bench line (roofline measured live with HIP events, CPU baseline on the host cores)
 python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.log" | tail -1 > "$OUT/${R}_bench.json"
 # 2. same command under rocprofv3 --kernel-trace --stats (per-kernel average durations must agree with the roofline object)
-rm -rf /tmp/prof_stats; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon > "$OUT/bench_under_rocprof.log" 2>&1
+rm -rf /tmp/prof_stats; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon > "$OUT/bench_under_rocprof.log" 2>&1
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
 fi
 
 if has trace; then
 # 2b. idle-gap analysis of one proof without the event instrumentation: the bench workload and the metric's own size (2^22 rows), 2^20
-rm -rf /tmp/prof_tl; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/tools/point.py" fib19 --steps 3 --warmup 1 > /dev/null 2>&1
+rm -rf /tmp/prof_tl; $RP --kernel-trace --output-format csv -d /tmp/prof_tl -- python3 "$ROOT/tools/point.py" fib19 --steps 3 --warmup 1 > /dev/null 2>&1
 python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_tl) 12 > "$OUT/${R}_timeline_gaps.txt" 2>&1
 python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_tl) > "$OUT/${R}_fib19_timeline.txt" 2>&1
 python3 "$ROOT/tools/fft_launches.py" $(kt /tmp/prof_tl) > "$OUT/${R}_fft_launches.txt" 2>&1
 for K in k_quotients k_constraints k_fold k_eval; do python3 "$ROOT/tools/fft_launches.py" $(kt /tmp/prof_tl) $K | head -12; done > "$OUT/${R}_field_kernel_launches.txt" 2>&1
 for w in 22 20; do
-  rm -rf /tmp/prof_$w; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 "$ROOT/tools/point.py" $w --steps 10 --warmup 2 > "$OUT/point_${w}_under_rocprof.json" 2>/dev/null
+  rm -rf /tmp/prof_$w; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 "$ROOT/tools/point.py" $w --steps 10 --warmup 2 > "$OUT/point_${w}_under_rocprof.json" 2>/dev/null
   cp $(ls /tmp/prof_$w/*/*kernel_stats.csv | head -1) "$OUT/${R}_2p${w}_kernel_stats.csv"
   python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_$w) 15 > "$OUT/${R}_2p${w}_timeline_gaps.txt" 2>&1
   python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) --summary > "$OUT/${R}_2p${w}_timeline_summary.txt" 2>&1
@@ -37,7 +40,7 @@ for w in 22 20; do
   # the same with the launches enqueued BEFORE each challenge (BFHIP_MAILBOX=1, opt-in): under the profiler the host is ~3x slower at
   # launching, so the mailbox kernels wait for it far longer than they do in an un-profiled run (r04_host_round_trips.txt has those waits)
   export BFHIP_MAILBOX=1
-  rm -rf /tmp/prof_${w}_mb; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${w}_mb -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
+  rm -rf /tmp/prof_${w}_mb; $RP --kernel-trace --output-format csv -d /tmp/prof_${w}_mb -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
   unset BFHIP_MAILBOX
   python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_${w}_mb) 15 > "$OUT/${R}_2p${w}_mailbox_on_timeline_gaps.txt" 2>&1
 done
@@ -49,7 +52,7 @@ fi
 if has pmc; then
 # 3. HBM traffic counters, one pass each, kernel trace only
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon > "$OUT/pmc_$C.log" 2>&1
+  rm -rf /tmp/prof_$C; $RP --kernel-trace --pmc $C --output-format csv -d /tmp/prof_$C -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events --no-sweep --no-poseidon > "$OUT/pmc_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_FETCH_SIZE /tmp/prof_WRITE_SIZE > "$OUT/${R}_pmc_traffic.json"
 fi
@@ -57,7 +60,7 @@ fi
 CNT="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU"
 if has clock; then
 # 3b. effective clock and issue-slot accounting of the Merkle kernel and of the register-only Blake2s micro-benchmark (one counter pass each)
-rm -rf /tmp/prof_clock; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_clock -- python3 "$ROOT/tools/merkle_shapes.py" > /dev/null 2>&1
+rm -rf /tmp/prof_clock; $RP --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_clock -- python3 "$ROOT/tools/merkle_shapes.py" > /dev/null 2>&1
 python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_clock > "$OUT/${R}_merkle_clock.json" 2>&1
 python3 "$ROOT/tools/merkle_shapes.py" > "$OUT/${R}_merkle_shapes.txt" 2>&1
 fi
@@ -65,14 +68,14 @@ fi
 if has fft; then
 # 4. FFT kernel run (BASELINE config 3 (i)): HIP-event profile, rocprofv3 kernel stats of the same command, FETCH/WRITE counter passes
 python3 "$ROOT/tools/fft_roofline.py" > "$OUT/${R}_fft_roofline.json" 2> "$OUT/fft_roofline.err"
-rm -rf /tmp/prof_fft; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fft -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > "$OUT/fft_roofline_under_rocprof.json" 2>/dev/null
+rm -rf /tmp/prof_fft; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_fft -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > "$OUT/fft_roofline_under_rocprof.json" 2>/dev/null
 cp $(ls /tmp/prof_fft/*/*kernel_stats.csv | head -1) "$OUT/${R}_fft_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_fft_$C; rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/prof_fft_$C -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
+  rm -rf /tmp/prof_fft_$C; $RP --kernel-trace --pmc $C --output-format csv -d /tmp/prof_fft_$C -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" /tmp/prof_fft_FETCH_SIZE /tmp/prof_fft_WRITE_SIZE > "$OUT/${R}_fft_pmc_traffic.json"
 # issue-slot / LDS counters of the FFT kernels (ISA audit): one counter pass over the same command
-rm -rf /tmp/prof_fft_sq; rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d /tmp/prof_fft_sq -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
+rm -rf /tmp/prof_fft_sq; $RP --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d /tmp/prof_fft_sq -- python3 "$ROOT/tools/fft_roofline.py" 24 128 > /dev/null 2>&1
 python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_fft_sq k_fft > "$OUT/${R}_fft_clock.json" 2>&1
 ( cd "$ROOT" && python3 tools/isa_mix.py stwo-brainfuck_amd/csrc/fft.hip k_fft_tile12 k_fft_strided7 k_fft_stridedK > "$OUT/${R}_fft_isa_mix.txt" 2>&1 )
 for tp in 0 1; do for lg in 20 21 22; do echo "== two_pass=$tp log=$lg"; BFHIP_FFT_TWO_PASS=$tp python3 "$ROOT/tools/fft_roofline.py" $lg 4 32 | python3 -c "
@@ -85,11 +88,11 @@ if has poseidon; then
 # 5. Poseidon252 variant (config 5): proof times, kernel stats, issue-slot counters of the layer kernel, register-only micro-benchmark
 python3 "$ROOT/tools/poseidon_trace.py" 24 2 > "$OUT/${R}_poseidon_trace_2p24.json" 2> "$OUT/poseidon_trace.err"
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -I "$ROOT/stwo-brainfuck_amd/csrc" -o /tmp/ubench_poseidon "$ROOT/tools/ubench_poseidon.hip" 2>/dev/null && /tmp/ubench_poseidon > "$OUT/${R}_ubench_poseidon.txt"
-rm -rf /tmp/prof_pos; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pos -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
+rm -rf /tmp/prof_pos; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_pos -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
 cp $(ls /tmp/prof_pos/*/*kernel_stats.csv | head -1) "$OUT/${R}_poseidon_2p22_kernel_stats.csv"
-rm -rf /tmp/prof_posc; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posc -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
+rm -rf /tmp/prof_posc; $RP --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posc -- python3 "$ROOT/tools/poseidon_trace.py" 22 1 > /dev/null 2>&1
 python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_posc k_merkle_layer_poseidon > "$OUT/${R}_poseidon_clock.json" 2>&1
-rm -rf /tmp/prof_posu; rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posu -- /tmp/ubench_poseidon > /dev/null 2>&1
+rm -rf /tmp/prof_posu; $RP --kernel-trace --pmc $CNT --output-format csv -d /tmp/prof_posu -- /tmp/ubench_poseidon > /dev/null 2>&1
 python3 "$ROOT/tools/merkle_clock.py" /tmp/prof_posu k_hades > "$OUT/${R}_ubench_poseidon_clock.json" 2>&1
 fi
 
