@@ -31,7 +31,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
     if (const char* v = getenv("BFHIP_OVERLAP")) { overlap = (u32)atoi(v) & 7u; overlap_user_set = true; }
-    if (const char* v = getenv("BFHIP_MAILBOX")) use_mailbox = atoi(v) != 0;
+    if (const char* v = getenv("BFHIP_MAILBOX")) mailbox_mode = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("BFHIP_MAILBOX_TIMEOUT_MS")) mailbox_timeout = std::max(1, atoi(v)) * 1e-3;
     if (const char* v = getenv("BFHIP_MAILBOX_TEST_DELAY_MS")) mailbox_test_delay_ms = std::max(0, atoi(v));
     for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));

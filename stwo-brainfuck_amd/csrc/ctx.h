@@ -92,9 +92,11 @@ struct Ctx {
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
     // ---- mailboxes and stamps (mailbox.hip, r04): the launches behind a Fiat-Shamir point are enqueued before the host knows the challenge ----
     u32 proof_seq = 0;                // flags and stamps of a proof carry its number (never 0), so a slot needs no reset between proofs
-    // OFF by default: measured over three boxes the order gains 1-3 % on 2^20-row proofs and nothing (fib19: -0.5 %) on large ones, where
-    // removing idle time does not shorten a VALU- and power-limited proof (finding iii); BFHIP_MAILBOX=1 enables it
-    bool use_mailbox = false;
+    // Measured over three boxes the order gains 1-3 % on 2^20-row proofs and nothing (fib19: +0.1..+0.5 %) on large ones, where the saved
+    // idle time is below the noise of a VALU-limited proof (finding iii). So by default it is used for proofs with
+    // LOG_MAX_ROWS <= 21 only (mailbox_mode -1, decided per proof in HipProver::prove); BFHIP_MAILBOX=1 / 0 forces it on / off.
+    int mailbox_mode = -1;
+    bool use_mailbox = false;         // the decision for the proof in progress
     int mailboxes_pending = 0;        // armed and not yet posted: the stream must not be waited for as a whole
     double mailbox_timeout = 10.0;    // seconds a mailbox kernel waits for the host before it gives up (BFHIP_MAILBOX_TIMEOUT_MS)
     int mailbox_test_delay_ms = 0;    // tests only (BFHIP_MAILBOX_TEST_DELAY_MS): the host sleeps this long before every post — a late host

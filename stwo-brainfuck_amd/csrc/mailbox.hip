@@ -1,5 +1,5 @@
-// Mailboxes: the launches that FOLLOW a Fiat-Shamir point are enqueued BEFORE the host knows the challenge (r04; opt-in: BFHIP_MAILBOX=1 —
-// measured, it pays on small proofs only, see ctx.h: use_mailbox and DESIGN.md section 5).
+// Mailboxes: the launches that FOLLOW a Fiat-Shamir point are enqueued BEFORE the host knows the challenge (r04). Used by default for proofs
+// with LOG_MAX_ROWS <= 21 — measured, it pays on small proofs only —; BFHIP_MAILBOX=1 / 0 forces it (ctx.h: mailbox_mode).
 //
 // At a Fiat-Shamir point the host must see a result of the GPU (a root, the sampled values), step the channel, and hand the next kernels the
 // challenge-dependent part of their parameter tables. Done in that order — wait, compute, copy, launch — the GPU idles for the host's wake-up,

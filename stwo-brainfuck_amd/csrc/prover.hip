@@ -706,6 +706,7 @@ struct HipProver {
         c.arena.reset();
         // Mailboxes (mailbox.hip): one process per proof only — a shard group's exchanges are rendezvous points of their own. The ring must
         // not need recycling while a mailbox kernel waits for this thread, so it is recycled here, where nothing of this context is in flight.
+        c.use_mailbox = c.mailbox_mode < 0 ? log_max_rows <= 21 : c.mailbox_mode != 0;
         const bool mb = c.use_mailbox && !sharded() && !(c.overlap & 2u);
         if (++c.proof_seq == 0) c.proof_seq = 1;
         c.reap_some();

@@ -479,8 +479,9 @@ def test_overlap_modes_do_not_change_the_proof(pkg, oracle):
 
 @pytest.mark.single_conv
 def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pkg, oracle, monkeypatch):
-    """csrc/mailbox.hip: by default the launches behind a Fiat-Shamir point are on the stream before the host knows the challenge (a one-workgroup
-    kernel waits for the host's flag and copies the challenge-dependent tables); BFHIP_MAILBOX=0 restores wait -> compute -> copy -> launch.
+    """csrc/mailbox.hip: for proofs with LOG_MAX_ROWS <= 21 (or with BFHIP_MAILBOX=1) the launches behind a Fiat-Shamir point are on the stream before
+    the host knows the challenge (a one-workgroup kernel waits for the host's flag and copies the challenge-dependent tables); BFHIP_MAILBOX=0
+    (and larger proofs) keep wait -> compute -> copy -> launch.
     Same bytes either way. A host that is later than the kernel's patience (1 ms of patience, 30 ms of test delay before every post) must end
     in an ERROR — the kernels ran on stale challenge words — never in a hang or in a proof, and the context proves correctly afterwards."""
     code = _prog("collatz.bf")

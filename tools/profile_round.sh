@@ -37,12 +37,14 @@ for w in 22 20; do
   python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_$w) 15 > "$OUT/${R}_2p${w}_timeline_gaps.txt" 2>&1
   python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) --summary > "$OUT/${R}_2p${w}_timeline_summary.txt" 2>&1
   python3 "$ROOT/tools/timeline_dump.py" $(kt /tmp/prof_$w) > "$OUT/${R}_2p${w}_timeline.txt" 2>&1
-  # the same with the launches enqueued BEFORE each challenge (BFHIP_MAILBOX=1, opt-in): under the profiler the host is ~3x slower at
+  # the same with the mailbox order forced on and off (the default is on for LOG_MAX_ROWS <= 21): under the profiler the host is ~3x slower at
   # launching, so the mailbox kernels wait for it far longer than they do in an un-profiled run (r04_host_round_trips.txt has those waits)
-  export BFHIP_MAILBOX=1
-  rm -rf /tmp/prof_${w}_mb; $RP --kernel-trace --output-format csv -d /tmp/prof_${w}_mb -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
+  for mbx in 1 0; do
+    export BFHIP_MAILBOX=$mbx; tag=$([ $mbx = 1 ] && echo on || echo off)
+    rm -rf /tmp/prof_${w}_mb; $RP --kernel-trace --output-format csv -d /tmp/prof_${w}_mb -- python3 "$ROOT/tools/point.py" $w --steps 3 --warmup 1 > /dev/null 2>&1
+    python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_${w}_mb) 15 > "$OUT/${R}_2p${w}_mailbox_${tag}_timeline_gaps.txt" 2>&1
+  done
   unset BFHIP_MAILBOX
-  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_${w}_mb) 15 > "$OUT/${R}_2p${w}_mailbox_on_timeline_gaps.txt" 2>&1
 done
 for w in 20 21 22 23 24 25 26 fib19; do python3 "$ROOT/tools/point.py" $w --steps 10; done > "$OUT/${R}_points.jsonl" 2>/dev/null
 # overlap switches on this box (A/B), concurrent k_merkle_layer + k_quotients visible in the timeline with bit 1
