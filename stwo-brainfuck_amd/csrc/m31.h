@@ -84,6 +84,26 @@ BF_HD Q31 q_sub(Q31 x, Q31 y) { return {c_sub(x.a, y.a), c_sub(x.b, y.b)}; }
 BF_HD Q31 q_neg(Q31 x) { return {c_neg(x.a), c_neg(x.b)}; }
 BF_HD Q31 q_mul(Q31 x, Q31 y) { return {c_add(c_mul(x.a, y.a), c_mulR(c_mul(x.b, y.b))), c_add(c_mul(x.a, y.b), c_mul(x.b, y.a))}; }
 BF_HD Q31 q_mulm(Q31 x, u32 y) { return {c_mulm(x.a, y), c_mulm(x.b, y)}; }
+// x * y for a y that is a constant of the kernel (the FRI folds: alpha and alpha^2). Multiplication by y is a 4 x 4 matrix over M31:
+//   out0 = a0 c0 - a1 c1 + b0 e0 - b1 e1     out1 = a0 c1 + a1 c0 + b0 e1 + b1 e0          (y = (c0 + c1 i) + (c2 + c3 i) u,
+//   out2 = a0 c2 - a1 c3 + b0 c0 - b1 c1     out3 = a0 c3 + a1 c2 + b0 c1 + b1 c0           e = (2 + i)(c2 + c3 i), x = (a0 + a1 i) + (b0 + b1 i) u)
+// With the negated entries kept as p - c, every component is a sum of FOUR products of values <= p: < 2^64, one u64 accumulator and no
+// intermediate reduction, then one reduction through 2^32 = 2 (mod p). 16 multiply-adds + 4 x 6 instructions instead of 16 x 6 + 12 x 3
+// for q_mul (r04: the fold kernels turned out VALU-bound, 0.86 of the issue slots: profiles/r04_field_kernels_clock.txt).
+struct QConst { u32 c0, c1, c2, c3, e0, e1, nc1, nc3, ne1; };
+BF_HD QConst q_const(Q31 y) {
+    const C31 e = c_mulR(y.b);
+    return {y.a.a, y.a.b, y.b.a, y.b.b, e.a, e.b, P31 - y.a.b, P31 - y.b.b, P31 - e.b};
+}
+BF_HD u32 m_red4(u64 x) {      // any u64 -> canonical: hi * 2^32 + lo = 2 hi + lo < 2^34, folded once more to < 2^31 + 8
+    const u64 t = ((x >> 32) << 1) + (u32)x;
+    const u32 s = ((u32)t & P31) + (u32)(t >> 31); const u32 d = s - P31; return d < s ? d : s;
+}
+BF_HD Q31 q_mul_const(Q31 x, const QConst& k) {
+    const u64 a0 = x.a.a, a1 = x.a.b, b0 = x.b.a, b1 = x.b.b;
+    return q_make(m_red4(a0 * k.c0 + a1 * k.nc1 + b0 * k.e0 + b1 * k.ne1), m_red4(a0 * k.c1 + a1 * k.c0 + b0 * k.e1 + b1 * k.e0),
+                  m_red4(a0 * k.c2 + a1 * k.nc3 + b0 * k.c0 + b1 * k.nc1), m_red4(a0 * k.c3 + a1 * k.c2 + b0 * k.c1 + b1 * k.c0));
+}
 BF_HD Q31 q_mulc(Q31 x, C31 y) { return {c_mul(x.a, y), c_mul(x.b, y)}; }
 BF_HD Q31 q_addm(Q31 x, u32 y) { x.a.a = m_add(x.a.a, y); return x; }
 BF_HD Q31 q_subm(Q31 x, u32 y) { x.a.a = m_sub(x.a.a, y); return x; }

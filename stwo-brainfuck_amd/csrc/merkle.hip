@@ -528,6 +528,7 @@ __global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict_
 #pragma unroll
         for (int w = 0; w < 4; w++) w4[w] = s_ch[8 + w] >= P31 ? s_ch[8 + w] - P31 : s_ch[8 + w];
         const Q31 alpha = q_make(w4[0], w4[1], w4[2], w4[3]), alpha_sq = q_mul(alpha, alpha);
+        const QConst k_alpha = q_const(alpha), k_alpha_sq = q_const(alpha_sq);       // the folds multiply by these two constants (m31.h: q_mul_const)
         if (t == 0) {
             u32* ao = a.alpha + 8 * (a.alpha_idx + k);
             ao[0] = alpha.a.a; ao[1] = alpha.a.b; ao[2] = alpha.b.a; ao[3] = alpha.b.b;
@@ -540,15 +541,15 @@ __global__ void __launch_bounds__(256) k_fri_tail(const FriTailArgs* __restrict_
         for (u32 i = t; i < (1u << (log - 1)); i += 256) {
             const u32 xinv = a.itw[a.tw_total - (1u << log) + i];
             const Q31 fx = q_make(ev[0][2 * i], ev[1][2 * i], ev[2][2 * i], ev[3][2 * i]), fn = q_make(ev[0][2 * i + 1], ev[1][2 * i + 1], ev[2][2 * i + 1], ev[3][2 * i + 1]);
-            Q31 r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+            Q31 r = q_add(q_add(fx, fn), q_mul_const(q_mulm(q_sub(fx, fn), xinv), k_alpha));
             if (L.quot[0]) {
                 const u32* t1 = a.itw + (a.tw_total - (1u << (log - 1)));
                 const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
                 const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
                 const Q31 fp = q_make(L.quot[0][2 * i], L.quot[1][2 * i], L.quot[2][2 * i], L.quot[3][2 * i]);
                 const Q31 fq = q_make(L.quot[0][2 * i + 1], L.quot[1][2 * i + 1], L.quot[2][2 * i + 1], L.quot[3][2 * i + 1]);
-                const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fq), yinv)), q_add(fp, fq));
-                r = q_add(q_mul(r, alpha_sq), fprime);
+                const Q31 fprime = q_add(q_mul_const(q_mulm(q_sub(fp, fq), yinv), k_alpha), q_add(fp, fq));
+                r = q_add(q_mul_const(r, k_alpha_sq), fprime);
             }
             nx[0][i] = r.a.a; nx[1][i] = r.a.b; nx[2][i] = r.b.a; nx[3][i] = r.b.b;
             out[0][i] = r.a.a; out[1][i] = r.a.b; out[2][i] = r.b.a; out[3][i] = r.b.b;
@@ -575,20 +576,20 @@ __global__ void __launch_bounds__(256) k_fri_layer(FriLayerArgs a) {
     u32 leaf[4];
     {
         const u32 i = blockIdx.x * 256 + t, slog = log + 1;
-        const Q31 alpha = q_make(a.alpha8[0], a.alpha8[1], a.alpha8[2], a.alpha8[3]);
+        const QConst k_alpha = q_const(q_make(a.alpha8[0], a.alpha8[1], a.alpha8[2], a.alpha8[3]));
         const u32 xinv = a.itw[a.tw_total - (1u << slog) + i];
         const uint2 a0 = reinterpret_cast<const uint2*>(a.src[0])[i], a1 = reinterpret_cast<const uint2*>(a.src[1])[i], a2 = reinterpret_cast<const uint2*>(a.src[2])[i], a3 = reinterpret_cast<const uint2*>(a.src[3])[i];
         const Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
-        Q31 r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+        Q31 r = q_add(q_add(fx, fn), q_mul_const(q_mulm(q_sub(fx, fn), xinv), k_alpha));
         if (a.quot[0]) {
-            const Q31 alpha_sq = q_make(a.alpha8[4], a.alpha8[5], a.alpha8[6], a.alpha8[7]);
+            const QConst k_alpha_sq = q_const(q_make(a.alpha8[4], a.alpha8[5], a.alpha8[6], a.alpha8[7]));
             const u32* t1 = a.itw + (a.tw_total - (1u << (slog - 1)));
             const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
             const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
             const uint2 b0 = reinterpret_cast<const uint2*>(a.quot[0])[i], b1 = reinterpret_cast<const uint2*>(a.quot[1])[i], b2 = reinterpret_cast<const uint2*>(a.quot[2])[i], b3 = reinterpret_cast<const uint2*>(a.quot[3])[i];
             const Q31 fp = q_make(b0.x, b1.x, b2.x, b3.x), fq = q_make(b0.y, b1.y, b2.y, b3.y);
-            const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fq), yinv)), q_add(fp, fq));
-            r = q_add(q_mul(r, alpha_sq), fprime);
+            const Q31 fprime = q_add(q_mul_const(q_mulm(q_sub(fp, fq), yinv), k_alpha), q_add(fp, fq));
+            r = q_add(q_mul_const(r, k_alpha_sq), fprime);
         }
         leaf[0] = r.a.a; leaf[1] = r.a.b; leaf[2] = r.b.a; leaf[3] = r.b.b;
         a.dst[0][i] = leaf[0]; a.dst[1][i] = leaf[1]; a.dst[2][i] = leaf[2]; a.dst[3][i] = leaf[3];

@@ -296,16 +296,16 @@ __global__ void __launch_bounds__(256) k_fold_circle_into_line(u32* const d0, u3
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     i += first;
-    const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]), alpha_sq = q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]);
+    const QConst alpha = q_const(q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3])), alpha_sq = q_const(q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]));
     const u32* t1 = itw + (tw_total - (1u << (log - 1)));
     u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
     u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
     uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
     Q31 fp = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
     Q31 f0 = q_add(fp, fn), f1 = q_mulm(q_sub(fp, fn), yinv);
-    Q31 fprime = q_add(q_mul(alpha, f1), f0);
+    Q31 fprime = q_add(q_mul_const(f1, alpha), f0);
     Q31 r = fprime;                                   // fresh destination: 0 * alpha^2 + f'
-    if (!fresh) { Q31 dst = q_make(d0[i], d1[i], d2[i], d3[i]); r = q_add(q_mul(dst, alpha_sq), fprime); }
+    if (!fresh) { Q31 dst = q_make(d0[i], d1[i], d2[i], d3[i]); r = q_add(q_mul_const(dst, alpha_sq), fprime); }
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
 __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __restrict__ d1, u32* __restrict__ d2, u32* __restrict__ d3,
@@ -314,12 +314,12 @@ __global__ void __launch_bounds__(256) k_fold_line(u32* __restrict__ d0, u32* __
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     i += first;
-    const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]);
+    const QConst alpha = q_const(q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]));
     u32 xinv = itw[tw_total - (1u << log) + i];
     uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
     Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
     Q31 f0 = q_add(fx, fn), f1 = q_mulm(q_sub(fx, fn), xinv);
-    Q31 r = q_add(f0, q_mul(alpha, f1));
+    Q31 r = q_add(f0, q_mul_const(f1, alpha));
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }
 // One FRI step below the first layer as ONE launch: next = fold_line(cur, alpha), then — when a quotient column of cur's size exists —
@@ -332,23 +332,23 @@ __global__ void __launch_bounds__(256) k_fold_line_circle(u32* __restrict__ d0, 
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     i += first;
-    const Q31 alpha = q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]);
+    const QConst alpha = q_const(q_make(alpha8[0], alpha8[1], alpha8[2], alpha8[3]));
     Q31 r;
     {
         const u32 xinv = itw[tw_total - (1u << log) + i];
         const uint2 a0 = reinterpret_cast<const uint2*>(s0)[i], a1 = reinterpret_cast<const uint2*>(s1)[i], a2 = reinterpret_cast<const uint2*>(s2)[i], a3 = reinterpret_cast<const uint2*>(s3)[i];
         const Q31 fx = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
-        r = q_add(q_add(fx, fn), q_mul(alpha, q_mulm(q_sub(fx, fn), xinv)));
+        r = q_add(q_add(fx, fn), q_mul_const(q_mulm(q_sub(fx, fn), xinv), alpha));
     }
     if (q0) {
-        const Q31 alpha_sq = q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]);
+        const QConst alpha_sq = q_const(q_make(alpha8[4], alpha8[5], alpha8[6], alpha8[7]));
         const u32* t1 = itw + (tw_total - (1u << (log - 1)));
         const u32 cx = t1[(i >> 2) * 2], cy = t1[(i >> 2) * 2 + 1], sel = i & 3;
         const u32 yinv = sel == 0 ? cy : sel == 1 ? m_neg(cy) : sel == 2 ? m_neg(cx) : cx;
         const uint2 a0 = reinterpret_cast<const uint2*>(q0)[i], a1 = reinterpret_cast<const uint2*>(q1)[i], a2 = reinterpret_cast<const uint2*>(q2)[i], a3 = reinterpret_cast<const uint2*>(q3)[i];
         const Q31 fp = q_make(a0.x, a1.x, a2.x, a3.x), fn = q_make(a0.y, a1.y, a2.y, a3.y);
-        const Q31 fprime = q_add(q_mul(alpha, q_mulm(q_sub(fp, fn), yinv)), q_add(fp, fn));
-        r = q_add(q_mul(r, alpha_sq), fprime);
+        const Q31 fprime = q_add(q_mul_const(q_mulm(q_sub(fp, fn), yinv), alpha), q_add(fp, fn));
+        r = q_add(q_mul_const(r, alpha_sq), fprime);
     }
     d0[i] = r.a.a; d1[i] = r.a.b; d2[i] = r.b.a; d3[i] = r.b.b;
 }

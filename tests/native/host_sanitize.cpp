@@ -48,6 +48,20 @@ int main(int argc, char** argv) {
                 x ^= x << 13; x ^= x >> 7; x ^= x << 17;
                 check((u32)(x % P31), (u32)((x >> 32) % P31));
             }
+            // QM31 product by a constant of the kernel (the FRI folds, r04): the 4 x 4 matrix form with one u64 accumulator per component
+            // against q_mul, on edge values in every position and on count / 8 pseudo-random pairs
+            auto qcheck = [&](Q31 a, Q31 y) {
+                const Q31 want = q_mul(a, y), got = q_mul_const(a, q_const(y));
+                if (!q_eq(want, got)) { printf("q_mul_const mismatch\n"); exit(1); }
+            };
+            const u32 qe[] = {0u, 1u, 2u, P31 - 2, P31 - 1, 0x40000000u};
+            for (u32 e0 : qe) for (u32 e1 : qe) for (u32 e2 : qe) for (u32 e3 : qe) { qcheck(q_make(e0, e1, e2, e3), q_make(e3, e2, e1, e0)); qcheck(q_make(P31 - 1, P31 - 1, P31 - 1, P31 - 1), q_make(e0, e1, e2, e3)); }
+            for (u64 i = 0; i < count / 8; i++) {
+                u32 w[8];
+                for (int j = 0; j < 8; j++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w[j] = (u32)(x % P31); }
+                qcheck(q_make(w[0], w[1], w[2], w[3]), q_make(w[4], w[5], w[6], w[7]));
+            }
+            if (m_red4(~0ull) != (u32)(((unsigned __int128)~0ull) % P31) || m_red4(0) != 0 || m_red4(P31) != 0) { printf("m_red4 mismatch\n"); exit(1); }
             printf("ok %llu\n", (unsigned long long)checked);
             return 0;
         }
