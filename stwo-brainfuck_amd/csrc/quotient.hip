@@ -51,19 +51,21 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __r
 #pragma unroll
                 for (u32 j = 0; j < 4; j++) {
                     const u32 idx = v4 * 4 + j;
-                    if (idx % 3 == 0 && idx) { a64[0] = m_fold(a64[0]); a64[1] = m_fold(a64[1]); a64[2] = m_fold(a64[2]); a64[3] = m_fold(a64[3]); }
+                    // four products of canonical values on top of a folded accumulator (< 2^34) stay below 2^64: 4 (p - 1)^2 + 2^34 < 2^64
+                    if (idx % 4 == 0 && idx) { a64[0] = m_fold(a64[0]); a64[1] = m_fold(a64[1]); a64[2] = m_fold(a64[2]); a64[3] = m_fold(a64[3]); }
                     const Q31 w = ld_q(s_w, idx);
                     a64[0] += (u64)w.a.a * cv[j]; a64[1] += (u64)w.a.b * cv[j]; a64[2] += (u64)w.b.a * cv[j]; a64[3] += (u64)w.b.b * cv[j];
                 }
             }
-            acc = q_make(m_canon(a64[0]), m_canon(a64[1]), m_canon(a64[2]), m_canon(a64[3]));
+            acc = q_make(m_red4(a64[0]), m_red4(a64[1]), m_red4(a64[2]), m_red4(a64[3]));
         } else {
             for (u32 k = 0; k < n; k++) acc = q_add(acc, q_mulm(ld_q(s_w, k), job.coeffs[k]));
         }
     }
     s_p[t] = pk_q(acc);
     __syncthreads();
-    // tree over the 256 lane partials: level b uses factor F[4 + b]
+    // tree over the 256 lane partials: level b uses factor F[4 + b] — a constant of the level, so the product is the 4 x 4 constant-matrix
+    // form (m31.h: q_mul_const; the tree's nine wave-level products cost more than the 16-term dot products in front of it, r04)
     for (u32 b = 0; b < 8; b++) {
         u32 half = 128u >> b;
         Q31 r;
@@ -71,7 +73,7 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage1(const EvalJob* __r
         if (act) {
             Q31 lo = ld_q(s_p, 2 * t), hi = ld_q(s_p, 2 * t + 1);
             // partial index bit b corresponds to coefficient-index bit 4 + b; beyond log_n the hi partial is zero anyway
-            r = (4 + b < job.log_n) ? q_add(lo, q_mul(hi, ld_q(F, 4 + b))) : lo;
+            r = (4 + b < job.log_n) ? q_add(lo, q_mul_const(hi, q_const(ld_q(F, 4 + b)))) : lo;
         }
         __syncthreads();
         if (act) s_p[t] = pk_q(r);
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256) k_eval_at_point_stage2(const EvalJob* __r
     for (u32 b = 0; b < lanes_log; b++) {
         u32 half = lanes >> (b + 1);
         Q31 r; bool act = t < half;
-        if (act) r = q_add(ld_q(s, 2 * t), q_mul(ld_q(s, 2 * t + 1), ld_q(F, EAP_CHUNK_LOG + per_log + b)));
+        if (act) r = q_add(ld_q(s, 2 * t), q_mul_const(ld_q(s, 2 * t + 1), q_const(ld_q(F, EAP_CHUNK_LOG + per_log + b))));
         __syncthreads();
         if (act) s[t] = pk_q(r);
         __syncthreads();
