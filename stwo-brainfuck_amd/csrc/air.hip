@@ -72,7 +72,7 @@ struct DomainEval : LogupState<DomainEval, Fm> {
     }
     __device__ __forceinline__ void constraint(Fm c) {
         const Q31 k = a.coeff[ci++];
-        if (pending == 3) fold();
+        if (pending == 4) fold();      // four products of canonical values on top of a folded accumulator stay below 2^64: 4 (p - 1)^2 + 2^34 < 2^64
         acc[0] += (u64)k.a.a * c.v; acc[1] += (u64)k.a.b * c.v; acc[2] += (u64)k.b.a * c.v; acc[3] += (u64)k.b.b * c.v;
         pending++;
     }
@@ -119,7 +119,7 @@ struct GroupEval {
     __device__ __forceinline__ Fm trace() { return {ld_col(a.trace[ti++], row)}; }
     __device__ __forceinline__ Fm cst(u32 k) { return {k}; }
     __device__ __forceinline__ void dot(u64 (&acc)[4], int& pending, const Q31& k, u32 v) {
-        if (pending == 3) { for (int w = 0; w < 4; w++) acc[w] = m_fold(acc[w]); pending = 0; }
+        if (pending == 4) { for (int w = 0; w < 4; w++) acc[w] = m_fold(acc[w]); pending = 0; }      // 4 (p - 1)^2 + 2^34 < 2^64
         acc[0] += (u64)k.a.a * v; acc[1] += (u64)k.a.b * v; acc[2] += (u64)k.b.a * v; acc[3] += (u64)k.b.b * v;
         pending++;
     }
