@@ -81,8 +81,18 @@ int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask);
  * out[1] = the arena's high-water mark over all proofs so far, out[2] = twiddle tree + inverse, out[3] = arena bytes in use now. */
 int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]);
 /* Host waits of this context: 0 (default) = poll briefly, then yield / block; 1 = hipStreamSynchronize at once (hosts with more waiting
- * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s). */
+ * contexts than cores). Waits inside a shard group are always bounded polls (BFHIP_COMM_TIMEOUT_S, default 300 s).
+ * Mailboxes (small proofs, LOG_MAX_ROWS <= 21: the launches behind a Fiat-Shamir point are enqueued before the host knows the challenge and a
+ * one-workgroup kernel waits on the GPU for the host's post) are OFF by default under policy 1 — the kernel would spin at the head of a
+ * hardware queue while the host thread sleeps. Where they are on (policy 0, or forced with BFHIP_MAILBOX=1), a host thread that is stalled for
+ * longer than BFHIP_MAILBOX_TIMEOUT_MS (default 10 000 ms: SIGSTOP, a debugger, heavy oversubscription) makes that proof FAIL with a
+ * "mailbox kernel gave up waiting for the host" error instead of merely being slow; the context stays usable and the next proof starts
+ * clean. BFHIP_MAILBOX=0 switches them off altogether. All members of a group must use the same overlap mask (bfhip_ctx_set_overlap). */
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);
+/* Mailbox settings of a live context (what BFHIP_MAILBOX / BFHIP_MAILBOX_TIMEOUT_MS / BFHIP_MAILBOX_TEST_DELAY_MS set at creation):
+ * mode -1 = automatic (see above), 0 = off, 1 = on; timeout_ms 0 = keep the current timeout; test_delay_ms >= 0: the host sleeps that long before
+ * every post (tests of the late-host path only; 0 in production), negative = keep. Takes effect at the next proof. */
+int32_t bfhip_ctx_set_mailbox(bfhip_ctx* ctx, int32_t mode, uint32_t timeout_ms, int32_t test_delay_ms);
 
 /* Conventions used by every operation of this context (prover, bfhip_merkle_commit_layer, bfhip_grind). conv == NULL restores the defaults. */
 int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv);

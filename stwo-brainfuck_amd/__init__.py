@@ -128,6 +128,14 @@ class Context:
         groups): the send-receive of a tree's largest size class on the partner stream beside the transforms of the smaller columns."""
         _check(lib().bfhip_ctx_set_overlap(self._h, int(mask)))
 
+    def set_sync_policy(self, blocking):
+        """bfhip_ctx_set_sync_policy: True = the host sleeps in its waits (more waiting contexts than cores), False (default) = polls first."""
+        _check(lib().bfhip_ctx_set_sync_policy(self._h, 1 if blocking else 0))
+
+    def set_mailbox(self, mode=-1, timeout_ms=0, test_delay_ms=-1):
+        """bfhip_ctx_set_mailbox: mode -1 automatic / 0 off / 1 on; timeout_ms 0 keeps the timeout; test_delay_ms < 0 keeps the (test) delay."""
+        _check(lib().bfhip_ctx_set_mailbox(self._h, int(mode), int(timeout_ms), int(test_delay_ms)))
+
     def memory(self):
         """bfhip_ctx_memory: {arena_reserved, arena_peak, twiddles, arena_in_use} in bytes."""
         out = (ctypes.c_uint64 * 4)()

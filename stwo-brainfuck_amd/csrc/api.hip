@@ -233,6 +233,15 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
     API_CATCH
 }
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking) { API_CTX(ctx) ctx->c.sync_blocking = blocking != 0; return 0; API_CATCH }
+int32_t bfhip_ctx_set_mailbox(bfhip_ctx* ctx, int32_t mode, uint32_t timeout_ms, int32_t test_delay_ms) {
+    API_CTX(ctx)
+    if (mode < -1 || mode > 1) throw HipError("bfhip_ctx_set_mailbox: mode must be -1, 0 or 1");
+    ctx->c.mailbox_mode = mode;
+    if (timeout_ms) ctx->c.mailbox_timeout = timeout_ms * 1e-3;
+    if (test_delay_ms >= 0) ctx->c.mailbox_test_delay_ms = test_delay_ms;
+    return 0;
+    API_CATCH
+}
 int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask) {
     API_CTX(ctx)
     if (mask > 7) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer, bit 2 = shard-group exchanges");

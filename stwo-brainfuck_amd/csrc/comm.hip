@@ -71,6 +71,11 @@ struct LocalGroup {
     std::vector<bool> taken;             // ranks currently held by a LocalComm
     struct Slot { void* buf = nullptr; hipEvent_t ready = nullptr, done = nullptr; std::vector<Xfer> sends; int device = -1; };
     std::vector<Slot> slots;
+    // Whether the members sit on more than one GPU. Group-wide state (not per member): the prover picks its collective sequence by it
+    // (Ctx::exchange_overlapped), so every member — also one that joins a rank another context left — must read the same value. Recomputed
+    // from the slots' devices by every member after the first rendezvous it takes part in (all slots of live members are filled by then).
+    std::atomic<int> spans{-1};          // -1 unknown (no collective yet), 0 one GPU, 1 several
+    std::atomic<u32> epoch{0};           // bumped by every join: members re-check their peers (and peer access) when the membership changed
     explicit LocalGroup(u32 n) : count(n), taken(n, false), slots(n) {}
     void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
     // The ranks of a proof reach a rendezvous within tens of microseconds of each other ~60 times per proof, and a thread that sleeps on the
@@ -146,7 +151,7 @@ __global__ void k_max_u32_n(u32* __restrict__ out, const u32* __restrict__ gathe
 struct LocalComm : Comm {
     std::shared_ptr<LocalGroup> g;
     u32* scratch = nullptr; size_t scratch_words = 0;     // (count + 1) * n words: the gathered copies, then the result
-    bool peers_checked = false, multi_device = false;
+    bool multi_device = false; u32 checked_epoch = ~0u;
     LocalComm(const std::shared_ptr<LocalGroup>& g_, u32 r) : g(g_) {
         rank = r; count = g_->count;
         {
@@ -155,6 +160,13 @@ struct LocalComm : Comm {
             g->taken[r] = true;
         }
         BF_HIP(hipGetDevice(&g->slots[r].device));        // the C-ABI entry has bound this thread to the context's GPU
+        {
+            // a member on another GPU than one already there makes the group multi-device at once, for every member (before any collective)
+            std::lock_guard<std::mutex> lk(g->mu);
+            for (u32 p = 0; p < count; p++)
+                if (p != r && g->taken[p] && g->slots[p].device >= 0 && g->slots[p].device != g->slots[r].device) g->spans.store(1, std::memory_order_release);
+            g->epoch.fetch_add(1, std::memory_order_release);
+        }
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].done, hipEventDisableTiming));
     }
@@ -165,24 +177,28 @@ struct LocalComm : Comm {
         (void)hipFree(scratch);
     }
     void abort() override { g->fail(); }
-    bool spans_devices() const override { return multi_device; }
+    // the group's answer where it is known (the same for every member), this member's own view before its first collective
+    bool spans_devices() const override { const int v = g->spans.load(std::memory_order_acquire); return v < 0 ? multi_device : v != 0; }
     const char* transport() const override {
         return multi_device ? "local (N contexts of one process on one GPU each, peer copies ordered by HIP events)"
                             : "local (N contexts of one process, device-to-device copies ordered by HIP events)";
     }
     // first collective (every rank has joined by its rendezvous): best-effort peer access to the other ranks' GPUs
     void check_peers() {
-        if (peers_checked) return;
-        peers_checked = true;
+        const u32 e = g->epoch.load(std::memory_order_acquire);
+        if (checked_epoch == e) return;
+        checked_epoch = e;
         const int mine = g->slots[rank].device;
         for (u32 p = 0; p < count; p++) {
             const int d = g->slots[p].device;
             if (d == mine || d < 0) continue;
             multi_device = true;
+            g->spans.store(1, std::memory_order_release);
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, mine, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);   // "already enabled" is fine
             (void)hipGetLastError();
         }
+        if (!multi_device) { int unknown = -1; g->spans.compare_exchange_strong(unknown, 0); }
     }
     // Blocks to copy from other ranks' memory into mine on my stream. One device for the whole group: one launch per <= 64 blocks
     // (k_copy_blocks); several devices: a runtime peer copy per block.
@@ -212,9 +228,11 @@ struct LocalComm : Comm {
         for (auto& b : blocks) {
             if (!b.bytes) continue;
             if (b.bytes >> (COPY_CHUNK_LOG + 30)) throw HipError("shard group: block too large");
+            const u64 need = (u64)((b.bytes + (size_t(1) << COPY_CHUNK_LOG) - 1) >> COPY_CHUNK_LOG);     // < 2^30 by the check above
+            if ((u64)chunks + need > 0x7fffffffull) flush();       // the grid (and chunk0) count chunks in 31 bits: start a new launch first
             cb.b[cb.n] = CopyBlock{b.src, b.dst, (unsigned long long)b.bytes};
             cb.chunk0[cb.n] = chunks;
-            chunks += (u32)((b.bytes + (size_t(1) << COPY_CHUNK_LOG) - 1) >> COPY_CHUNK_LOG);
+            chunks += (u32)need;
             if (++cb.n == COPY_BATCH) flush();
         }
         flush();

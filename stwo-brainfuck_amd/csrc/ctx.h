@@ -240,7 +240,8 @@ inline void Ctx::wait_stamp(int k) {
                 if (e == hipSuccess) { if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == proof_seq) return; throw HipError("the stream drained without writing the stamp the host waits for"); }
                 if (e != hipErrorNotReady) BF_HIP(e);
             }
-            if (waited > spin_seconds) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            // past the polling budget (200 us under the blocking sync policy, 8 ms inside a proof otherwise): sleep between looks
+            if (waited > spin_seconds) std::this_thread::sleep_for(std::chrono::microseconds(sync_blocking ? 200 : 50));
         }
     }
 }

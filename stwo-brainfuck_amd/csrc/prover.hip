@@ -702,11 +702,13 @@ struct HipProver {
         double t_start = now();
         mark_t0 = t_start;
         struct SpinScope { Ctx& c; double saved; ~SpinScope() { c.spin_seconds = saved; } } spin_scope{c, c.spin_seconds};
-        c.spin_seconds = 8e-3;
+        if (!c.sync_blocking) c.spin_seconds = 8e-3;      // bfhip_ctx_set_sync_policy(blocking): hosts with more contexts than cores keep the short poll
         c.arena.reset();
         // Mailboxes (mailbox.hip): one process per proof only — a shard group's exchanges are rendezvous points of their own. The ring must
         // not need recycling while a mailbox kernel waits for this thread, so it is recycled here, where nothing of this context is in flight.
-        c.use_mailbox = c.mailbox_mode < 0 ? log_max_rows <= 21 : c.mailbox_mode != 0;
+        // Not by default under the blocking sync policy either: a mailbox kernel spins on the GPU until this thread posts, and a host that
+        // asked for sleeping waits is one whose threads may be descheduled for long (BFHIP_MAILBOX=1 still forces it; wait_stamp then sleeps).
+        c.use_mailbox = c.mailbox_mode < 0 ? (log_max_rows <= 21 && !c.sync_blocking) : c.mailbox_mode != 0;
         const bool mb = c.use_mailbox && !sharded() && !(c.overlap & 2u);
         if (++c.proof_seq == 0) c.proof_seq = 1;
         c.reap_some();
@@ -1090,7 +1092,12 @@ struct HipProver {
         // ---- FRI commit (a10), proof of work (a11), decommitment (a12) -------------------------------------------------------------------
         // Sanity check of prover::prove (composition OODS value == constraints evaluated on the sampled mask values): host arithmetic on values
         // known since the sampling — done while the GPU runs the FRI commit phase, not after the proof's last kernel (r04)
+        auto mailbox_gave_up = [&]() { for (int k = 1; k <= 5; k++) if (c.mailbox_err_host()[2 * k]) return true; return false; };
+        const char* mailbox_msg = "a mailbox kernel gave up waiting for the host (BFHIP_MAILBOX_TIMEOUT_MS): the proof was computed from stale challenge words";
         auto sanity_check = [&]() {
+            // the mailbox error words are final here (every mailbox kernel ran before stamp 4 was written): a kernel that gave up made the
+            // phases run on stale challenge words, and THAT is the error to report — not the constraint mismatch it causes
+            if (mb && mailbox_gave_up()) throw HipError(mailbox_msg);
             Q31 want = eval_composition_at_point(bp.log_sizes, bp.claimed_sums, log_max_rows, el, oods, bp.proof.sampled_values, random_coeff, c.conv);
             const auto& cv = bp.proof.sampled_values[3];
             std::vector<Q31> ce[4] = {cv[0], cv[1], cv[2], cv[3]};
@@ -1105,7 +1112,7 @@ struct HipProver {
             mark("mailbox 4 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[9] * 0.01;
             mark("mailbox 5 waited"); if (trace_host) host_marks.back().second = host_marks[host_marks.size() - 2].second + c.mailbox_err_host()[11] * 0.01;
         }
-        if (*c.mailbox_err_host()) throw HipError("a mailbox kernel gave up waiting for the host (BFHIP_MAILBOX_TIMEOUT_MS): the proof was computed from stale challenge words");
+        if (*c.mailbox_err_host()) throw HipError(mailbox_msg);
         {
             float ms0 = 0.f, ms1 = 0.f;
             if (!reuse) BF_HIP(hipEventElapsedTime(&ms0, c.ev[0], c.ev[1]));

@@ -499,8 +499,22 @@ def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pk
     monkeypatch.setenv("BFHIP_MAILBOX_TEST_DELAY_MS", "30")
     c = pkg.Context(0, max_log_domain=23)
     try:
-        with pytest.raises(pkg.BfhipError):
+        # the error names its cause (a late host), not the constraint mismatch the stale challenge words produce
+        with pytest.raises(pkg.BfhipError, match="mailbox kernel gave up waiting for the host"):
             pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21)
+        # the SAME context recovers: the timeout and the test delay are reset on the live context (Ctx::init read the environment), the stale
+        # flag / stamp slots, the error words, the staging ring and the pending-mailbox count of the failed proof must not leak into the next
+        c.set_mailbox(1, 10000, 0)
+        for _ in range(3):
+            assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
+        c.set_mailbox(0, 0, -1)
+        assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
+        # the blocking sync policy switches the automatic mailbox mode off (and a forced one still proves the same bytes, sleeping in its waits)
+        c.set_mailbox(-1, 0, -1)
+        c.set_sync_policy(True)
+        assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
+        c.set_mailbox(1, 0, -1)
+        assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
     finally:
         c.close()
     monkeypatch.delenv("BFHIP_MAILBOX_TIMEOUT_MS"); monkeypatch.delenv("BFHIP_MAILBOX_TEST_DELAY_MS")
