@@ -5,6 +5,7 @@
 // precompute_twiddles crates/brainfuck_prover/src/brainfuck_air/mod.rs:480-484, interpolate/evaluate via
 // tree_builder.extend_evals/commit mod.rs:497-500,550-583,690-723.
 #pragma once
+#include "simd_port.h"
 #include "field.h"
 #include <algorithm>
 
@@ -185,6 +186,10 @@ static inline M31 circle_twiddle(const M31* first_line, size_t h) {
 // CircleEvaluation (bit-reversed order) -> CirclePoly coefficients. CpuBackend::interpolate, log_size >= 3.
 static inline void circle_interpolate(M31* values, u32 log_size, const TwiddleTree& tw) {
     assert(log_size >= 3);
+    if (simd::enabled() && log_size >= 5) {      // SIMD mode of the port (orc_set_simd: bench.py's cpu_baseline): same values, 16 lanes per instruction
+        simd::circle_ifft(reinterpret_cast<u32*>(values), log_size, reinterpret_cast<const u32*>(tw.itwiddles.data()), tw.itwiddles.size(), inv(M31(u32(1) << log_size)).v);
+        return;
+    }
     u32 half_log = log_size - 1;
     size_t n = size_t(1) << log_size;
     size_t l0len; const M31* l0 = line_twiddles_layer(tw.itwiddles, half_log, 0, &l0len);
@@ -206,6 +211,10 @@ static inline void circle_interpolate(M31* values, u32 log_size, const TwiddleTr
 // bit-reversed order. CpuBackend::evaluate.
 static inline void circle_evaluate(M31* values, u32 log_size, const TwiddleTree& tw) {
     assert(log_size >= 3);
+    if (simd::enabled() && log_size >= 5) {
+        simd::circle_fft(reinterpret_cast<u32*>(values), log_size, reinterpret_cast<const u32*>(tw.twiddles.data()), tw.twiddles.size());
+        return;
+    }
     u32 half_log = log_size - 1;
     size_t n = size_t(1) << log_size;
     for (int layer = (int)half_log - 1; layer >= 0; layer--) {

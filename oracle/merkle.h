@@ -8,6 +8,7 @@
 // Reference call sites: tree_builder.commit(channel) crates/brainfuck_prover/src/brainfuck_air/mod.rs:500,583,723.
 #pragma once
 #include "blake2s.h"
+#include "simd_port.h"
 #include <map>
 #include <string>
 #include <algorithm>
@@ -71,6 +72,13 @@ struct MerkleProver {
             auto& layer = mp.layers[log];
             layer.resize(n);
             const std::vector<Hash32>* prev = (log < (int)max_log) ? &mp.layers[log + 1] : nullptr;
+            // SIMD mode of the port (orc_set_simd: bench.py's cpu_baseline): 16 nodes per vector compression, same bytes
+            if (simd::enabled() && n >= 16 && conventions().merkle_channel == 0 && conventions().merkle_node_hash == 0) {
+                std::vector<const u32*> ptrs(lc.size());
+                for (size_t c = 0; c < lc.size(); c++) ptrs[c] = lc[c].data;
+                simd::merkle_layer_blake2s(prev ? (*prev)[0].b : nullptr, ptrs.data(), ptrs.size(), n, layer[0].b);
+                continue;
+            }
 #pragma omp parallel for schedule(static) if (n >= 4096)
             for (size_t i = 0; i < n; i++) {
                 u32 vals_buf[64]; std::vector<u32> big; u32* vals = vals_buf;

@@ -34,6 +34,10 @@ int orc_set_threads(int n) {
     (void)n; return 1;
 #endif
 }
+// SIMD mode of the port (oracle/simd_port.cpp): 1 = the Merkle layer loop and the circle transforms run on AVX-512 (bench.py's cpu_baseline,
+// the stand-in for SimdBackend + rayon); 0 (default) = the scalar checker code. Returns the mode in force (0 when the host lacks AVX-512).
+int orc_set_simd(int on) { orc::simd::set_enabled(on != 0); return orc::simd::enabled() ? 1 : 0; }
+int orc_simd_available() { return orc::simd::available() ? 1 : 0; }
 
 // Byte-level stwo conventions (field.h `Conventions`; same numbering as include/bfhip.h `bfhip_conventions`). Process-wide: set it before a call.
 int orc_set_conventions(u32 merkle_node_hash, u32 mix_u64, u32 logup_mask_order, u32 merkle_channel) {

@@ -331,10 +331,20 @@ struct Prover {
     std::function<void(const char*, const Channel&)> trace_hook;  // optional transcript tap for tests
 
     BrainfuckProof prove(const std::vector<Registers>& vm_trace, const std::vector<u32>& code) {
+        // ORC_TIMING=1: wall-clock seconds per phase on stderr (where the port's time goes; bench.py's cpu_baseline notes)
+        const bool timing = getenv("ORC_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "orc timing %-28s %8.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+            t_last = t;
+        };
         // Protocol Setup (mod.rs:479-487)
         TwiddleTree tw = precompute_twiddles(CanonicCoset{log_max_rows + cfg.log_blowup + 2}.circle_domain().half_coset);
         Channel ch;
         std::vector<CommitmentTree> trees(4);
+        lap("twiddles");
 
         // Phase 0 — preprocessed trace: IsFirst(LOG_MAX_ROWS..=LOG_N_LANES) (mod.rs:495-500)
         trees[0].polys.resize(log_max_rows - LOG_N_LANES + 1);
@@ -344,8 +354,10 @@ struct Prover {
             std::vector<u32> col(size_t(1) << log, 0); col[0] = 1;   // gen_is_first
             trees[0].polys[i] = interpolate_col(col, log, tw);
         }
+        lap("preprocessed interpolate");
         commit_tree(trees[0], cfg, tw, ch);
         tap("root0", ch);
+        lap("preprocessed commit");
 
         // Phase 1 — main trace (mod.rs:506-583)
         std::vector<Table> tables = build_tables(vm_trace, code);
@@ -363,8 +375,10 @@ struct Prover {
                 trees[1].polys[j] = interpolate_col(broadcast16(tables[jobs[j].first].cols[jobs[j].second]), bp.log_sizes[jobs[j].first], tw);
         }
         for (int c = 0; c < N_COMPONENTS; c++) ch.mix_u64(bp.log_sizes[c]);     // claim.mix_into (mod.rs:102-116, components/mod.rs:132-134)
+        lap("tables + main interpolate");
         commit_tree(trees[1], cfg, tw, ch);
         tap("root1", ch);
+        lap("main commit");
 
         // Phase 2 — interaction trace (mod.rs:589-723)
         InteractionElements el;
@@ -376,19 +390,24 @@ struct Prover {
             for (auto& col : cols) trees[2].polys.push_back(interpolate_col(col, bp.log_sizes[c], tw));
         }
         for (int c = 0; c < N_COMPONENTS; c++) ch.mix_felts(&bp.claimed_sums[c], 1);         // interaction_claim.mix_into (mod.rs:189-203)
+        lap("logUp + interpolate");
         commit_tree(trees[2], cfg, tw, ch);
         tap("root2", ch);
+        lap("interaction commit");
 
         // Proof generation — stwo prover::prove (mod.rs:729-732)
         auto L = component_layouts(bp.log_sizes);
         QM31 random_coeff = ch.draw_felt();
         compute_composition(trees, L, el, bp.claimed_sums, random_coeff, tw);
+        lap("composition");
         commit_tree(trees[3], cfg, tw, ch);
         tap("root3", ch);
+        lap("composition commit");
 
         PointQ oods = get_random_point(ch);
         auto sample_points = mask_points(L, log_max_rows, oods);
         bp.proof = prove_values(trees, sample_points, ch, tw);
+        lap("sampling, quotients, FRI");
 
         // Sanity check of prover::prove: composition OODS eval must match the constraints evaluated on the sampled mask.
         QM31 comp_eval[4];
@@ -465,6 +484,14 @@ struct Prover {
     // CommitmentSchemeProver::prove_values
     StarkProof prove_values(std::vector<CommitmentTree>& trees, const std::vector<std::vector<std::vector<PointQ>>>& sample_points, Channel& ch, const TwiddleTree&) {
         StarkProof pf;
+        const bool timing = getenv("ORC_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "orc timing   %-26s %8.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+            t_last = t;
+        };
         // OODS sampling (a8)
         std::vector<std::vector<std::vector<PointSample>>> samples(trees.size());
         pf.sampled_values.resize(trees.size());
@@ -481,6 +508,7 @@ struct Prover {
         }
         { std::vector<QM31> flat; for (auto& t : pf.sampled_values) for (auto& c : t) for (auto& v : c) flat.push_back(v); ch.mix_felts(flat.data(), flat.size()); }
         tap("sampled", ch);
+        lap("sampling");
         QM31 random_coeff = ch.draw_felt();
 
         // compute_fri_quotients: group columns by LDE log size (descending, stable), one SecureEvaluation per size.
@@ -499,12 +527,43 @@ struct Prover {
             SecureCol q; q.init(log);
             size_t n = size_t(1) << log;
             const size_t CH = 1024, nb = sb.size();
+            // SIMD mode of the port (orc_set_simd: bench.py's cpu_baseline): the column loop of accumulate_row_quotients on 16 rows per
+            // instruction (simd_port.cpp); denominators and their batch inverse stay the scalar code. Same values.
+            const bool use_simd = simd::enabled() && n >= 16;
+            std::vector<u32> lc_flat; std::vector<u32> ci_flat; std::vector<size_t> lc_off(nb + 1, 0);
+            if (use_simd) {
+                for (size_t b = 0; b < nb; b++) {
+                    lc_off[b] = ci_flat.size();
+                    for (size_t k = 0; k < sb[b].cols.size(); k++) {
+                        ci_flat.push_back((u32)sb[b].cols[k].first);
+                        for (int w = 0; w < 3; w++) { auto a = qc.line_coeffs[b][k][w].to_u32(); lc_flat.insert(lc_flat.end(), a.begin(), a.end()); }
+                    }
+                }
+                lc_off[nb] = ci_flat.size();
+            }
 #pragma omp parallel for schedule(static)
             for (size_t r0 = 0; r0 < n; r0 += CH) {
                 size_t r1 = std::min(n, r0 + CH);
                 std::vector<CM31> den((r1 - r0) * nb), deninv((r1 - r0) * nb);
                 for (size_t row = r0; row < r1; row++) for (size_t b = 0; b < nb; b++) den[(row - r0) * nb + b] = quotient_denominator(sb[b], pts[bit_reverse_index((u32)row, log)]);
                 batch_inverse(den.data(), deninv.data(), den.size());
+                if (use_simd) {
+                    const size_t m = r1 - r0;
+                    std::vector<u32> ys(m), da(m * nb), db(m * nb);
+                    for (size_t row = r0; row < r1; row++) {
+                        ys[row - r0] = pts[bit_reverse_index((u32)row, log)].y.v;
+                        for (size_t b = 0; b < nb; b++) { da[b * m + (row - r0)] = deninv[(row - r0) * nb + b].a.v; db[b * m + (row - r0)] = deninv[(row - r0) * nb + b].b.v; }
+                    }
+                    std::vector<simd::QuotientBatch> qb(nb);
+                    for (size_t b = 0; b < nb; b++) {
+                        qb[b].col_index = ci_flat.data() + lc_off[b]; qb[b].line_coeffs = lc_flat.data() + 12 * lc_off[b]; qb[b].n_cols = lc_off[b + 1] - lc_off[b];
+                        auto bc = qc.batch_random_coeffs[b].to_u32(); for (int w = 0; w < 4; w++) qb[b].batch_coeff[w] = bc[w];
+                        qb[b].deninv_a = da.data() + b * m; qb[b].deninv_b = db.data() + b * m;
+                    }
+                    u32* outp[4] = {q.c[0].data(), q.c[1].data(), q.c[2].data(), q.c[3].data()};
+                    simd::quotient_rows(cols.data(), ys.data(), qb.data(), nb, r0, r1, outp);
+                    continue;
+                }
                 std::vector<u32> vals(cols.size());
                 for (size_t row = r0; row < r1; row++) {
                     for (size_t k = 0; k < cols.size(); k++) vals[k] = cols[k][row];
@@ -515,12 +574,14 @@ struct Prover {
             i = j;
         }
 
+        lap("quotients");
         // FriProver::commit
         auto coord_refs = [](const SecureCol& s) { std::vector<ColRef> r; for (int k = 0; k < 4; k++) r.push_back({s.c[k].data(), s.log_size}); return r; };
         std::vector<ColRef> first_refs;
         for (auto& q : quotients) for (auto& r : coord_refs(q)) first_refs.push_back(r);
         MerkleProver first_tree = MerkleProver::commit(first_refs);
         ch.mix_root(first_tree.root());
+        lap("FRI first-layer tree");
         struct Inner { std::vector<QM31> eval; u32 log; SecureCol sc; MerkleProver tree; };
         std::vector<Inner> inner;
         u32 line_log = quotients[0].log_size - 1;
@@ -549,6 +610,7 @@ struct Prover {
         pf.fri_proof.last_layer_coeffs = coeffs;
         pf.fri_proof.last_layer_log_size = cfg.log_last_layer_degree_bound;
         tap("fri_commit", ch);
+        lap("FRI folds + layer trees");
 
         // Proof of work
         pf.proof_of_work = grind(ch, cfg.pow_bits);

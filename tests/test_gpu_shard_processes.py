@@ -1,0 +1,174 @@
+"""-m gpu: a shard group whose ranks are PROCESSES (one libbfhip context each) — the deployment's control flow: the 128-byte unique id travels
+over torch.distributed (gloo), every process joins with bfhip_ctx_join_rccl_group, RcclComm moves DEVICE buffers, the waits are bounded across
+processes. The box has one GPU and real librccl refuses two ranks on one device, so the RCCL entry points come from the process-per-rank test
+double tests/mock_rccl_ipc.cpp (BFHIP_RCCL_LIBRARY; POSIX shared-memory rendezvous, hipIpc memory handles). Still unexercised afterwards:
+librccl itself and xGMI."""
+import glob
+import hashlib
+import json
+import os
+import signal
+import socket
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROGS = os.path.join(ROOT, "tests", "golden", "programs")
+
+
+def build_ipc_double():
+    """tests/libmock_rccl_ipc.so (also built by __graft_entry__.build()); rebuilt when the source is newer."""
+    src, so = os.path.join(ROOT, "tests", "mock_rccl_ipc.cpp"), os.path.join(ROOT, "tests", "libmock_rccl_ipc.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", so, src,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return so
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def start_ranks(tmp_path, world, program, inp, lmr, proofs=1, extra_env=None, conv=(0, 0, 0, 0)):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        out = str(tmp_path / f"rank{r}.json")
+        log = open(str(tmp_path / f"rank{r}.log"), "w")
+        p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), "--program", os.path.join(PROGS, program), "--input-hex", inp.hex(),
+                              "--log-max-rows", str(lmr), "--out", out, "--proofs", str(proofs), "--conventions", ",".join(str(v) for v in conv)], env=env, stdout=log, stderr=subprocess.STDOUT)
+        procs.append((p, out, log))
+    return procs
+
+
+def finish(procs, timeout):
+    """Waits for every rank (bounded); kills exactly the PIDs started here if the limit passes. Returns [(exit code, result dict, log text)]."""
+    t_end = time.time() + timeout
+    res = []
+    for p, out, log in procs:
+        try:
+            p.wait(timeout=max(1.0, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        log.close()
+        try:
+            data = json.load(open(out))
+        except Exception:
+            data = {}
+        res.append((p.returncode, data, open(log.name).read()[-3000:]))
+    for f in glob.glob("/dev/shm/bfhip_mock_*"):      # a killed rank cannot unlink the rendezvous segment
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return res
+
+
+@pytest.mark.with_poseidon
+@pytest.mark.parametrize("world", [2, 4])
+def test_process_group_proves_collatz_like_one_gpu(pkg, oracle, conv, tmp_path, world):
+    code, inp, lmr = open(os.path.join(PROGS, "collatz.bf")).read(), b"7\n", 21
+    c1 = pkg.Context(0, max_log_domain=lmr + 2)
+    try:
+        single = pkg.prove_brainfuck(code, inp, ctx=c1, log_max_rows=lmr)
+    finally:
+        c1.close()
+    want, _, _ = oracle.prove(code, inp, log_max_rows=lmr)
+    assert single == want
+    res = finish(start_ranks(tmp_path, world, "collatz.bf", inp, lmr, proofs=2, conv=conv), timeout=600)
+    for r, (rc, data, log) in enumerate(res):
+        assert rc == 0, (r, rc, data, log)
+        assert "BFHIP_RCCL_LIBRARY" in data["transport"], data
+        assert data["proofs"] == [hashlib.sha256(single).hexdigest()] * 2, (r, data)
+        assert open(str(tmp_path / f"rank{r}.json") + ".proof", "rb").read() == single, f"rank {r}: bytes differ from the single-GPU proof"
+        st = data["group_stats"]
+        assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
+
+
+@pytest.mark.single_conv
+@pytest.mark.parametrize("world", [2, 4])
+def test_process_group_proves_fib19_like_one_gpu(pkg, tmp_path, world):
+    """BASELINE config 2 / 4 size (2^24 domain rows) over `world` processes; the digest is the committed one of the CPU oracle's proof."""
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "fib19_lmr24_oracle_proof.json")))["stwo"]
+    res = finish(start_ranks(tmp_path, world, "fib19.bf", b"", 24), timeout=900)
+    for r, (rc, data, log) in enumerate(res):
+        assert rc == 0, (r, rc, data, log)
+        assert data["proofs"] == [want["sha256"]], (r, data)
+        assert os.path.getsize(str(tmp_path / f"rank{r}.json") + ".proof") == want["proof_bytes"]
+
+
+def test_a_killed_rank_fails_the_others_within_the_timeout(tmp_path):
+    """Rank 1 is killed (SIGKILL, the exact PID) while the group is proving in a loop: rank 0 must come back with an ERROR from the library
+    within BFHIP_COMM_TIMEOUT_S — not hang, and not exit as if it had proved."""
+    limit = 20
+    procs = start_ranks(tmp_path, 2, "collatz.bf", b"7\n", 21, proofs=100000, extra_env={"BFHIP_COMM_TIMEOUT_S": str(limit)})
+    out0 = procs[0][1]
+    t0 = time.time()
+    while time.time() - t0 < 300:                      # until the group has produced a few proofs
+        try:
+            if len(json.load(open(out0)).get("proofs", [])) >= 3:
+                break
+        except Exception:
+            pass
+        if procs[0][0].poll() is not None:
+            break
+        time.sleep(0.05)
+    else:
+        finish(procs, 1)
+        pytest.fail("the group never produced a proof")
+    victim = procs[1][0]
+    os.kill(victim.pid, signal.SIGKILL)
+    t_kill = time.time()
+    try:
+        procs[0][0].wait(timeout=limit + 30)
+    except subprocess.TimeoutExpired:
+        finish(procs, 1)
+        pytest.fail(f"rank 0 still running {limit + 30} s after its peer was killed")
+    took = time.time() - t_kill
+    res = finish(procs, 5)
+    rc0, data0, log0 = res[0]
+    assert rc0 == 3, (rc0, data0, log0)               # BfhipError caught by the worker: the library reported the failure
+    assert "error" in data0 and len(data0["proofs"]) >= 3, data0
+    assert took <= limit + 10, took
+
+
+def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
+    """`python3 bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (fresh processes), they form a shard group (here both on
+    device 0 through the process-per-rank double, torch.distributed over gloo), and rank 0's ONE line reports n_gpus 2, scaling "strong", the
+    group's proof with the SHA-256 of the one-GPU proof, the replicas beside it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
+                        "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "900"], env=env, capture_output=True, text=True, timeout=1000)
+    for f in glob.glob("/dev/shm/bfhip_mock_*"):
+        os.remove(f)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "fib19_lmr24_oracle_proof.json")))["stwo"]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 3
+    assert line["parity_checked"] is True and line["parity"]["proof_sha256"] == want["sha256"]
+    head = line["strong_scaling"]["workloads"]["fib19"]
+    assert head["identical_to_n1"] is True and head["proof_sha256"] == want["sha256"] and head["speedup_vs_n1"] == line["speedup_vs_n1"]
+    assert line["replicas"]["scaling"] == "weak" and line["replicas"]["value"] > 0
+    assert line["config"]["ranks_started_by"].startswith("bench.py itself")
+    assert abs(line["value"] - line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6      # one proof's cells, not N times
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "must agree" in r.stderr
