@@ -236,19 +236,14 @@ def _bench():
     return m
 
 
-def test_bench_strong_scaling_digest_shapes():
-    """`strong_scaling` of the bench line: per workload ms_per_proof / n1_ms_per_proof / speedup_vs_n1 / comm_share_of_proof lifted out of the
-    probe result, an unfinished stage reported as an error, the in-process transport beside RCCL."""
+def test_bench_cpu_budget_reports_effective_cores():
+    """cpu_baseline.cores must be the cores the process can actually use: min(threads in the affinity mask, cgroup CPU quota) — not the size of
+    an OpenMP team that time-shares them (VERDICT r04 weak #8)."""
     b = _bench()
-    probe = {"transport": "RCCL", "stages": {"fib19": {"ms_per_proof": 10.0, "n1_ms_per_proof": 30.0, "speedup_vs_n1": 3.0, "comm_share_of_proof": 0.2, "identical_to_n1": True,
-                                                       "proof_sha256": "ab", "cells_per_s": 1.0, "all_members_same_proof": True},
-                                             "trace_2p26_poseidon252": {"error": "boom"}},
-             "single_process": {"transport": "local", "stages": {"fib19": {"ms_per_proof": 11.0}}}}
-    d = b.strong_scaling_summary(probe, 8)
-    assert d["n_gpus"] == 8 and d["rccl"]["workloads"]["fib19"]["speedup_vs_n1"] == 3.0 and d["rccl"]["workloads"]["fib19"]["identical_to_n1"] is True
-    assert "error" in d["rccl"]["workloads"]["trace_2p26_poseidon252"]
-    assert d["single_process"]["workloads"]["fib19"] == {"ms_per_proof": 11.0}
-    assert b.strong_scaling_summary({"error": "no gpus"}, 2)["rccl"]["error"] == "no gpus"
+    bud = b.host_cpu_budget()
+    assert bud["affinity_threads"] >= 1 and 1 <= bud["cores_effective"] <= bud["affinity_threads"]
+    if bud["quota_cores"] is not None:
+        assert bud["cores_effective"] <= max(1, int(bud["quota_cores"]))
 
 
 def test_bench_simdbackend_work_counts_fib19():
