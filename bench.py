@@ -80,6 +80,48 @@ def committed_digests():
         return {}
 
 
+def roofline_from_committed_rocprof(compressions_per_proof, launches_per_proof):
+    """frac_rocprof: k_merkle_layer's VALU fraction recomputed from the latest committed profiles/rNN_roofline_single_stream_kernel_stats.csv (average
+    launch duration by rocprofv3) — next to `frac` (HIP events of THIS run). The JSON line of the profiled run lies beside the CSV and carries the
+    SHA-256 of the kernel sources; a mismatch reports null with the reason. frac_range_this_round: min..max of `frac` over the round's committed lines."""
+    import csv
+    import glob
+    out = {"frac_rocprof": None, "frac_rocprof_source": None, "frac_range_this_round": None}
+    if not compressions_per_proof:
+        return out
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_single_stream_kernel_stats.csv")))
+    if not cands:
+        out["frac_rocprof_source"] = "no committed rocprofv3 summary (tools/profile_round.sh rNN roofline)"
+        return out
+    path = cands[-1]
+    rnd = os.path.basename(path).split("_")[0]
+    try:
+        line = json.loads(open(path.replace("_kernel_stats.csv", "_under_rocprof.json")).read().strip().split("\n")[-1])
+        if line["roofline"].get("kernel_sources_sha256") != kernel_sources_sha256():
+            out["frac_rocprof_source"] = os.path.relpath(path, ROOT) + " is STALE: taken on other kernel sources — rerun tools/profile_round.sh roofline"
+            return out
+        row = next(r for r in csv.DictReader(open(path)) if r["Name"].split("(")[0].replace("void ", "").replace("bf::", "") == "k_merkle_layer")
+        avg_us = float(row["AverageNs"]) / 1e3
+        ms_per_proof = avg_us * launches_per_proof / 1e3
+        out["frac_rocprof"] = round(compressions_per_proof * VALU_OPS_PER_COMPRESSION / (ms_per_proof * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)
+        out["avg_launch_us_rocprof"] = round(avg_us, 2)
+        out["frac_rocprof_source"] = (os.path.relpath(path, ROOT) + f": {row['Calls']} launches, average {avg_us:.1f} us (rocprofv3 --kernel-trace --stats of bench.py --steps 20 --warmup 5 "
+                                      "on one stream, same kernel sources; that run's own HIP events: frac " + str(line["roofline"].get("frac")) + ")")
+        fr = []
+        for f in glob.glob(os.path.join(ROOT, "profiles", rnd + "_*.json")):
+            try:
+                d = json.loads(open(f).read().strip().split("\n")[-1])
+                if isinstance(d, dict) and isinstance(d.get("roofline"), dict) and d["roofline"].get("kernel") == "k_merkle_layer" and d.get("n_gpus") == 1:
+                    fr.append(d["roofline"]["frac"])
+            except Exception:
+                pass
+        if fr:
+            out["frac_range_this_round"] = {"min": min(fr), "max": max(fr), "lines": len(fr), "what": f"`frac` (HIP events) over the {rnd} bench lines committed under profiles/ (boxes and run modes differ)"}
+    except Exception as e:
+        out["frac_rocprof_source"] = f"{os.path.relpath(path, ROOT)}: {e!r}"
+    return out
+
+
 def host_cpu_budget():
     """What this process may use of the host: hardware threads in its affinity mask, the cgroup CPU quota (cores) if one is set, SMT width.
     cores_effective = min(affinity threads, quota): a team of more threads than that only time-shares the granted cores."""
@@ -793,6 +835,10 @@ def main():
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}, or plain python3 bench.py --gpus {args.gpus})")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1:
+        # a rank that is ended from outside (the self-launcher's time limit, a driver's timeout) says where it was: Python stacks of all its threads
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGTERM, all_threads=True, chain=True)
         os.environ.setdefault("BFHIP_COMM_TIMEOUT_S", "120")     # a collective that never completes ends the stage with an error, not the run with a hang
 
     # N > 1, replicas mode: besides the contract's weak-scaling number, measure ONE proof over all N GPUs (shard group, strong scaling) in
@@ -854,6 +900,13 @@ def main():
     spec.loader.exec_module(replicas)
     cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
 
+    t_start = time.time()
+
+    def note(msg):
+        """N > 1: one stderr line per stage and rank — where a multi-GPU run is when something hangs (the JSON line stays the only stdout)."""
+        if world > 1:
+            print(f"bench.py[rank {rank}/{world} +{time.time() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     def over_ranks(value, op):
         """max / min / sum of a number over the ranks (the timing protocol's channel: torch.distributed)."""
         if dist is None:
@@ -879,6 +932,7 @@ def main():
     shard_error, n1 = None, None
     if sharded:
         # the same proof by ONE GPU alone, every rank on its own GPU at the same time, right before the group forms: what speedup_vs_n1 divides by
+        note("one-GPU reference proofs")
         trace.prove(args.log_max_rows); ctx.sync()
         t0 = time.perf_counter()
         for _ in range(max(1, args.n1_steps)):
@@ -886,9 +940,11 @@ def main():
         ctx.sync()
         n1 = {"ms_per_proof": over_ranks((time.perf_counter() - t0) / max(1, args.n1_steps), "max") * 1e3, "proof_sha256": hashlib.sha256(p1).hexdigest(),
               "steps": max(1, args.n1_steps), "note": "every rank alone on its own GPU at the same time; the slowest rank's time"}
+        note(f"one-GPU reference {n1['ms_per_proof']:.2f} ms; joining the shard group")
         try:
             join_group(ctx)
             ok = True
+            note("joined: " + ctx.group_info()[2])
         except Exception as e:
             ok, shard_error = False, f"joining the shard group failed on rank {rank}: {e!r}"
         if not agree(ok):
@@ -918,6 +974,7 @@ def main():
     pin = lambda: pinned_host_thread(args.pin and args.inflight == 1, device, local_rank, world)      # noqa: E731
     group = None
     if sharded:
+        note(f"timed region: {args.warmup} + {args.steps} proofs over the group")
         try:
             with pin():
                 dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t, on_timed_start=start_events)
@@ -928,6 +985,7 @@ def main():
             ok = True
         except Exception as e:
             ok, shard_error = False, f"the shard group's proof failed on rank {rank}: {e!r}"
+        note("group proofs done" if ok else f"group proofs FAILED: {shard_error}")
         if not agree(ok):
             shard_error = shard_error or "the shard group's proof failed on another rank"
             sharded = False
@@ -944,6 +1002,7 @@ def main():
     # ---- N > 1: BASELINE configs 3/4 literal (synthetic 2^24-row trace) and 5 (2^26 rows, Poseidon252) over a second group, each with its one-GPU time
     extra_stages = {}
     if sharded and not args.no_extra_stages:
+        note("extra stages: 2^24-row trace (configs 3/4), 2^26-row Poseidon252 trace (config 5)")
         big = None
         try:
             stages = [("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, None), ("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, None)]
@@ -966,6 +1025,7 @@ def main():
 
     # ---- replicas: every rank proves its own trace, no data-path collective (the headline at N = 1, with --replicas, or if the group failed) -------
     replica_line = None
+    note("replicas")
     if not sharded:
         with pin():
             dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t, on_timed_start=start_events)
@@ -1022,6 +1082,10 @@ def main():
                         "hbm": hbm}
         else:
             roofline = {**common, **hbm}
+        roofline["kernel_sources_sha256"] = kernel_sources_sha256()
+        # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this command (tools/profile_round.sh roofline: 20 steps on ONE
+        # stream, BFHIP_SINGLE_STREAM=1) — trusted only while that run was taken on the kernel sources that ran here
+        roofline.update(roofline_from_committed_rocprof(roofline.get("compressions_per_proof"), roofline["launches"] / args.steps))
         if sharded:
             roofline["scope"] = f"rank 0's share of the group's proofs (1 of {world} ranks): launches, compressions and kernel times are this rank's"
         # ---- the circle-FFT kernels (north-star: >= 60 % HBM on the FFT kernel): one extra UNTIMED proof with every kernel bracketed ----
@@ -1169,8 +1233,6 @@ def main():
         print(json.dumps(out), flush=True)
     if args.reuse_preprocessed:
         lib.bfhip_ctx_reuse_preprocessed(ctx._h, 0)
-    if sharded:
-        ctx.leave_group()
     for c2, t2 in extra:
         t2.close(); c2.close()
     trace.close()

@@ -30,6 +30,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
+    if (const char* v = getenv("BFHIP_SINGLE_STREAM")) single_stream = atoi(v) != 0;
     if (const char* v = getenv("BFHIP_OVERLAP")) { overlap = (u32)atoi(v) & 7u; overlap_user_set = true; }
     if (const char* v = getenv("BFHIP_MAILBOX")) mailbox_mode = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("BFHIP_MAILBOX_TIMEOUT_MS")) mailbox_timeout = std::max(1, atoi(v)) * 1e-3;

@@ -57,6 +57,9 @@ struct Ctx {
     // overlap: bit 0 = hash a tree's largest layers beside the transforms of its smaller columns; bit 1 = hash the FRI first-layer tree level by
     // level behind the quotient launches; bit 2 (shard groups) = the send-receive of a tree's largest size class on aux[0] beside the transforms of
     // its smaller columns (bfhip_ctx_set_overlap; BFHIP_OVERLAP presets it at context creation for A/B runs)
+    // BFHIP_SINGLE_STREAM=1 (at context creation): the preprocessed phase stays on the main stream — ONE stream per proof, for profiler runs whose
+    // per-kernel durations must not depend on how two streams share the GPU under the profiler (tools/profile_round.sh roofline). Same bytes.
+    bool single_stream = false;
     bool overlap_user_set = false;   // bfhip_ctx_set_overlap / BFHIP_OVERLAP decided the mask: no default is applied on top of it
     // bit 2 is ON BY DEFAULT for a shard group whose ranks sit on different GPUs (exchange_overlapped()): there an exchange is an xGMI transfer
     // that costs the stream nothing but waiting; on one shared GPU it is a copy competing for the same HBM (r03: 38.5 vs 38.8 ms) and stays off

@@ -27,6 +27,8 @@ static constexpr int TILE = 1 << TILE_LOG;
 static constexpr int CHUNK_LOG = 5;          // 32 x u32 = 128 B contiguous per strided row
 static constexpr int STRIDED_K = TILE_LOG - CHUNK_LOG;  // 7 layers per strided pass
 static constexpr int FFT_THREADS = 256;
+// PassArgs::scale of an inverse transform is 2^-n = a power of two (m31.h: m_inv_pow2): its exponent, for m_mul_pow2 (uniform: scalar unit)
+__device__ __forceinline__ u32 scale_shift(u32 scale) { return (u32)__builtin_ctz(scale); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Twiddle generation (a1). Layered buffer exactly as stwo's slow_precompute_twiddles(Coset::half_odds(R)):
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __rest
         for (u32 e4 = t * 4; e4 < tile_n; e4 += 4 * FFT_THREADS) {
             u32 gidx = lo ? (base | ((e4 >> c) << lo) | (e4 & ((1u << c) - 1))) : (base + e4);
             uint4 v = *reinterpret_cast<uint4*>(&s_val[e4]);
-            if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+            if (INV && a.scale != 1) { const u32 sk = scale_shift(a.scale); v.x = m_mul_pow2(v.x, sk); v.y = m_mul_pow2(v.y, sk); v.z = m_mul_pow2(v.z, sk); v.w = m_mul_pow2(v.w, sk); }
             st16(dst + gidx, v);
         }
     }
@@ -238,13 +240,12 @@ template <bool INV, class TW> __device__ __forceinline__ void radix16(u32 (&v)[1
 }
 __device__ __forceinline__ u32 lds_pad(u32 i) { return i + 4 * (i >> 6); }
 
-template <bool INV>
-__global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__ groups, u32 ngroups) {
-    const BlockOfGroup bg = find_group(groups, ngroups);
-    const PassArgs a = groups[bg.g];
-    __shared__ __attribute__((aligned(16))) u32 s_val[4096 + 4 * 64];
-    __shared__ u32 s_tw[4096];
-    const u32 t = threadIdx.x, k = a.k, tile = bg.tile;
+// KC != 0: k == KC is a compile-time fact (KC = 9, 10, 11, 12: k0 = layers - 7 x strided passes; the contiguous pass of the three-pass transforms of 2^24 / 2^25 / >= 2^26 cells and of
+// every two-pass size): every "layer < k" test folds away, and with them the phi copies the compiler otherwise keeps for the skipped-layer paths
+// (r05: profiles/r05_fft_isa_mix.txt). KC = 0: k read from the pass descriptor. One kernel, a uniform branch at its top picks the body.
+template <bool INV, int KC>
+__device__ __forceinline__ void fft_tile12_body(const PassArgs& a, const BlockOfGroup& bg, u32* __restrict__ s_val, u32* __restrict__ s_tw) {
+    const u32 t = threadIdx.x, k = KC ? (u32)KC : a.k, tile = bg.tile;
     const u32 base = tile << 12;
     const u32 col0 = bg.by * a.cols_per_block, col1 = min(a.ncols, col0 + a.cols_per_block);
     // The tile of the next column is fetched while the current one is transformed (16 more registers, same occupancy): without it
@@ -364,10 +365,24 @@ __global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             uint4 v = make_uint4(r[q][0], r[q][1], r[q][2], r[q][3]);
-            if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+            if (INV && a.scale != 1) { const u32 sk = scale_shift(a.scale); v.x = m_mul_pow2(v.x, sk); v.y = m_mul_pow2(v.y, sk); v.z = m_mul_pow2(v.z, sk); v.w = m_mul_pow2(v.w, sk); }
             st16(dst + base + 1024 * q + 4 * t, v);
         }
     }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__ groups, u32 ngroups, u32 generic) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
+    __shared__ __attribute__((aligned(16))) u32 s_val[4096 + 4 * 64];
+    __shared__ u32 s_tw[4096];
+    const u32 k = generic ? 0u : a.k;                  // generic: A/B knob (BFHIP_FFT_TILE12_GENERIC=1), same bytes
+    if (k == 12) fft_tile12_body<INV, 12>(a, bg, s_val, s_tw);
+    else if (k == 11) fft_tile12_body<INV, 11>(a, bg, s_val, s_tw);
+    else if (k == 10) fft_tile12_body<INV, 10>(a, bg, s_val, s_tw);
+    else if (k == 9) fft_tile12_body<INV, 9>(a, bg, s_val, s_tw);
+    else fft_tile12_body<INV, 0>(a, bg, s_val, s_tw);
 }
 
 // CL = log2 of the cells per row: 5 (128-byte rows, 128 lanes) or 6 (256-byte rows, 256 lanes: longer contiguous bursts per DRAM page at
@@ -421,7 +436,7 @@ __global__ void __launch_bounds__(4 << CL, 3) k_fft_strided7(const PassArgs* __r
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 u32 m = 8 * e + mlow;
-                if (to_global) __builtin_nontemporal_store((INV && a.scale != 1) ? m_mul(v[e], a.scale) : v[e], dst + (base | (m << lo) | l));   // streamed: +2 %
+                if (to_global) __builtin_nontemporal_store((INV && a.scale != 1) ? m_mul_pow2(v[e], scale_shift(a.scale)) : v[e], dst + (base | (m << lo) | l));   // streamed: +2 %
                 else s_val[C * m + l] = v[e];
             }
         };
@@ -526,7 +541,7 @@ __global__ void __launch_bounds__((1 << (K + CL)) / 32) k_fft_stridedK(const Pas
         for (u32 i = 0; i < 8; i++) {
             const u32 idx = 4 * (t + NT * i), m = idx >> CL, l = idx & (C - 1);
             uint4 v = *reinterpret_cast<uint4*>(&s_val[idx]);
-            if (INV && a.scale != 1) { v.x = m_mul(v.x, a.scale); v.y = m_mul(v.y, a.scale); v.z = m_mul(v.z, a.scale); v.w = m_mul(v.w, a.scale); }
+            if (INV && a.scale != 1) { const u32 sk = scale_shift(a.scale); v.x = m_mul_pow2(v.x, sk); v.y = m_mul_pow2(v.y, sk); v.z = m_mul_pow2(v.z, sk); v.w = m_mul_pow2(v.w, sk); }
             st16(dst + (base | (m << lo) | l), v);
         }
     }
@@ -695,8 +710,9 @@ void fft_run(hipStream_t stream, const FftPlan& plan) {
         switch (L.kind) {
             case K_TILE12: {
                 ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L.bytes, L.alg);
-                if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, g, L.ngroups);
-                else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, g, L.ngroups);
+                static const u32 generic = [] { const char* v = getenv("BFHIP_FFT_TILE12_GENERIC"); return (v && v[0] == '1') ? 1u : 0u; }();
+                if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
+                else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
                 break; }
             case K_STRIDED5: {
                 ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);

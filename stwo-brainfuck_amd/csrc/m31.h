@@ -50,6 +50,9 @@ BF_HD u32 m_mul_pre2(u32 a, u32 w2) {
     u64 p = (u64)a * w2;
     u32 s = (u32)(p >> 32) + ((u32)p >> 1); u32 t = s - P31; return t < s ? t : s;
 }
+// Product by 2^k, 0 <= k <= 30: 2^31 = 1 (mod p), so it is the rotation of the 31-bit word by k — shift, shift, and-or: 3 instructions where the
+// general product needs 6. a < 2^31; a canonical value (not all 31 bits set) stays canonical. The inverse transforms scale by 2^-n = 2^((31 - n % 31) % 31).
+BF_HD u32 m_mul_pow2(u32 a, u32 k) { return ((a << k) & P31) | (a >> (31u - k)); }
 BF_HD u32 m_sqr(u32 a) { return m_mul(a, a); }
 BF_HD u32 m_inv_pow2(u32 n) { return 1u << ((31u - n % 31u) % 31u); }   // 2^-n: 2^31 = 1 (mod P)
 BF_HD u32 m_pow(u32 b, u32 e) { u32 r = 1; while (e) { if (e & 1) r = m_mul(r, b); b = m_mul(b, b); e >>= 1; } return r; }

@@ -736,7 +736,7 @@ struct HipProver {
         BF_HIP(hipMemsetAsync(c.d_counters, 0, 4 * 64 * sizeof(u32), c.stream));      // ticket counters (a failed proof may have left one mid-count)
         BF_HIP(hipEventRecord(c.ev[0], c.stream));
         // In a shard group everything stays on the main stream: the group's exchanges are issued in one order on one stream per rank.
-        const bool use_side = !sharded();
+        const bool use_side = !sharded() && !c.single_stream;
         if (reuse) trees[0] = cache.tree;
         else {
             if (use_side) {

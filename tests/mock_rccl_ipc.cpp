@@ -4,16 +4,19 @@
  * of a shard group (unique-id hand-off over torch.distributed, RcclComm with device buffers, the same collective sequence in every process)
  * — real librccl refuses two ranks on one GPU.
  *
- *   rendezvous  a POSIX shared-memory segment named by the unique id (created by ncclGetUniqueId): a barrier, the ranks' op queues, pids.
- *   data path   device blocks travel by hipIpcGetMemHandle / hipIpcOpenMemHandle + a device-to-device copy on the receiver's stream;
- *               blocks that are not plain device allocations (pinned host aliases) and the small reduce go through a per-rank staging
- *               area inside the segment (hipMemcpy on both ends).
+ *   rendezvous  a POSIX shared-memory segment named by the unique id (created by ncclGetUniqueId): a barrier, per-round manifests, pids.
+ *   data path   every rank owns ONE device bounce buffer (64 MiB, hipMalloc), exported once with hipIpcGetMemHandle and opened by every peer at
+ *               communicator creation. A transfer is: sender copies a piece of its block into its bounce buffer (device to device), rendezvous,
+ *               receiver copies from the peer's mapped bounce buffer to its destination, rendezvous; blocks larger than the buffer take several
+ *               rounds. (The caller's own allocations are never exported: mapping a 2 GiB arena chunk of another process did not return on
+ *               this pool.) The small max-reduce goes through a host staging area inside the segment.
  *   semantics   SYNCHRONOUS: a collective first waits for the caller's stream, and returns after every rank has consumed the data. (RCCL
  *               enqueues a kernel and returns; the values that land in the buffers are the same.) Grouped point-to-point calls are matched
  *               per (sender, receiver) pair in issue order, as in the RCCL documentation.
  *   failures    every wait is bounded by BFHIP_COMM_TIMEOUT_S (the library's own setting) and watches the peers' pids: a rank that died makes
  *               the others return ncclInternalError (libbfhip: an error from the proof) instead of hanging.
- * Test infrastructure only: built by __graft_entry__.build() / tests with g++ against libamdhip64 into tests/libmock_rccl_ipc.so. */
+ * BFHIP_MOCK_RCCL_TRACE=1: one stderr line per collective and round. Test infrastructure only: built by __graft_entry__.build() / tests with g++
+ * against libamdhip64 into tests/libmock_rccl_ipc.so. */
 #include <hip/hip_runtime_api.h>
 #include <atomic>
 #include <cerrno>
@@ -24,7 +27,6 @@
 #include <cstring>
 #include <ctime>
 #include <fcntl.h>
-#include <map>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -36,36 +38,36 @@ enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInt
 typedef struct { char internal[128]; } ncclUniqueId;
 
 namespace {
-enum { MAX_RANKS = 16, MAX_OPS = 4096 };
-constexpr size_t STAGE_BYTES = size_t(32) << 20;      // per rank; only touched pages are ever backed by memory
-constexpr uint32_t MAGIC = 0x6d6f636bu;
+enum { MAX_RANKS = 16, MAX_SEGS = 4096 };
+constexpr size_t BOUNCE_BYTES = size_t(64) << 20;     // device memory per rank
+constexpr size_t STAGE_BYTES = size_t(32) << 20;      // host staging per rank (max-reduce); only touched pages are ever backed by memory
+constexpr uint32_t MAGIC = 0x6d6f636cu;
 
-struct Block {                    // how a receiver finds the bytes of one published block
-    int staged;                   // 1: at `off` inside the owner's staging area; 0: device memory behind an IPC handle
-    hipIpcMemHandle_t handle;
-    size_t off, bytes;
-};
-struct Op { int is_send, peer, used; Block b; void* recv_ptr; };
+// one piece of one send of this round: bytes [block_off, block_off + len) of the sender's pair_seq-th block to `peer` lie at bounce_off
+struct Seg { int peer, pair_seq; size_t block_bytes, block_off, len, bounce_off; };
 struct Shared {
     uint32_t magic; int n;
     std::atomic<int> joined, left, failed;
     std::atomic<uint32_t> bar_count, bar_gen;
     int pids[MAX_RANKS];
-    int n_ops[MAX_RANKS];
-    size_t stage_used[MAX_RANKS];
-    Block coll[MAX_RANKS];
-    Op ops[MAX_RANKS][MAX_OPS];
+    hipIpcMemHandle_t bounce[MAX_RANKS];
+    int n_segs[MAX_RANKS], more[MAX_RANKS];
+    int n_recv_from[MAX_RANKS][MAX_RANKS];            // [receiver][sender]: receives posted in the current group
+    Seg segs[MAX_RANKS][MAX_SEGS];
 };
 constexpr size_t HEADER_BYTES = (sizeof(Shared) + 4095) & ~size_t(4095);
 constexpr size_t SEGMENT_BYTES = HEADER_BYTES + MAX_RANKS * STAGE_BYTES;
 
 struct Comm {
     Shared* sh = nullptr; char* base = nullptr; int rank = 0; std::string name;
-    std::map<std::string, void*> opened;          // peers' allocations mapped into this process, by handle bytes
-    std::map<void*, hipIpcMemHandle_t> exported;  // my allocations, by base pointer
+    char* bounce = nullptr;                       // my device bounce buffer
+    char* peer_bounce[MAX_RANKS] = {};            // the peers' bounce buffers mapped into this process
     char* stage(int r) const { return base + HEADER_BYTES + size_t(r) * STAGE_BYTES; }
 };
+struct LocalOp { int is_send, peer; char* ptr; size_t bytes, done; };
 
+bool tracing() { static const bool on = getenv("BFHIP_MOCK_RCCL_TRACE") != nullptr; return on; }
+#define TRACE(...) do { if (tracing()) { fprintf(stderr, "mock_rccl_ipc[%d] ", (int)getpid()); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); fflush(stderr); } } while (0)
 double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 double timeout_s() { const char* v = getenv("BFHIP_COMM_TIMEOUT_S"); double x = v ? atof(v) : 0.0; return x > 0.0 ? x : 300.0; }
 bool alive(int pid) {
@@ -102,53 +104,21 @@ int barrier(Comm* c) {
 }
 #define HIPOK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "mock_rccl_ipc: %s -> %s\n", #expr, hipGetErrorString(e__)); return ncclUnhandledCudaError; } } while (0)
 
-// publishes one of MY blocks: device allocation -> IPC handle + offset; anything else -> copied into my staging area now
-ncclResult_t publish(Comm* c, const void* ptr, size_t bytes, Block* out) {
-    memset(out, 0, sizeof *out);
-    out->bytes = bytes;
-    if (!bytes) { out->staged = 1; return ncclSuccess; }
-    hipPointerAttribute_t at;
-    bool device = hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeDevice;
-    (void)hipGetLastError();
-    if (device && !getenv("BFHIP_MOCK_RCCL_STAGE_ALL")) {
-        void* b = nullptr; size_t sz = 0;
-        if (hipMemGetAddressRange((hipDeviceptr_t*)&b, &sz, (hipDeviceptr_t)ptr) == hipSuccess && b) {
-            auto it = c->exported.find(b);
-            if (it == c->exported.end()) {
-                hipIpcMemHandle_t h;
-                if (hipIpcGetMemHandle(&h, b) == hipSuccess) it = c->exported.emplace(b, h).first;
-                else (void)hipGetLastError();
-            }
-            if (it != c->exported.end()) { out->handle = it->second; out->off = (const char*)ptr - (const char*)b; return ncclSuccess; }
-        }
-        (void)hipGetLastError();
-    }
-    size_t& used = c->sh->stage_used[c->rank];
-    const size_t at_off = (used + 255) & ~size_t(255);
-    if (at_off + bytes > STAGE_BYTES) { fprintf(stderr, "mock_rccl_ipc: staging area exhausted (%zu bytes)\n", bytes); return ncclInternalError; }
-    HIPOK(hipMemcpy(c->stage(c->rank) + at_off, ptr, bytes, hipMemcpyDefault));
-    out->staged = 1; out->off = at_off; used = at_off + bytes;
-    return ncclSuccess;
-}
-// copies a block published by rank `owner` to dst (stream-ordered for device blocks; the caller synchronises)
-ncclResult_t fetch(Comm* c, int owner, const Block& b, void* dst, size_t skip, size_t bytes, hipStream_t s) {
-    if (!bytes) return ncclSuccess;
-    if (b.staged) { HIPOK(hipMemcpyAsync(dst, c->stage(owner) + b.off + skip, bytes, hipMemcpyDefault, s)); return ncclSuccess; }
-    std::string key((const char*)&b.handle, sizeof b.handle);
-    auto it = c->opened.find(key);
-    if (it == c->opened.end()) {
-        void* p = nullptr;
-        HIPOK(hipIpcOpenMemHandle(&p, b.handle, hipIpcMemLazyEnablePeerAccess));
-        it = c->opened.emplace(key, p).first;
-    }
-    HIPOK(hipMemcpyAsync(dst, (const char*)it->second + b.off + skip, bytes, hipMemcpyDeviceToDevice, s));
-    return ncclSuccess;
-}
-
 thread_local int t_in_group = 0;
 thread_local Comm* t_comm = nullptr;
 thread_local hipStream_t t_stream = nullptr;
+thread_local std::vector<LocalOp> t_ops;
 std::atomic<int> g_next_id{1};
+
+void release(Comm* c, bool orderly) {
+    for (int r = 0; r < MAX_RANKS; r++) if (c->peer_bounce[r]) (void)hipIpcCloseMemHandle(c->peer_bounce[r]);
+    if (orderly) (void)barrier(c);                 // every peer has unmapped my buffer before it is freed
+    if (c->bounce) (void)hipFree(c->bounce);
+    (void)hipGetLastError();
+    if (c->sh->left.fetch_add(1) + 1 >= c->sh->n) shm_unlink(c->name.c_str());      // the last one out removes the name
+    munmap(c->base, SEGMENT_BYTES);
+    delete c;
+}
 }  // namespace
 
 typedef Comm* ncclComm_t;
@@ -164,7 +134,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
     void* m = mmap(nullptr, HEADER_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
     if (m == MAP_FAILED) { shm_unlink(id->internal); return ncclSystemError; }
-    Shared* s = (Shared*)m;               // a fresh segment is zero filled: counters, queues and flags start at 0
+    Shared* s = (Shared*)m;               // a fresh segment is zero filled: counters, manifests and flags start at 0
     s->magic = MAGIC;
     munmap(m, HEADER_BYTES);
     return ncclSuccess;
@@ -183,40 +153,42 @@ ncclResult_t ncclCommInitRank(ncclComm_t* out, int n, ncclUniqueId id, int rank)
     if (s->magic != MAGIC) { munmap(m, SEGMENT_BYTES); return ncclInvalidArgument; }
     Comm* c = new Comm;
     c->sh = s; c->base = (char*)m; c->rank = rank; c->name = id.internal;
+    if (hipMalloc((void**)&c->bounce, BOUNCE_BYTES) != hipSuccess || hipIpcGetMemHandle(&s->bounce[rank], c->bounce) != hipSuccess) {
+        fprintf(stderr, "mock_rccl_ipc: bounce buffer: %s\n", hipGetErrorString(hipGetLastError()));
+        s->failed.store(1); munmap(m, SEGMENT_BYTES); delete c; return ncclUnhandledCudaError;
+    }
     if (rank == 0) s->n = n;
     s->pids[rank] = (int)getpid();
     s->joined.fetch_add(1);
     // like the real call: returns once every rank has joined (bounded: a rank that never shows up fails the group)
-    for (double t0 = now(); s->joined.load() < n; usleep(200)) if (now() - t0 > timeout_s() || s->failed.load()) { s->failed.store(1); munmap(m, SEGMENT_BYTES); delete c; return ncclInternalError; }
+    for (double t0 = now(); s->joined.load() < n; usleep(200)) if (now() - t0 > timeout_s() || s->failed.load()) { s->failed.store(1); release(c, false); return ncclInternalError; }
     while (s->n == 0) usleep(50);
-    if (s->n != n) { s->failed.store(1); munmap(m, SEGMENT_BYTES); delete c; return ncclInvalidArgument; }
+    if (s->n != n) { s->failed.store(1); release(c, false); return ncclInvalidArgument; }
+    if (barrier(c) != 0) { release(c, false); return ncclInternalError; }
+    for (int r = 0; r < n; r++) {
+        if (r == rank) continue;
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, s->bounce[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            fprintf(stderr, "mock_rccl_ipc: hipIpcOpenMemHandle of rank %d: %s\n", r, hipGetErrorString(hipGetLastError()));
+            s->failed.store(1); release(c, false); return ncclUnhandledCudaError;
+        }
+        c->peer_bounce[r] = (char*)p;
+    }
+    TRACE("rank %d of %d joined, bounce buffers mapped", rank, n);
     *out = c;
     return barrier(c) == 0 ? ncclSuccess : ncclInternalError;
 }
 
-static void release(Comm* c) {
-    for (auto& kv : c->opened) (void)hipIpcCloseMemHandle(kv.second);
-    (void)hipGetLastError();
-    if (c->sh->left.fetch_add(1) + 1 >= c->sh->n) shm_unlink(c->name.c_str());      // the last one out removes the name
-    munmap(c->base, SEGMENT_BYTES);
-    delete c;
-}
-ncclResult_t ncclCommDestroy(ncclComm_t c) { if (c) { (void)barrier(c); release(c); } return ncclSuccess; }
-ncclResult_t ncclCommAbort(ncclComm_t c) { if (c) { c->sh->failed.store(1); release(c); } return ncclSuccess; }
+ncclResult_t ncclCommDestroy(ncclComm_t c) { if (c) { (void)barrier(c); release(c, true); } return ncclSuccess; }
+ncclResult_t ncclCommAbort(ncclComm_t c) { if (c) { c->sh->failed.store(1); release(c, false); } return ncclSuccess; }
 ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t* st) { *st = (c && c->sh->failed.load()) ? ncclInternalError : ncclSuccess; return ncclSuccess; }
 
-ncclResult_t ncclGroupStart(void) { t_in_group = 1; t_comm = nullptr; t_stream = nullptr; return ncclSuccess; }
+ncclResult_t ncclGroupStart(void) { t_in_group = 1; t_comm = nullptr; t_stream = nullptr; t_ops.clear(); return ncclSuccess; }
 static ncclResult_t queue_op(int is_send, void* ptr, size_t count, int dt, int peer, ncclComm_t c, hipStream_t stream) {
     if (!t_in_group) return ncclInvalidUsage;     /* libbfhip always groups its point-to-point calls */
     if (dt != 1 /* ncclUint8 */ || peer < 0 || peer >= c->sh->n || peer == c->rank) return ncclInvalidArgument;
-    Shared* s = c->sh;
-    if (!t_comm) { HIPOK(hipStreamSynchronize(stream)); s->stage_used[c->rank] = 0; }     // first op of the group: my buffers are final
-    if (s->n_ops[c->rank] == MAX_OPS) return ncclInternalError;
-    Op& op = s->ops[c->rank][s->n_ops[c->rank]];
-    memset(&op, 0, sizeof op);
-    op.is_send = is_send; op.peer = peer; op.recv_ptr = ptr; op.b.bytes = count;
-    if (is_send) { ncclResult_t r = publish(c, ptr, count, &op.b); if (r != ncclSuccess) return r; }
-    s->n_ops[c->rank]++;
+    if (t_comm && t_comm != c) return ncclInvalidUsage;
+    t_ops.push_back(LocalOp{is_send, peer, (char*)ptr, count, 0});
     t_comm = c; t_stream = stream;
     return ncclSuccess;
 }
@@ -227,46 +199,79 @@ ncclResult_t ncclGroupEnd(void) {
     Comm* c = t_comm;
     if (!c) return ncclSuccess;                   /* an empty group: nothing was queued on this rank (all ranks must agree) */
     Shared* s = c->sh;
+    hipStream_t stream = t_stream;
     ncclResult_t rc = ncclSuccess;
-    if (barrier(c) != 0) return ncclInternalError;          /* every rank has posted its queue */
-    for (int k = 0; k < s->n_ops[c->rank]; k++) {
-        Op* r = &s->ops[c->rank][k];
-        if (r->is_send) continue;
-        Op* snd = nullptr;
-        for (int j = 0; j < s->n_ops[r->peer] && !snd; j++) {
-            Op* q = &s->ops[r->peer][j];
-            if (q->is_send && q->peer == c->rank && !q->used) snd = q;
-        }
-        if (!snd || snd->b.bytes != r->b.bytes) { rc = ncclInvalidUsage; if (snd) snd->used = 1; continue; }
-        snd->used = 1;
-        ncclResult_t f = fetch(c, r->peer, snd->b, r->recv_ptr, 0, r->b.bytes, t_stream);
-        if (f != ncclSuccess) rc = f;
+    TRACE("group: %zu ops, waiting for the stream", t_ops.size());
+    HIPOK(hipStreamSynchronize(stream));         /* my send buffers are final */
+    std::vector<LocalOp*> sends, recvs[MAX_RANKS];
+    std::vector<int> send_seq;
+    int n_send_to[MAX_RANKS] = {};
+    for (auto& op : t_ops) {
+        if (op.is_send) { sends.push_back(&op); send_seq.push_back(n_send_to[op.peer]++); }
+        else recvs[op.peer].push_back(&op);
     }
-    if (hipStreamSynchronize(t_stream) != hipSuccess) rc = ncclUnhandledCudaError;
-    if (barrier(c) != 0) return ncclInternalError;          /* every rank has consumed what was sent to it */
-    for (int k = 0; k < s->n_ops[c->rank]; k++) if (s->ops[c->rank][k].is_send && !s->ops[c->rank][k].used) rc = ncclInvalidUsage;   /* a send nobody received */
-    s->n_ops[c->rank] = 0;
-    if (barrier(c) != 0) return ncclInternalError;
+    for (int p = 0; p < s->n; p++) s->n_recv_from[c->rank][p] = (int)recvs[p].size();
+    size_t i = 0, off = 0;
+    for (int round = 0;; round++) {
+        /* pack as much of my pending sends as fits into my bounce buffer */
+        size_t used = 0; int n_segs = 0;
+        while (i < sends.size() && n_segs < MAX_SEGS) {
+            const size_t at = (used + 255) & ~size_t(255);
+            if (at >= BOUNCE_BYTES) break;
+            const size_t len = sends[i]->bytes - off < BOUNCE_BYTES - at ? sends[i]->bytes - off : BOUNCE_BYTES - at;
+            if (len) HIPOK(hipMemcpyAsync(c->bounce + at, sends[i]->ptr + off, len, hipMemcpyDefault, stream));
+            s->segs[c->rank][n_segs++] = Seg{sends[i]->peer, send_seq[i], sends[i]->bytes, off, len, at};
+            used = at + len; off += len;
+            if (off == sends[i]->bytes) { i++; off = 0; }
+        }
+        HIPOK(hipStreamSynchronize(stream));
+        s->n_segs[c->rank] = n_segs;
+        s->more[c->rank] = i < sends.size() ? 1 : 0;
+        if (barrier(c) != 0) return ncclInternalError;      /* every rank has published its round */
+        if (round == 0)
+            for (int p = 0; p < s->n; p++) if (p != c->rank && s->n_recv_from[p][c->rank] != n_send_to[p]) rc = ncclInvalidUsage;      /* a send nobody receives / a receive nobody sends */
+        for (int p = 0; p < s->n; p++) {
+            if (p == c->rank) continue;
+            for (int k = 0; k < s->n_segs[p]; k++) {
+                const Seg& g = s->segs[p][k];
+                if (g.peer != c->rank) continue;
+                if (g.pair_seq >= (int)recvs[p].size() || recvs[p][g.pair_seq]->bytes != g.block_bytes) { rc = ncclInvalidUsage; continue; }
+                LocalOp* r = recvs[p][g.pair_seq];
+                if (g.len) HIPOK(hipMemcpyAsync(r->ptr + g.block_off, c->peer_bounce[p] + g.bounce_off, g.len, hipMemcpyDeviceToDevice, stream));
+                r->done += g.len;
+            }
+        }
+        HIPOK(hipStreamSynchronize(stream));
+        int any_more = 0;
+        for (int p = 0; p < s->n; p++) any_more |= s->more[p];
+        TRACE("group round %d: sent %zu bytes in %d pieces, more rounds: %d", round, used, n_segs, any_more);
+        if (barrier(c) != 0) return ncclInternalError;      /* every rank has consumed the round: the bounce buffers may be overwritten */
+        if (!any_more) break;
+    }
+    for (int p = 0; p < s->n; p++) for (auto* r : recvs[p]) if (r->done != r->bytes) rc = ncclInvalidUsage;
+    t_ops.clear();
     return rc;
 }
 
 ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, int dt, ncclComm_t c, hipStream_t stream) {
     if (dt != 1) return ncclInvalidArgument;
     Shared* s = c->sh;
+    TRACE("all-gather %zu bytes per rank", count);
     HIPOK(hipStreamSynchronize(stream));
-    s->stage_used[c->rank] = 0;
-    ncclResult_t rc = publish(c, send, count, &s->coll[c->rank]);
-    if (rc != ncclSuccess) { s->failed.store(1); return rc; }
-    if (barrier(c) != 0) return ncclInternalError;
-    for (int r = 0; r < s->n; r++) {
-        char* dst = (char*)recv + (size_t)r * count;
-        if (r == c->rank && dst == (const char*)send) continue;       /* in place: my block already lies where it belongs */
-        ncclResult_t f = fetch(c, r, s->coll[r], dst, 0, count, stream);
-        if (f != ncclSuccess) rc = f;
+    char* mine = (char*)recv + (size_t)c->rank * count;
+    if (mine != (const char*)send && count) HIPOK(hipMemcpyAsync(mine, send, count, hipMemcpyDefault, stream));      /* not in place */
+    for (size_t off = 0; off < count || off == 0; off += BOUNCE_BYTES) {
+        const size_t len = count - off < BOUNCE_BYTES ? count - off : BOUNCE_BYTES;
+        if (len) HIPOK(hipMemcpyAsync(c->bounce, (const char*)send + off, len, hipMemcpyDefault, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        if (barrier(c) != 0) return ncclInternalError;
+        for (int r = 0; r < s->n; r++)
+            if (r != c->rank && len) HIPOK(hipMemcpyAsync((char*)recv + (size_t)r * count + off, c->peer_bounce[r], len, hipMemcpyDeviceToDevice, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        if (barrier(c) != 0) return ncclInternalError;
+        if (count == 0) break;
     }
-    if (hipStreamSynchronize(stream) != hipSuccess) rc = ncclUnhandledCudaError;
-    if (barrier(c) != 0) return ncclInternalError;
-    return rc;
+    return ncclSuccess;
 }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dt, int op, ncclComm_t c, hipStream_t stream) {
@@ -274,6 +279,7 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, int dt, i
     Shared* s = c->sh;
     const size_t bytes = count * 4;
     if (bytes > STAGE_BYTES) return ncclInternalError;
+    TRACE("max-reduce %zu words", count);
     HIPOK(hipStreamSynchronize(stream));
     HIPOK(hipMemcpy(c->stage(c->rank), send, bytes, hipMemcpyDefault));      /* the reduce is taken on the host over the ranks' staged inputs */
     if (barrier(c) != 0) return ncclInternalError;

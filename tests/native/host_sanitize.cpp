@@ -40,6 +40,8 @@ int main(int argc, char** argv) {
             auto check = [&](u32 a, u32 w) {
                 const u32 want = (u32)(((unsigned __int128)a * w) % P31);
                 if (m_mul(a, w) != want || m_mul_pre2(a, 2u * w) != want) { printf("mismatch a=%u w=%u\n", a, w); exit(1); }
+                // the product by a power of two as a 31-bit rotation (the inverse transforms' scaling by 2^-n, r05) against 128-bit arithmetic
+                { const u32 k = w % 31u; if (m_mul_pow2(a, k) != (u32)((((unsigned __int128)a) << k) % P31)) { printf("m_mul_pow2 mismatch a=%u k=%u\n", a, k); exit(1); } }
                 if (m_add(a, w) != (u32)(((u64)a + w) % P31) || m_sub(a, w) != (u32)(((u64)a + P31 - w) % P31)) { printf("add/sub mismatch a=%u w=%u\n", a, w); exit(1); }
                 checked++;
             };

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the measurement artefacts of a round on the GPU box (run through gpurun from the repository root):
-#   gpurun -- 'bash tools/profile_round.sh r04 [part ...]'      parts: bench trace pmc clock fft poseidon shard latency misc   (default: all)
+#   gpurun -- 'bash tools/profile_round.sh r04 [part ...]'      parts: bench roofline trace inflight pmc clock fft poseidon shard latency misc   (default: all)
 # Writes into gpurun_out/<round>/ ; copy what should be judged into profiles/.
 set -u
 R=${1:-r04}; shift || true
-PARTS=${*:-bench trace pmc clock fft poseidon shard latency misc}
+PARTS=${*:-bench roofline trace inflight pmc clock fft poseidon shard latency misc}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p "$OUT"
@@ -22,6 +22,30 @@ python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.
 rm -rf /tmp/prof_stats; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon > "$OUT/bench_under_rocprof.log" 2>&1
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
+fi
+
+if has roofline; then
+# 2a. the headline roofline, reproducible: the SAME command (20 steps, 5 warm-up, nothing else) un-profiled and under rocprofv3 --kernel-trace --stats, on ONE
+#     stream (BFHIP_SINGLE_STREAM=1: the preprocessed tree's Blake2s does not co-run with the main-trace transforms, so a launch's duration does not
+#     depend on how the profiler lets two queues share the GPU) and, beside it, with the default two streams. tools/recompute_from_profiles.py reads them.
+for ss in 1 0; do
+  tag=$([ $ss = 1 ] && echo single_stream || echo two_streams)
+  BFHIP_SINGLE_STREAM=$ss python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-sweep --no-poseidon --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > "$OUT/${R}_roofline_${tag}_events.json"
+  rm -rf /tmp/prof_rf; BFHIP_SINGLE_STREAM=$ss $RP --kernel-trace --stats --output-format csv -d /tmp/prof_rf -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-sweep --no-poseidon --no-cpu-baseline > "$OUT/roofline_${tag}_under_rocprof.log" 2>&1
+  grep '^{"metric"' "$OUT/roofline_${tag}_under_rocprof.log" | tail -1 > "$OUT/${R}_roofline_${tag}_under_rocprof.json"
+  cp $(ls /tmp/prof_rf/*/*kernel_stats.csv | head -1) "$OUT/${R}_roofline_${tag}_kernel_stats.csv"
+  python3 "$ROOT/tools/merkle_launches.py" $(kt /tmp/prof_rf) > "$OUT/${R}_roofline_${tag}_merkle_launches.txt" 2>&1
+done
+fi
+
+if has inflight; then
+# 2c. proofs in flight at the metric's own size: un-profiled ms per proof for 1 / 2 / 3 in flight, then the kernel trace of 2 in flight: how much of the
+#     time launches of BOTH queues are in flight (one proof's single-workgroup chains under the other's kernels)
+for w in 22 20 fib19; do for k in 1 2 3; do python3 "$ROOT/tools/inflight_profile.py" $w $k --rounds 8; done; done > "$OUT/${R}_inflight.jsonl" 2>/dev/null
+for k in 1 2; do
+  rm -rf /tmp/prof_if; $RP --kernel-trace --output-format csv -d /tmp/prof_if -- python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 6 > "$OUT/inflight${k}_under_rocprof.json" 2>/dev/null
+  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_if) --window 0.35:0.80 > "$OUT/${R}_2p22_inflight${k}_timeline_gaps.txt" 2>&1
+done
 fi
 
 if has trace; then

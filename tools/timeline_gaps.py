@@ -1,18 +1,56 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 --kernel-trace CSV (…_kernel_trace.csv) and reports, for the LAST proof in the trace, the GPU busy fraction and
-the largest idle gaps between consecutive kernels (with the kernels on either side). A k_mailbox launch (waiting for the host) counts as idle. Usage: timeline_gaps.py <kernel_trace.csv> [n_gaps]"""
+the largest idle gaps between consecutive kernels (with the kernels on either side). A k_mailbox launch (waiting for the host) counts as idle. Usage: timeline_gaps.py <kernel_trace.csv> [n_gaps]
+--window A:B  (fractions of the trace's span, e.g. 0.45:0.85) instead of the last proof: every queue's launches inside that window — for k proofs in
+flight (tools/inflight_profile.py): busy fraction, the share of the time with launches of two or more QUEUES in flight (one proof's latency chain
+under another proof's kernels), proofs started in the window."""
 import csv
 import sys
 
 
 def main():
     path = sys.argv[1]
-    n_gaps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-    rows = []
+    window = None
+    argv = list(sys.argv[2:])
+    if "--window" in argv:
+        i = argv.index("--window"); a, b = argv[i + 1].split(":"); window = (float(a), float(b)); del argv[i:i + 2]
+    n_gaps = int(argv[0]) if argv else 25
+    rows, queues = [], []
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bf::", "")))
+            queues.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), rows[-1][2]))
     rows.sort()
+    if window:
+        lo_t, hi_t = rows[0][0], max(r[1] for r in rows)
+        w0, w1 = lo_t + window[0] * (hi_t - lo_t), lo_t + window[1] * (hi_t - lo_t)
+        inside = sorted(q for q in queues if q[0] >= w0 and q[1] <= w1 and not q[3].startswith("k_mailbox"))
+        # sweep over start/end events: time with >= 1 launch in flight, and with launches of >= 2 different queues in flight
+        ev = []
+        for s_, e_, q, _ in inside:
+            ev.append((s_, 1, q)); ev.append((e_, -1, q))
+        ev.sort()
+        active, busy, multi, last = {}, 0, 0, None
+        for t, d, q in ev:
+            if last is not None:
+                nq = sum(1 for v in active.values() if v > 0)
+                if nq >= 1: busy += t - last
+                if nq >= 2: multi += t - last
+            active[q] = active.get(q, 0) + d
+            last = t
+        span = w1 - w0
+        starts = sum(1 for i, q in enumerate(inside) if q[3].startswith("k_is_first_coeffs"))
+        per_q = {}
+        for s_, e_, q, _ in inside:
+            per_q.setdefault(q, [0, 0]); per_q[q][0] += 1; per_q[q][1] += e_ - s_
+        print(f"window {window[0]:.2f}..{window[1]:.2f} of the trace: {span/1e6:.3f} ms, {len(inside)} launches on {len(per_q)} queues, {starts} proofs started")
+        print(f"busy (>= 1 launch in flight) {busy/1e6:.3f} ms = {100.0*busy/span:.1f} %   idle {(span-busy)/1e6:.3f} ms")
+        print(f"launches of >= 2 queues in flight {multi/1e6:.3f} ms = {100.0*multi/span:.1f} % of the window (one proof's chains under another's kernels)")
+        if starts:
+            print(f"window / proofs started = {span/1e6/starts:.3f} ms per proof")
+        for q, (n, tot) in sorted(per_q.items(), key=lambda kv: -kv[1][1]):
+            print(f"  queue {q}: {n} launches, {tot/1e6:.3f} ms of kernel time")
+        return
     # k_mailbox (csrc/mailbox.hip) is one workgroup waiting for the host's flag: its duration is idle time of the GPU, not work — it is reported
     # as a gap in front of the kernel that follows it (the few microseconds of its table copy are counted as idle too)
     mailbox = [r for r in rows if r[2].startswith("k_mailbox")]
