@@ -816,6 +816,7 @@ def main():
     ap.add_argument("--probe-timeout", type=int, default=240)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
+    ap.add_argument("--pipelined-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-out", help=argparse.SUPPRESS)
@@ -823,6 +824,11 @@ def main():
     args = ap.parse_args()
     if args.shard_probe:
         return shard_probe(args)
+    if args.pipelined_child:
+        # child-process mode: the proofs-in-flight measurement in a process of its own (see the call site)
+        pkg = load_package()
+        print(json.dumps(run_pipelined(pkg, pick_device(0, pkg.device_count(), args.device), args)), flush=True)
+        return 0
 
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
         # no launcher started the ranks: do it here, before anything in this process touches the GPU (children are fresh processes)
@@ -849,6 +855,23 @@ def main():
             shard_probe_result = run_shard_probe(args, rank, world)
         except Exception as e:
             shard_probe_result = {"n_gpus": world, "error": repr(e)}
+
+    # ---- N = 1: proofs in flight (fresh contexts, one host thread + stream each): the single-workgroup latency chains and host points of one
+    # proof are filled by another proof's kernels. {fib19, 2^22 rows (the metric's size), 2^20 rows} x {1, 2, 3 in flight}, SHA-256 per proof.
+    # Reported beside `value`, never as it: one call = one proof (mod.rs:471-735); batching is the caller's.
+    # In a process of its own, started BEFORE this one touches the GPU: HIP maps streams onto a few hardware queues, and with this process's
+    # own context alive (four streams) the main streams of two more contexts can share a queue and serialise — measured on one box: 2 in flight at
+    # 2^22 rows gain 2 % inside this process, 12 % in a fresh one (the deployment's situation: one context per proof in flight).
+    pipelined_early = None
+    if world == 1 and args.inflight == 1 and not args.no_sweep:
+        import subprocess
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--pipelined-child", "--log-max-rows", str(args.log_max_rows)] + (["--device", str(args.device)] if args.device is not None else [])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+            pipelined_early = json.loads(line) if line else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+        except Exception as e:
+            pipelined_early = {"error": repr(e)}
 
     import torch
     dist = None
@@ -1111,15 +1134,8 @@ def main():
                 # multi-level kernels of the small end (k_merkle_subtree, k_merkle_top, k_fri_layer, k_fri_tail)
                 roofline["compressions_per_proof_all_merkle_kernels"] = round(sum(v.get("units", 0) for k, v in full.items() if k in ("k_merkle_layer", "k_merkle_subtree", "k_merkle_top", "k_fri_tail", "k_fri_layer")))
 
-    # ---- N = 1: proofs in flight (fresh contexts, one host thread + stream each): the single-workgroup latency chains and host points of one
-    # proof are filled by another proof's kernels. {fib19, 2^22 rows (the metric's size), 2^20 rows} x {2, 3 in flight}, SHA-256 per proof.
-    # Reported beside `value`, never as it: one call = one proof (mod.rs:471-735); batching is the caller's.
-    pipelined = None
-    if world == 1 and args.inflight == 1 and not args.no_sweep:
-        try:
-            pipelined = run_pipelined(pkg, device, args)
-        except Exception as e:
-            pipelined = {"error": repr(e)}
+    # ---- N = 1: proofs in flight: measured in a CHILD process started before this one touched the GPU (pipelined_early below) --------------------
+    pipelined = pipelined_early
 
     sweep = None
     if world == 1 and not args.no_sweep and rank == 0:

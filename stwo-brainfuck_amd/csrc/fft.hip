@@ -220,6 +220,11 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __rest
 // LDS index padding p(i) = i + 4*(i >> 6) keeps the stride-4 round conflict-free and the 16-byte accesses aligned.
 // ---------------------------------------------------------------------------------------------------------------------
 // t2 = TWICE the twiddle (the kernels below stage their twiddles doubled in LDS, once per workgroup and batch of columns): m31.h m_mul_pre2
+// 11 VALU per butterfly (product 5, a + t 3, a - t 3), and no lazily reduced form is shorter in 32-bit lanes (r05): p = 2^31 - 1
+// leaves one spare bit, so (i) m_mul_pre2 needs its multiplicand < 2^31 — for b < 2^32 the fold high + (low >> 1) of b * 2w can reach
+// 2^32 + 2^31 and loses the carry —, (ii) a lazy sum a + t <= 2p may be added to once more at most (3p > 2^32) while half of a layer's outputs are the
+// next layer's multiplicands, and (iii) folding the addition into the multiply-add (b * 2w + 2a in 64 bits) saves an add but costs a second
+// v_mad_u64_u32 (1.6 issue slots) for the subtracted output.
 template <bool INV> __device__ __forceinline__ void bfly(u32& x, u32& y, u32 t2) {
     if (INV) { u32 s = m_add(x, y); y = m_mul_pre2(m_sub(x, y), t2); x = s; }
     else { u32 w = m_mul_pre2(y, t2); y = m_sub(x, w); x = m_add(x, w); }
