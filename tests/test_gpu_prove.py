@@ -440,7 +440,15 @@ def test_bench_line_contract(tmp_path):
     assert d["config"]["headline_2^22"]["cells_per_s"] > 0 and all(len(p["proof_sha256"]) == 64 for p in d["sweep"])
     assert d["poseidon252"]["verified"] is True and d["poseidon252"]["conventions"] == [0, 0, 0, 1] and d["poseidon252"]["log_domain_rows"] == 20
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    assert cb["kind"] in ("port-simd", "port") and cb["value"] > 0 and "sample" in cb
+    assert cb["cores"] == cb["cores_effective"] >= 1 and cb["threads"] <= max(cb["cores_effective"], 1) and "gpu_over_port" not in cb      # effective cores, no ratio against the scalar port
+    # r05: both roofline fractions ride in the line (frac_rocprof is null with its reason when the committed summary is stale), proofs in flight at three sizes
+    assert "frac_rocprof" in rf and "frac_rocprof_source" in rf and len(rf["kernel_sources_sha256"]) == 64
+    pl = d["pipelined"]
+    for w in ("fib19", "2^22_rows", "2^20_rows"):
+        assert pl[w]["in_flight_2"]["same_proof_as_1"] and pl[w]["in_flight_3"]["all_same_proof"] and pl[w]["in_flight_1"]["ms_per_proof"] > 0, pl[w]
+    assert d["metric_point"]["pipelined"]["in_flight_2"]["ms_per_proof"] > 0
+    assert "2^22 rows" in d["config"]["workload"] and "fib19" in d["config"]["workload"]
 
 
 def test_prove_entries_reject_null_arguments(pkg, ctx):
