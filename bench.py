@@ -664,49 +664,68 @@ class pinned_host_thread:
         return False
 
 
-def run_pipelined(pkg, device, args, rounds=6):
+PIPELINED_WORK = [("fib19", None, None), ("2^22_rows", 22, 22), ("2^20_rows", 20, 20)]      # (name, sweep log or None = the bench workload, LOG_MAX_ROWS or None = --log-max-rows)
+
+
+def run_pipelined_one(pkg, device, code, lmr, k, rounds=6):
     """k proofs in flight on one GPU: k FRESH contexts (stream, arena, staging ring each), one host thread each proving `rounds` proofs back to back.
-    Per workload: the one-in-flight time on a fresh context (the reference of the gain, measured the same way), then 2 and 3 in flight."""
+    Runs in a process of its own (one configuration per process: see run_pipelined)."""
     import threading
-    work = [("fib19", FIB19, args.log_max_rows), ("2^22_rows", sweep_program(22), 22), ("2^20_rows", sweep_program(20), 20)]
-    out = {"what": "k proofs in flight per GPU = k contexts + k host threads; ms_per_proof = wall time / proofs completed", "rounds_per_context": rounds}
-    for name, code, lmr in work:
-        row = {"log_max_rows": lmr}
-        for k in (1, 2, 3):
-            ctxs = [pkg.Context(device, max_log_domain=lmr + 2) for _ in range(k)]
-            traces = [pkg.Trace(c, code, b"") for c in ctxs]
-            shas, errs = [None] * k, []
+    ctxs = [pkg.Context(device, max_log_domain=lmr + 2) for _ in range(k)]
+    traces = [pkg.Trace(c, code, b"") for c in ctxs]
+    shas, errs = [None] * k, []
+    try:
+        def run(i, n, keep):
             try:
-                def run(i, n, keep):
-                    try:
-                        for _ in range(n):
-                            proof, _ = traces[i].prove(lmr, want_json=keep)
-                        if keep:
-                            shas[i] = hashlib.sha256(proof).hexdigest()
-                    except Exception as e:
-                        errs.append(repr(e))
-                def wave(n, keep):
-                    th = [threading.Thread(target=run, args=(i, n, keep)) for i in range(k)]
-                    [t.start() for t in th]; [t.join() for t in th]
-                    for c in ctxs:
-                        c.sync()
-                wave(2, False)                                   # warm-up (arena growth, first-proof setup)
-                t0 = time.perf_counter(); wave(rounds, False); dt = time.perf_counter() - t0
-                wave(1, True)                                    # the bytes: one more proof per context with the JSON kept
-                if errs:
-                    raise RuntimeError("; ".join(errs))
-                ms = dt / (rounds * k) * 1e3
-                row[f"in_flight_{k}"] = {"ms_per_proof": round(ms, 3), "cells_per_s": traces[0].cells / (ms * 1e-3), "proof_sha256": shas,
-                                         "all_same_proof": len(set(shas)) == 1}
-            finally:
-                for t in traces:
-                    t.close()
-                for c in ctxs:
-                    c.close()
-        base = row["in_flight_1"]["ms_per_proof"]
+                for _ in range(n):
+                    proof, _ = traces[i].prove(lmr, want_json=keep)
+                if keep:
+                    shas[i] = hashlib.sha256(proof).hexdigest()
+            except Exception as e:
+                errs.append(repr(e))
+
+        def wave(n, keep):
+            th = [threading.Thread(target=run, args=(i, n, keep)) for i in range(k)]
+            [t.start() for t in th]; [t.join() for t in th]
+            for c in ctxs:
+                c.sync()
+        wave(2, False)                                   # warm-up (arena growth, first-proof setup)
+        t0 = time.perf_counter(); wave(rounds, False); dt = time.perf_counter() - t0
+        wave(1, True)                                    # the bytes: one more proof per context with the JSON kept
+        if errs:
+            raise RuntimeError("; ".join(errs))
+        ms = dt / (rounds * k) * 1e3
+        return {"ms_per_proof": round(ms, 3), "cells_per_s": traces[0].cells / (ms * 1e-3), "proof_sha256": shas, "all_same_proof": len(set(shas)) == 1}
+    finally:
+        for t in traces:
+            t.close()
+        for c in ctxs:
+            c.close()
+
+
+def run_pipelined(args, rounds=6):
+    """{fib19, 2^22 rows, 2^20 rows} x {1, 2, 3 proofs in flight}, every configuration in a CHILD PROCESS of its own, started before this process
+    touches the GPU. Why a fresh process per configuration: HIP multiplexes streams onto a few hardware queues in creation order, and contexts that
+    came before (this process's own, or earlier configurations' — even closed ones) shift the assignment so that the main streams of two contexts
+    can share a queue and serialise: measured on one box, 2 in flight at 2^22 rows gain 2-3 % inside a process with history and 12 % in a fresh one,
+    which is the deployment's situation (one long-lived context per proof in flight)."""
+    import subprocess
+    out = {"what": "k proofs in flight per GPU = k contexts + k host threads in a fresh process; ms_per_proof = wall time / proofs completed", "rounds_per_context": rounds}
+    for name, _, _ in PIPELINED_WORK:
+        row = {}
+        for k in (1, 2, 3):
+            cmd = [sys.executable, os.path.abspath(__file__), "--pipelined-child", f"{name}:{k}:{rounds}", "--log-max-rows", str(args.log_max_rows)] + (["--device", str(args.device)] if args.device is not None else [])
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+                row[f"in_flight_{k}"] = json.loads(line) if line else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+            except Exception as e:
+                row[f"in_flight_{k}"] = {"error": repr(e)}
+        base = row["in_flight_1"]
         for k in (2, 3):
-            row[f"in_flight_{k}"]["gain_vs_1"] = round(base / row[f"in_flight_{k}"]["ms_per_proof"], 3)
-            row[f"in_flight_{k}"]["same_proof_as_1"] = row[f"in_flight_{k}"]["proof_sha256"][0] == row["in_flight_1"]["proof_sha256"][0]
+            if "ms_per_proof" in base and "ms_per_proof" in row[f"in_flight_{k}"]:
+                row[f"in_flight_{k}"]["gain_vs_1"] = round(base["ms_per_proof"] / row[f"in_flight_{k}"]["ms_per_proof"], 3)
+                row[f"in_flight_{k}"]["same_proof_as_1"] = row[f"in_flight_{k}"]["proof_sha256"][0] == base["proof_sha256"][0]
         out[name] = row
     return out
 
@@ -806,7 +825,8 @@ def main():
     ap.add_argument("--replicas", action="store_true", help="N > 1: headline = N independent proofs (weak scaling) instead of ONE proof over the shard group (strong scaling, default)")
     ap.add_argument("--no-extra-stages", action="store_true", help="N > 1: only the headline workload over the group, not the 2^24-row synthetic trace (configs 3/4) and the 2^26-row "
                     "Poseidon252 trace (config 5)")
-    ap.add_argument("--n1-steps", type=int, default=3, help="N > 1: proofs each rank times ALONE on its GPU before the group forms (what speedup_vs_n1 divides by)")
+    ap.add_argument("--group-timeout", type=int, default=900, help="N > 1: seconds the shard group's part (join, timed proofs, extra stages) may take; after that rank 0 prints the replicas "
+                    "line measured before the group formed and every rank leaves (a collective that never returns cannot be interrupted)")
     ap.add_argument("--rccl-child-probe", action="store_true", help="N > 1: also run the group stages in child processes (one per rank, RCCL) before the ranks touch their GPUs — "
                     "the pre-round-5 way, kept for debugging a transport that takes the main process down")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
@@ -816,7 +836,7 @@ def main():
     ap.add_argument("--probe-timeout", type=int, default=240)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
-    ap.add_argument("--pipelined-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pipelined-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--probe-out", help=argparse.SUPPRESS)
@@ -825,9 +845,12 @@ def main():
     if args.shard_probe:
         return shard_probe(args)
     if args.pipelined_child:
-        # child-process mode: the proofs-in-flight measurement in a process of its own (see the call site)
+        # child-process mode: ONE proofs-in-flight configuration "name:k:rounds" in a process of its own (run_pipelined)
+        name, k, rounds = args.pipelined_child.split(":")
+        _, sweep_log, lmr = next(w for w in PIPELINED_WORK if w[0] == name)
         pkg = load_package()
-        print(json.dumps(run_pipelined(pkg, pick_device(0, pkg.device_count(), args.device), args)), flush=True)
+        code, lmr = (FIB19, args.log_max_rows) if sweep_log is None else (sweep_program(sweep_log), lmr)
+        print(json.dumps(run_pipelined_one(pkg, pick_device(0, pkg.device_count(), args.device), code, lmr, int(k), int(rounds))), flush=True)
         return 0
 
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
@@ -859,17 +882,11 @@ def main():
     # ---- N = 1: proofs in flight (fresh contexts, one host thread + stream each): the single-workgroup latency chains and host points of one
     # proof are filled by another proof's kernels. {fib19, 2^22 rows (the metric's size), 2^20 rows} x {1, 2, 3 in flight}, SHA-256 per proof.
     # Reported beside `value`, never as it: one call = one proof (mod.rs:471-735); batching is the caller's.
-    # In a process of its own, started BEFORE this one touches the GPU: HIP maps streams onto a few hardware queues, and with this process's
-    # own context alive (four streams) the main streams of two more contexts can share a queue and serialise — measured on one box: 2 in flight at
-    # 2^22 rows gain 2 % inside this process, 12 % in a fresh one (the deployment's situation: one context per proof in flight).
+    # In child processes started BEFORE this one touches the GPU (run_pipelined says why).
     pipelined_early = None
     if world == 1 and args.inflight == 1 and not args.no_sweep:
-        import subprocess
         try:
-            cmd = [sys.executable, os.path.abspath(__file__), "--pipelined-child", "--log-max-rows", str(args.log_max_rows)] + (["--device", str(args.device)] if args.device is not None else [])
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
-            pipelined_early = json.loads(line) if line else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
+            pipelined_early = run_pipelined(args)
         except Exception as e:
             pipelined_early = {"error": repr(e)}
 
@@ -953,30 +970,6 @@ def main():
     if sharded and args.inflight > 1:
         raise SystemExit("a shard group proves one trace at a time: --inflight needs --replicas (or one GPU)")
     shard_error, n1 = None, None
-    if sharded:
-        # the same proof by ONE GPU alone, every rank on its own GPU at the same time, right before the group forms: what speedup_vs_n1 divides by
-        note("one-GPU reference proofs")
-        trace.prove(args.log_max_rows); ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(max(1, args.n1_steps)):
-            p1, _ = trace.prove(args.log_max_rows)
-        ctx.sync()
-        n1 = {"ms_per_proof": over_ranks((time.perf_counter() - t0) / max(1, args.n1_steps), "max") * 1e3, "proof_sha256": hashlib.sha256(p1).hexdigest(),
-              "steps": max(1, args.n1_steps), "note": "every rank alone on its own GPU at the same time; the slowest rank's time"}
-        note(f"one-GPU reference {n1['ms_per_proof']:.2f} ms; joining the shard group")
-        try:
-            join_group(ctx)
-            ok = True
-            note("joined: " + ctx.group_info()[2])
-        except Exception as e:
-            ok, shard_error = False, f"joining the shard group failed on rank {rank}: {e!r}"
-        if not agree(ok):
-            shard_error = shard_error or "joining the shard group failed on another rank"
-            try:
-                ctx.leave_group()
-            except Exception:
-                pass
-            sharded = False
 
     def sync():
         ctx.sync()
@@ -996,6 +989,57 @@ def main():
 
     pin = lambda: pinned_host_thread(args.pin and args.inflight == 1, device, local_rank, world)      # noqa: E731
     group = None
+    replica_line, watchdog = None, None
+    if sharded:
+        # ---- first the N independent proofs, one per GPU, under the contract's protocol (W warm-up, barrier, K steps, barrier, MAX over ranks): this is
+        # (a) the `replicas` field, (b) the one-GPU time speedup_vs_n1 divides by (every rank alone on its own GPU, the slowest rank's time), and
+        # (c) the line this run prints if the group below never comes back — a multi-GPU run always yields a line.
+        note(f"replicas: {args.warmup} + {args.steps} proofs per GPU")
+        with pin():
+            dt_r, (proof_r, _) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t)
+        cells_r = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
+        replica_line = {"what": "N independent proofs, one per GPU, no data-path collective (weak scaling; the headline before round 5, and with --replicas)", "value": cells_r * args.steps / dt_r,
+                        "unit": "trace cells/s", "ms_per_step": dt_r / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                        "proof_sha256": hashlib.sha256(proof_r).hexdigest()}
+        n1 = {"ms_per_proof": replica_line["ms_per_step"], "proof_sha256": replica_line["proof_sha256"], "steps": args.steps,
+              "note": "every rank alone on its own GPU at the same time (the replicas run of this line); the slowest rank's time"}
+
+        def group_never_came_back():
+            # the group's part has not finished within --group-timeout: a collective that cannot be interrupted from here (a hung bootstrap, a wedged
+            # queue). Rank 0 prints the replicas line — measured above under the contract's protocol — and every rank leaves.
+            if rank == 0:
+                want_r = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == args.log_max_rows), None)
+                line = {"metric": "trace cells committed+proved/sec", "value": replica_line["value"], "unit": "trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": replica_line["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31 / QM31 modular arithmetic)",
+                        "data": "fib19.bf execution trace (199246 VM steps), synthetic in the sense of the contract: a bundled program, no external data",
+                        "parity_checked": bool(want_r is not None and want_r["sha256"] == replica_line["proof_sha256"]),
+                        "config": {"workload": "fib19.bf (BASELINE config 2; 2^24 domain rows, Blake2s Merkle), 1 proof per step and GPU", "log_max_rows": args.log_max_rows,
+                                   "cells_per_proof": trace.cells, "parallelism": "replicas"},
+                        "roofline": None, "replicas": replica_line,
+                        "shard_group_error": f"the shard group (ONE proof over the {world} GPUs) did not finish within {args.group_timeout} s and could not be interrupted — value / ms_per_step are the "
+                                             "REPLICAS (weak scaling), measured before the group formed"}
+                print(json.dumps(line), flush=True)
+            print(f"bench.py[rank {rank}/{world}] the shard group did not come back within {args.group_timeout} s: leaving", file=sys.stderr, flush=True)
+            os._exit(0)      # the line above says what happened; a non-zero code would only make a launcher discard it
+
+        import threading
+        watchdog = threading.Timer(args.group_timeout, group_never_came_back)
+        watchdog.daemon = True
+        watchdog.start()
+        note(f"one-GPU reference {n1['ms_per_proof']:.2f} ms; joining the shard group")
+        try:
+            join_group(ctx)
+            ok = True
+            note("joined: " + ctx.group_info()[2])
+        except Exception as e:
+            ok, shard_error = False, f"joining the shard group failed on rank {rank}: {e!r}"
+        if not agree(ok):
+            shard_error = shard_error or "joining the shard group failed on another rank"
+            try:
+                ctx.leave_group()
+            except Exception:
+                pass
+            sharded = False
     if sharded:
         note(f"timed region: {args.warmup} + {args.steps} proofs over the group")
         try:
@@ -1046,21 +1090,16 @@ def main():
                 pass
             big.close()
 
-    # ---- replicas: every rank proves its own trace, no data-path collective (the headline at N = 1, with --replicas, or if the group failed) -------
-    replica_line = None
-    note("replicas")
+    if watchdog is not None:
+        watchdog.cancel()
+    # ---- replicas as the headline: N = 1, --replicas, or the group failed (its own replicas run above then stands) -----------------------------------
     if not sharded:
+        note("replicas (headline)")
         with pin():
             dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t, on_timed_start=start_events)
         total_cells = replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=cuda_t)
     else:
         total_cells = trace.cells                         # all ranks proved the same one
-        with pin():
-            dt_r, _ = replicas.timed_region(one_step, max(1, min(args.steps, 10)), 1, dist=dist, sync_fn=sync, backend_tensor=cuda_t)
-        cells_r = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
-        k_r = max(1, min(args.steps, 10))
-        replica_line = {"what": "N independent proofs, one per GPU, no data-path collective (weak scaling; the headline before round 5)", "value": cells_r * k_r / dt_r,
-                        "unit": "trace cells/s", "ms_per_step": dt_r / k_r * 1e3, "steps": k_r, "scaling": "weak"}
 
     # ---- parity: the proof timed last against the committed digest of the CPU oracle's proof of this workload (same conventions) ------
     digest = hashlib.sha256(proof).hexdigest()

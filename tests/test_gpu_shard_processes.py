@@ -168,6 +168,24 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     assert abs(line["value"] - line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6      # one proof's cells, not N times
 
 
+def test_bench_prints_the_replicas_line_when_the_group_never_comes_back():
+    """--group-timeout: a shard group that does not finish in time (here: a limit of 0 s) cannot be interrupted — rank 0 prints the replicas line it measured
+    before the group formed (contract protocol, K steps), flagged with shard_group_error, and every rank leaves with code 0: a multi-GPU run always yields a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
+                        "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--group-timeout", "0", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
+    for f in glob.glob("/dev/shm/bfhip_mock_*"):
+        os.remove(f)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3 and "did not finish within 0 s" in line["shard_group_error"]
+    assert line["parity_checked"] is True and line["value"] == line["replicas"]["value"] > 0
+    assert abs(line["value"] - 2 * line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6      # two proofs per step: one per rank
+
+
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
