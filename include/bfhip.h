@@ -87,7 +87,8 @@ int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]);
  * hardware queue while the host thread sleeps. Where they are on (policy 0, or forced with BFHIP_MAILBOX=1), a host thread that is stalled for
  * longer than BFHIP_MAILBOX_TIMEOUT_MS (default 10 000 ms: SIGSTOP, a debugger, heavy oversubscription) makes that proof FAIL with a
  * "mailbox kernel gave up waiting for the host" error instead of merely being slow; the context stays usable and the next proof starts
- * clean. BFHIP_MAILBOX=0 switches them off altogether. All members of a group must use the same overlap mask (bfhip_ctx_set_overlap). */
+ * clean. At most one proof of a process runs in the mailbox order at a time (two could block each other through a shared hardware queue): with several
+ * proofs in flight the others keep the plain order. BFHIP_MAILBOX=0 switches them off altogether. All members of a group must use the same overlap mask (bfhip_ctx_set_overlap). */
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);
 /* Mailbox settings of a live context (what BFHIP_MAILBOX / BFHIP_MAILBOX_TIMEOUT_MS / BFHIP_MAILBOX_TEST_DELAY_MS set at creation):
  * mode -1 = automatic (see above), 0 = off, 1 = on; timeout_ms 0 = keep the current timeout; test_delay_ms >= 0: the host sleeps that long before

@@ -2,6 +2,7 @@
 // driver code it calls (CommitmentSchemeProver / TreeBuilder / prover::prove / FriProver). Everything that touches a column runs
 // in the gfx950 kernels; the host keeps only the Fiat–Shamir channel, the sample/batch bookkeeping and the decommitment control
 // flow (which depends on query positions, never on column data). There is no CPU fallback for any column operation.
+#include <atomic>
 #include "../../include/bfhip.h"
 #include "ctx.h"
 #include "host/circle.h"
@@ -709,6 +710,18 @@ struct HipProver {
         // Not by default under the blocking sync policy either: a mailbox kernel spins on the GPU until this thread posts, and a host that
         // asked for sleeping waits is one whose threads may be descheduled for long (BFHIP_MAILBOX=1 still forces it; wait_stamp then sleeps).
         c.use_mailbox = c.mailbox_mode < 0 ? (log_max_rows <= 21 && !c.sync_blocking) : c.mailbox_mode != 0;
+        // At most ONE proof of the process runs in the mailbox order at a time (r05). HIP multiplexes the streams of all contexts onto a few
+        // hardware queues; with two proofs in that order, A's stamp-producing kernels can sit behind B's spinning mailbox kernel on a shared
+        // queue while B's sit behind A's — each host thread waits for a stamp that cannot be written until the other posts: both give up after
+        // BFHIP_MAILBOX_TIMEOUT_MS (seen with three 2^20-row proofs in flight, profiles/r05_bench.json of the first pass). A proof that does not
+        // get the token keeps the order wait -> draw -> copy -> launch: behind one spinning kernel it is merely later, never stuck.
+        struct MailboxToken {
+            bool held = false;
+            static std::atomic<int>& flag() { static std::atomic<int> f{0}; return f; }
+            bool acquire() { int z = 0; held = flag().compare_exchange_strong(z, 1); return held; }
+            ~MailboxToken() { if (held) flag().store(0); }
+        } mailbox_token;
+        if (c.use_mailbox && !sharded() && !(c.overlap & 2u) && !mailbox_token.acquire()) c.use_mailbox = false;
         const bool mb = c.use_mailbox && !sharded() && !(c.overlap & 2u);
         if (++c.proof_seq == 0) c.proof_seq = 1;
         c.reap_some();

@@ -531,3 +531,34 @@ def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pk
         assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
     finally:
         c.close()
+
+
+@pytest.mark.single_conv
+def test_several_proofs_in_flight_in_the_mailbox_order_do_not_block_each_other(pkg, oracle, monkeypatch):
+    """Four contexts of one process proving at the same time with the mailbox order forced on: their streams share the GPU's few hardware queues, and two
+    spinning mailbox kernels could each sit in front of the kernels the OTHER proof's host thread waits for (seen in round 5: three 2^20-row proofs in flight ->
+    'a mailbox kernel gave up waiting for the host'). Only one proof of the process holds the mailbox order at a time; the others keep the plain order. Same bytes,
+    no error, well inside the kernels' patience (3 s here)."""
+    import threading
+    monkeypatch.setenv("BFHIP_MAILBOX", "1")
+    monkeypatch.setenv("BFHIP_MAILBOX_TIMEOUT_MS", "3000")
+    code = _prog("collatz.bf")
+    want, _, _ = oracle.prove(code, b"7\n", log_max_rows=21)
+    ctxs = [pkg.Context(0, max_log_domain=23) for _ in range(4)]
+    errors, wrong = [], []
+
+    def run(c):
+        try:
+            for _ in range(8):
+                if pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) != want:
+                    wrong.append(1)
+        except Exception as e:
+            errors.append(repr(e))
+
+    try:
+        th = [threading.Thread(target=run, args=(c,)) for c in ctxs]
+        [t.start() for t in th]; [t.join() for t in th]
+    finally:
+        for c in ctxs:
+            c.close()
+    assert not errors and not wrong, (errors, len(wrong))

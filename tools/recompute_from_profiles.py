@@ -64,7 +64,8 @@ def main():
     print(f"Poseidon252 2^26 rows: {b['poseidon252']['ms_per_proof']} ms")
     for w in ("fib19", "2^22_rows", "2^20_rows"):
         if w in pl:
-            print(f"proofs in flight, {w}: " + ", ".join(f"{k[-1]} in flight {pl[w][k]['ms_per_proof']} ms/proof" + (f" (x{pl[w][k]['gain_vs_1']}, same bytes {pl[w][k]['same_proof_as_1']})" if 'gain_vs_1' in pl[w][k] else "") for k in ("in_flight_1", "in_flight_2", "in_flight_3")))
+            print(f"proofs in flight, {w}: " + ", ".join((f"{k[-1]} in flight {pl[w][k]['ms_per_proof']} ms/proof" + (f" (x{pl[w][k]['gain_vs_1']}, same bytes {pl[w][k]['same_proof_as_1']})" if 'gain_vs_1' in pl[w][k] else ""))
+                                                             if "ms_per_proof" in pl[w][k] else f"{k[-1]} in flight: {pl[w][k].get('error', '?')[:80]}" for k in ("in_flight_1", "in_flight_2", "in_flight_3")))
     cb = b["cpu_baseline"]
     print(f"cpu_baseline ({cb['kind']}): {cb['value']:.3e} cells/s with {cb.get('threads')} threads on {cb.get('cores_effective')} effective cores (quota {cb.get('quota_cores')}, affinity {cb.get('host_threads_in_affinity_mask')}); "
           f"proof identical to the GPU's: {cb.get('proof_identical_to_gpu')}; scalar port (not timed here): {cb.get('scalar_value', 0):.3e} cells/s")
