@@ -58,6 +58,18 @@ struct Coset {
     // All points, by repeated addition of the step (Coset::iter()).
     std::vector<PointM> points() const {
         std::vector<PointM> out(size());
+        if (simd::enabled() && out.size() >= (size_t(1) << 14)) {
+            // SIMD mode of the port (bench.py's cpu_baseline): the walk in parallel chunks, each started at its own index — the group law is exact, so
+            // the points are the same words as the serial walk's
+            const size_t chunk = size_t(1) << 12, n = out.size();
+            const PointM s = step();
+#pragma omp parallel for schedule(static)
+            for (size_t c0 = 0; c0 < n; c0 += chunk) {
+                PointM p = at(c0);
+                for (size_t i = c0; i < c0 + chunk; i++) { out[i] = p; p = p + s; }
+            }
+            return out;
+        }
         PointM p = initial(), s = step();
         for (size_t i = 0; i < out.size(); i++) { out[i] = p; p = p + s; }
         return out;
@@ -148,6 +160,21 @@ static inline std::vector<M31> slow_precompute_twiddles(Coset coset) {
     u32 logn = coset.log_size;
     for (u32 l = 0; l < logn; l++) {
         size_t i0 = tw.size(), half = coset.size() / 2;
+        if (simd::enabled() && half >= (size_t(1) << 14)) {
+            // SIMD mode of the port: the layer's points in parallel chunks, written straight to their bit-reversed places (same words)
+            tw.resize(i0 + half);
+            const size_t chunk = size_t(1) << 12;
+            const PointM s = coset.step();
+            u32 lg = 0; while ((size_t(1) << lg) < half) lg++;
+            M31* dst = tw.data() + i0;
+#pragma omp parallel for schedule(static)
+            for (size_t c0 = 0; c0 < half; c0 += chunk) {
+                PointM p = coset.at(c0);
+                for (size_t i = c0; i < c0 + chunk; i++) { dst[bit_reverse_index((u32)i, lg)] = p.x; p = p + s; }
+            }
+            coset = coset.dbl();
+            continue;
+        }
         PointM p = coset.initial(), s = coset.step();
         for (size_t i = 0; i < half; i++) { tw.push_back(p.x); p = p + s; }
         bit_reverse(tw.data() + i0, half);

@@ -7,6 +7,7 @@
 // restates the published algorithm of stwo `core/fields/{m31,cm31,qm31}.rs` and is pinned only by
 // algebraic identities and by the reference's own call sites (e.g. `.inverse()` crates/brainfuck_vm/src/machine.rs:225).
 #pragma once
+#include "simd_port.h"
 #include <cstdint>
 #include <cstddef>
 #include <vector>
@@ -120,6 +121,22 @@ static inline QM31 from_partial_evals(const QM31 e[4]) {
 template <class F>
 static inline void batch_inverse(const F* src, F* dst, size_t n) {
     if (n == 0) return;
+    if (simd::enabled() && n >= (size_t(1) << 15)) {
+        // SIMD mode of the port (bench.py's cpu_baseline): independent chunks in parallel — an inverse is unique, so the words are the same
+        const size_t chunk = size_t(1) << 13;
+#pragma omp parallel for schedule(static)
+        for (size_t c0 = 0; c0 < n; c0 += chunk) {
+            const size_t m = std::min(chunk, n - c0);
+            std::vector<F> pref(m);
+            F acc = src[c0];
+            pref[0] = acc;
+            for (size_t i = 1; i < m; i++) { acc = acc * src[c0 + i]; pref[i] = acc; }
+            F ia = inv(acc);
+            for (size_t i = m - 1; i > 0; i--) { dst[c0 + i] = ia * pref[i - 1]; ia = ia * src[c0 + i]; }
+            dst[c0] = ia;
+        }
+        return;
+    }
     std::vector<F> pref(n);
     F acc = src[0];
     pref[0] = acc;

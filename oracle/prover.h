@@ -245,6 +245,7 @@ static inline QM31 accumulate_row_quotients(const std::vector<SampleBatch>& sb, 
 static inline std::vector<PointM> domain_points(u32 log) {
     auto half = CanonicCoset{log}.half_coset().points();
     std::vector<PointM> pts(half.size() * 2);
+#pragma omp parallel for schedule(static) if (simd::enabled() && half.size() >= 4096)
     for (size_t i = 0; i < half.size(); i++) { pts[i] = half[i]; pts[half.size() + i] = -half[i]; }
     return pts;
 }
@@ -385,6 +386,16 @@ struct Prover {
         { auto f = ch.draw_felts(2); el.memory = LookupElements::make(f[0], f[1]); }        // MemoryElements::draw
         { auto f = ch.draw_felts(2); el.instruction = LookupElements::make(f[0], f[1]); }   // InstructionElements::draw
         { auto f = ch.draw_felts(2); el.processor = LookupElements::make(f[0], f[1]); }     // ProcessorElements::draw
+        if (simd::enabled()) {
+            // SIMD mode of the port (bench.py's cpu_baseline): the 13 components side by side (the reference's rayon would do no less); commit order kept
+            std::vector<std::vector<PolyCol>> per(N_COMPONENTS);
+#pragma omp parallel for schedule(dynamic)
+            for (int c = 0; c < N_COMPONENTS; c++) {
+                auto cols = gen_interaction_trace(c, tables[c], el, &bp.claimed_sums[c]);
+                for (auto& col : cols) per[c].push_back(interpolate_col(col, bp.log_sizes[c], tw));
+            }
+            for (int c = 0; c < N_COMPONENTS; c++) for (auto& pc : per[c]) trees[2].polys.push_back(std::move(pc));
+        } else
         for (int c = 0; c < N_COMPONENTS; c++) {
             auto cols = gen_interaction_trace(c, tables[c], el, &bp.claimed_sums[c]);
             for (auto& col : cols) trees[2].polys.push_back(interpolate_col(col, bp.log_sizes[c], tw));
@@ -592,6 +603,7 @@ struct Prover {
         while (layer.size() > last_size) {
             while (qi < quotients.size() && (size_t(1) << (quotients[qi].log_size - 1)) == layer.size()) fold_circle_into_line(layer, quotients[qi++], folding_alpha);
             Inner in; in.eval = layer; in.log = line_log; in.sc.init(line_log);
+#pragma omp parallel for schedule(static) if (simd::enabled() && layer.size() >= 4096)
             for (size_t i = 0; i < layer.size(); i++) in.sc.set(i, layer[i]);
             in.tree = MerkleProver::commit(coord_refs(in.sc));
             ch.mix_root(in.tree.root());
