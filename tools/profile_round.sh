@@ -43,7 +43,7 @@ if has inflight; then
 #     time launches of BOTH queues are in flight (one proof's single-workgroup chains under the other's kernels)
 for w in 22 20 fib19; do for k in 1 2 3; do python3 "$ROOT/tools/inflight_profile.py" $w $k --rounds 8; done; done > "$OUT/${R}_inflight.jsonl" 2>/dev/null
 for k in 1 2; do
-  rm -rf /tmp/prof_if; $RP --kernel-trace --output-format csv -d /tmp/prof_if -- python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 6 > "$OUT/inflight${k}_under_rocprof.json" 2>/dev/null
+  rm -rf /tmp/prof_if; $RP --kernel-trace --output-format csv -d /tmp/prof_if -- python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 6 --min-seconds 0 > "$OUT/inflight${k}_under_rocprof.json" 2>/dev/null
   python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_if) --window 0.35:0.80 > "$OUT/${R}_2p22_inflight${k}_timeline_gaps.txt" 2>&1
 done
 fi
