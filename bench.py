@@ -710,10 +710,10 @@ def run_pipelined_one(pkg, device, code, lmr, k, rounds=6):
 
 def run_pipelined(args, rounds=6):
     """{fib19, 2^22 rows, 2^20 rows} x {1, 2, 3 proofs in flight}, every configuration in a CHILD PROCESS of its own, started before this process
-    touches the GPU. Why a fresh process per configuration: HIP multiplexes streams onto a few hardware queues in creation order, and contexts that
-    came before (this process's own, or earlier configurations' — even closed ones) shift the assignment so that the main streams of two contexts
-    can share a queue and serialise: measured on one box, 2 in flight at 2^22 rows gain 2-3 % inside a process with history and 12 % in a fresh one,
-    which is the deployment's situation (one long-lived context per proof in flight)."""
+    touches the GPU: what a deployment sees — k long-lived contexts and nothing else. (Round 5 found the gain to depend on what else the process had
+    created: HIP hands every stream a hardware queue at creation, and with four streams per context the main streams of two contexts shared one —
+    2-3 % instead of 12-17 % at 2^22 rows. Contexts now create their two partner streams on demand and the gain no longer depends on history,
+    profiles/r05_inflight_history.txt; the child processes stay: one configuration, one process, no leftovers.)"""
     import subprocess
     out = {"what": "k proofs in flight per GPU = k contexts + k host threads in a fresh process; ms_per_proof = wall time / proofs completed", "rounds_per_context": rounds}
     for name, _, _ in PIPELINED_WORK:

@@ -18,6 +18,8 @@ void bfhip_set_error(const std::string& s) { g_err = s; }
 
 namespace bf {
 
+void Ctx::ensure_aux() { for (auto& a : aux) if (!a) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking)); }
+
 void Ctx::init(int dev, u32 max_log_domain) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device: the bfhip backend has no CPU fallback");
@@ -35,7 +37,7 @@ void Ctx::init(int dev, u32 max_log_domain) {
     if (const char* v = getenv("BFHIP_MAILBOX")) mailbox_mode = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("BFHIP_MAILBOX_TIMEOUT_MS")) mailbox_timeout = std::max(1, atoi(v)) * 1e-3;
     if (const char* v = getenv("BFHIP_MAILBOX_TEST_DELAY_MS")) mailbox_test_delay_ms = std::max(0, atoi(v));
-    for (auto& a : aux) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    if (overlap) ensure_aux();      // the partner streams exist only for contexts that use them (ctx.h: ensure_aux)
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : reap_ev) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev) BF_HIP(hipEventCreate(&e));
@@ -132,6 +134,7 @@ int32_t bfhip_ctx_join_local_group(bfhip_ctx* ctx, bfhip_local_group* group, uin
     API_CTX(ctx)
     if (!group) throw HipError("null group");
     check_group_size(rank, group->count);
+    ctx->c.ensure_aux();                  // a group's exchange may run on the partner stream (Ctx::exchange_overlapped)
     join_group(ctx, local_comm_join(group->g, rank));
     return 0;
     API_CATCH
@@ -140,6 +143,7 @@ int32_t bfhip_rccl_unique_id(uint8_t id[128]) { API_TRY rccl_unique_id(id); retu
 int32_t bfhip_ctx_join_rccl_group(bfhip_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t count) {
     API_CTX(ctx)
     check_group_size(rank, count);
+    ctx->c.ensure_aux();
     join_group(ctx, rccl_comm_join(id, rank, count));
     return 0;
     API_CATCH
@@ -247,6 +251,7 @@ int32_t bfhip_ctx_set_overlap(bfhip_ctx* ctx, uint32_t mask) {
     API_CTX(ctx)
     if (mask > 7) throw HipError("overlap mask: bit 0 = tree commitment, bit 1 = quotients / FRI first layer, bit 2 = shard-group exchanges");
     ctx->c.sync();
+    if (mask) ctx->c.ensure_aux();
     ctx->c.overlap = mask;
     ctx->c.overlap_user_set = true;      // also switches OFF the default exchange overlap of a multi-GPU shard group when bit 2 is clear
     return 0;

@@ -66,7 +66,10 @@ struct Ctx {
     bool exchange_overlapped() const { return (overlap & 4u) != 0 || (!overlap_user_set && shard.count > 1 && shard.comm && shard.comm->spans_devices()); }
     u32 overlap = 0;      // measured (profiles/r03_overlap_ab*.txt): bit 1 gains 0-0.3 ms on fib19 box to box, bit 0 nothing — both sides of either overlap are
                           // VALU-limited (co-running kernels stretch each other), and the dominant kernel's event-timed roofline would include the interference
+    // Created on demand (r05): HIP hands every stream one of a few hardware queues (GPU_MAX_HW_QUEUES, default 4) when it is created; with four
+    // streams per context the main streams of two contexts shared a queue and two proofs in flight serialised (tools/inflight_history.py).
     hipStream_t aux[2] = {nullptr, nullptr};
+    void ensure_aux();
     hipStream_t id_main = nullptr;  // the main stream's handle (stream and stream2 are swapped while the preprocessed phase is enqueued)
     hipStream_t aux_of(hipStream_t s) const { return s == id_main ? aux[0] : aux[1]; }
     hipEvent_t evp[32] = {};        // ordering events (no timing), handed out round robin: a wait captures the event's state when it is enqueued

@@ -2114,11 +2114,11 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
 // Profiler state is per stream, i.e. per context: contexts on other threads are not affected (prof.hip).
 static void sync_both(Ctx& c) { c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a)); }
 extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) {
-    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); for (auto a : ctx->c.aux) prof_enable(a, mode); return 0; }
+    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); for (auto a : ctx->c.aux) if (a) prof_enable(a, mode); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) {
-    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); for (auto a : ctx->c.aux) prof_reset(a); return 0; }
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); for (auto a : ctx->c.aux) if (a) prof_reset(a); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {
