@@ -64,8 +64,8 @@ int32_t bfhip_device_count(void);
  * SimdBackend::precompute_twiddles(CanonicCoset::new(LOG_MAX_ROWS + log_blowup + 2).circle_domain().half_coset), mod.rs:480-484).
  * Range [6, 29]: columns of up to 2^29 cells (LOG_MAX_ROWS <= 27). */
 /* A context owns two HIP streams (main, side) and creates two partner streams on demand (bfhip_ctx_set_overlap, shard groups). Several proofs in flight on
- * one GPU = one context and one host thread each; HIP gives every stream one of GPU_MAX_HW_QUEUES (default 4) hardware queues at creation, so with more than
- * two proofs in flight per process export GPU_MAX_HW_QUEUES >= 2 x contexts before the runtime starts (profiles/r05_inflight_history.txt). */
+ * one GPU = one context and one host thread each; HIP gives every stream one of GPU_MAX_HW_QUEUES (default 4) hardware queues at creation, with two streams per
+ * context up to four proofs in flight per process need no setting (measured; more queues than that change nothing: profiles/r05_inflight_history.txt). */
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
