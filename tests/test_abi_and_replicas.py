@@ -261,3 +261,19 @@ def test_bench_kernel_source_digest_is_stable_and_sensitive(tmp_path):
     b = _bench()
     h = b.kernel_sources_sha256()
     assert h == b.kernel_sources_sha256() and len(h) == 64
+
+
+def test_bench_roofline_from_the_committed_rocprof_summary():
+    """roofline.frac_rocprof: recomputed from profiles/rNN_roofline_single_stream_kernel_stats.csv while that run's kernel sources are the current ones; a stale
+    summary yields null WITH the reason (never a number measured on another kernel). Either way the shape is fixed."""
+    b = _bench()
+    out = b.roofline_from_committed_rocprof(669777920, 78.0)
+    assert set(out) >= {"frac_rocprof", "frac_rocprof_source", "frac_range_this_round"} and isinstance(out["frac_rocprof_source"], str)
+    if out["frac_rocprof"] is None:
+        assert "STALE" in out["frac_rocprof_source"] or "no committed" in out["frac_rocprof_source"] or ":" in out["frac_rocprof_source"]
+    else:
+        assert 0.5 < out["frac_rocprof"] < 1.0 and out["avg_launch_us_rocprof"] > 0
+        # the arithmetic a reader would do by hand: compressions x 977 lane-ops / (average launch x launches per proof) / (256 CU x 4 SIMD x 16 lanes x 2.4 GHz)
+        want = 669777920 * 977 / (out["avg_launch_us_rocprof"] * 1e-6 * 78.0) / (256 * 4 * 16 * 2.4e9)
+        assert abs(want - out["frac_rocprof"]) < 2e-3
+    assert b.roofline_from_committed_rocprof(None, 78.0)["frac_rocprof"] is None
