@@ -59,12 +59,23 @@ def share_unique_id(dist, make_id, device=None) -> bytes:
     import torch
     rank = dist.get_rank()
     t = torch.zeros(128, dtype=torch.uint8)
+    failure = None
     if rank == 0:
-        raw = make_id()
-        if len(raw) != 128:
-            raise ValueError("an RCCL unique id has 128 bytes")
-        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+        # a rank 0 that cannot create the id (librccl missing ...) must still take part in the broadcast: the other ranks are already waiting in it.
+        # It sends 128 zero bytes — never a valid id — and every rank raises.
+        try:
+            raw = make_id()
+            if len(raw) != 128:
+                raise ValueError("an RCCL unique id has 128 bytes")
+            t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+        except Exception as e:
+            failure = e
     if device is not None:
         t = t.to(device)
     dist.broadcast(t, src=0)
-    return bytes(t.cpu().numpy().tobytes())
+    if failure is not None:
+        raise failure
+    out = bytes(t.cpu().numpy().tobytes())
+    if out == bytes(128):
+        raise RuntimeError("rank 0 could not create the RCCL unique id (it broadcast the all-zero marker)")
+    return out

@@ -73,6 +73,15 @@ made = []
 uid = rep.share_unique_id(dist, lambda: (made.append(1), bytes(range(128)))[1])
 assert uid == bytes(range(128)), uid
 assert len(made) == (1 if rank == 0 else 0)
+# a rank 0 that cannot create the id still takes part in the broadcast, and EVERY rank gets an exception (no rank is left waiting)
+def broken():
+    raise RuntimeError("no librccl here")
+try:
+    rep.share_unique_id(dist, broken)
+    raise SystemExit("share_unique_id should have raised on rank %d" % rank)
+except RuntimeError as e:
+    assert ("no librccl here" in str(e)) if rank == 0 else ("all-zero marker" in str(e)), str(e)
+dist.barrier()
 print("ok", rank, round(dt, 3))
 dist.destroy_process_group()
 """

@@ -190,3 +190,19 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_bench_falls_back_to_the_replicas_when_the_group_cannot_be_formed(tmp_path):
+    """The RCCL entry points cannot be loaded (BFHIP_RCCL_LIBRARY names a file that does not exist): joining fails on every rank, the ranks agree on that over
+    torch.distributed, and the line is the replicas' (weak scaling) with shard_group_error saying why — exit code 0, one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BFHIP_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
+                        "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "joining the shard group failed" in line["shard_group_error"] and "RCCL" in line["shard_group_error"]
+    assert line["parity_checked"] is True and line["roofline"]["kernel"] == "k_merkle_layer"
+    assert abs(line["value"] - 2 * line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
