@@ -1053,7 +1053,7 @@ def main():
             comm_after = ctx.group_times()
             comm_ms = {k: (comm_after[k] - comm_before.get(k, 0.0)) / args.steps for k in comm_after}
             group = {"transport": ctx.group_info()[2], "per_proof_rank0": {k: round(v / (args.warmup + args.steps), 1) for k, v in ctx.group_stats().items()},
-                     "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()}, "comm_ms_per_proof_max_rank": round(over_ranks(sum(comm_ms.values()), "max"), 3)}
+                     "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()}}
             ok = True
         except Exception as e:
             ok, shard_error = False, f"the shard group's proof failed on rank {rank}: {e!r}"
@@ -1062,6 +1062,9 @@ def main():
             shard_error = shard_error or "the shard group's proof failed on another rank"
             sharded = False
             lib.bfhip_profile_enable(ctx._h, 0)
+        else:
+            # only now, with every rank known to be here: collectives of the timing channel are never issued from inside a try block a peer may have left
+            group["comm_ms_per_proof_max_rank"] = round(over_ranks(sum(comm_ms.values()), "max"), 3)
         try:
             ctx.leave_group()
         except Exception:
