@@ -78,3 +78,16 @@ def test_simd_mode_leaves_the_other_conventions_alone(simd, conv, name, inp):
     if conv == (0, 0, 0, 0):
         pytest.skip("covered by test_simd_proof_equals_scalar_proof")
     _same_proof(simd, name, inp)
+
+
+@pytest.mark.single_conv
+def test_simd_port_under_address_and_ub_sanitizers(simd, tmp_path):
+    """The SIMD mode's gathers, scatters, unaligned vector accesses and chunked parallel loops under ASan + UBSan (a separate binary: the oracle sources + a small driver),
+    on a program large enough for every vector path (hello_kakarot.bf: components up to 2^17 rows). Scalar and SIMD proofs must be identical there too."""
+    import subprocess
+    exe = tmp_path / "oracle_simd_sanitize"
+    src = [os.path.join(ROOT, "tests", "native", "oracle_simd_sanitize.cpp")] + [os.path.join(ROOT, "oracle", f) for f in ("oracle_capi.cpp", "simd_bound.cpp", "simd_port.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fopenmp", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(ROOT, "oracle"), "-o", str(exe)] + src + ["-lpthread"])
+    r = subprocess.run([str(exe), os.path.join(PROGS, "hello_kakarot.bf"), "17"], capture_output=True, text=True, timeout=600, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "identical: 1" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
