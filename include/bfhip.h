@@ -58,14 +58,19 @@ typedef struct bfhip_conventions {
 const char* bfhip_last_error(void);
 /* Number of visible HIP devices (0 when there is no GPU). */
 int32_t bfhip_device_count(void);
+/* hipMemGetInfo of one device: bytes free right now and in total (either pointer may be NULL). What a caller sizes a pool with, and what
+ * the leak test of a failed bfhip_ctx_create compares before / after. */
+int32_t bfhip_device_memory(int32_t device_id, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* Context: owns the stream, the twiddle tree and scratch memory.
  * max_log_domain = log2 of the largest evaluation domain that will be used (reference: LOG_MAX_ROWS + log_blowup + 1 = 26, since
  * SimdBackend::precompute_twiddles(CanonicCoset::new(LOG_MAX_ROWS + log_blowup + 2).circle_domain().half_coset), mod.rs:480-484).
  * Range [6, 29]: columns of up to 2^29 cells (LOG_MAX_ROWS <= 27). */
-/* A context owns two HIP streams (main, side) and creates two partner streams on demand (bfhip_ctx_set_overlap, shard groups). Several proofs in flight on
- * one GPU = one context and one host thread each; HIP gives every stream one of GPU_MAX_HW_QUEUES (default 4) hardware queues at creation, with two streams per
- * context up to four proofs in flight per process need no setting (measured; more queues than that change nothing: profiles/r05_inflight_history.txt). */
+/* A context owns a main HIP stream, creates its side stream at its first proof (the preprocessed commitment runs there) and two partner streams on
+ * demand (bfhip_ctx_set_overlap, shard groups). HIP gives every stream one of GPU_MAX_HW_QUEUES (default 4) hardware queues at creation; with two
+ * streams per context up to four proofs in flight per process need no setting (profiles/r05_inflight_history.txt). Several proofs in flight on one GPU:
+ * a pool (bfhip_pool_create below) behind one caller thread, or one context and one host thread each.
+ * A creation that fails (no device, out of memory at the twiddle tree, ...) releases everything it had allocated. */
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out);
 int32_t bfhip_ctx_destroy(bfhip_ctx* ctx);
 int32_t bfhip_ctx_sync(bfhip_ctx* ctx);
@@ -93,9 +98,11 @@ int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]);
  * clean. At most one proof of a process runs in the mailbox order at a time (two could block each other through a shared hardware queue): with several
  * proofs in flight the others keep the plain order. BFHIP_MAILBOX=0 switches them off altogether. All members of a group must use the same overlap mask (bfhip_ctx_set_overlap). */
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);
-/* Mailbox settings of a live context (what BFHIP_MAILBOX / BFHIP_MAILBOX_TIMEOUT_MS / BFHIP_MAILBOX_TEST_DELAY_MS set at creation):
- * mode -1 = automatic (see above), 0 = off, 1 = on; timeout_ms 0 = keep the current timeout; test_delay_ms >= 0: the host sleeps that long before
- * every post (tests of the late-host path only; 0 in production), negative = keep. Takes effect at the next proof. */
+/* Mailbox settings of a live context (what BFHIP_MAILBOX / BFHIP_MAILBOX_TIMEOUT_MS set at creation):
+ * mode -2 = keep the current mode, -1 = automatic (see above), 0 = off, 1 = on; timeout_ms 0 = keep the current timeout; test_delay_ms: the
+ * host sleeps that long before every post — a test hook that exists only in the test-hooks build of the library (libbfhip_testhooks.so,
+ * -DBFHIP_TEST_HOOKS: there BFHIP_MAILBOX_TEST_DELAY_MS presets it); the default build accepts <= 0 (no delay) and rejects anything else.
+ * Takes effect at the next proof. */
 int32_t bfhip_ctx_set_mailbox(bfhip_ctx* ctx, int32_t mode, uint32_t timeout_ms, int32_t test_delay_ms);
 
 /* Conventions used by every operation of this context (prover, bfhip_merkle_commit_layer, bfhip_grind). conv == NULL restores the defaults. */
@@ -237,9 +244,10 @@ int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]);
 /* GPU-side milliseconds this rank's stream spent inside {all-gathers, max-reduces, grouped send-receives} since the group was joined (one
  * HIP-event pair per collective): the communication share of a proof over several GPUs. Synchronises the context's stream. */
 int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]);
-/* Test entry: joins an RCCL group (unique id, rank, count), runs ONE grouped send-receive on the given blocks and leaves. With a test double
- * of librccl (environment BFHIP_RCCL_LIBRARY, tests/mock_rccl.c) the blocks are host memory and no GPU is needed; with the real library they
- * must be device memory. stats_out (optional) = the counters of bfhip_ctx_group_stats. */
+/* Test entry: joins an RCCL group (unique id, rank, count), runs ONE grouped send-receive on the given blocks and leaves. With the real library
+ * the blocks must be device memory. In the test-hooks build of the library (libbfhip_testhooks.so, -DBFHIP_TEST_HOOKS) the environment variable
+ * BFHIP_RCCL_LIBRARY names a test double of the RCCL entry points (tests/mock_rccl.c: host-memory blocks, no GPU needed); the default build
+ * ignores that variable and loads librccl only. stats_out (optional) = the counters of bfhip_ctx_group_stats. */
 int32_t bfhip_rccl_exchange_raw(const uint8_t id[128], uint32_t rank, uint32_t count, uint32_t n_sends, const uint32_t* send_peer, void* const* send_ptr,
                                 const size_t* send_bytes, uint32_t n_recvs, const uint32_t* recv_peer, void* const* recv_ptr, const size_t* recv_bytes,
                                 uint64_t stats_out[4]);
@@ -279,6 +287,37 @@ int32_t bfhip_ctx_set_table_builder(bfhip_ctx* ctx, int32_t on_gpu);
 int32_t bfhip_trace_column(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t component, uint32_t column, uint32_t* out_h, size_t cap, size_t* n_rows);
 int32_t bfhip_prove_trace(bfhip_ctx* ctx, const bfhip_trace* trace, uint32_t log_max_rows, char** proof_json, size_t* proof_len,
                           char** transcript, double* phase_seconds);
+
+/* ---- proofs in flight: a pool of sub-contexts on one GPU behind ONE caller thread -------------------------------------------------------------
+ * The reference's caller is a single thread of control (prove_brainfuck, mod.rs:471-735); a single proof leaves the GPU partly idle in its
+ * single-workgroup chains (tree tops, small FRI layers) and at its Fiat-Shamir round trips. A pool proves the proofs of a batch n_in_flight at a
+ * time on internal worker threads (one sub-context each) and returns when all are done: +19 % (2 in flight) / +23 % (3) throughput at 2^22 rows,
+ * +36..57 % at 2^20 rows, +10 % for fib19. Proof bytes are those of bfhip_prove_trace, proof by proof.
+ * The sub-contexts share the twiddle tree and point tables of the first one, and — by default — ONE preprocessed commitment per batch:
+ *   bfhip_pool_set_preprocessed(pool, mode): 0 = every proof recommits IsFirst(LOG_MAX_ROWS..=4) as the reference does in every prove_brainfuck
+ *   call (mod.rs:495-500); 1 (default) = once per batch, committed by a builder context beside the first proofs' main-trace phase; 2 = kept
+ *   across batches while LOG_MAX_ROWS and the hasher stay the same. Byte-neutral: the tree depends on LOG_MAX_ROWS and the hasher only.
+ * Traces of a batch must be resident on the pool's device: create them with bfhip_trace_create*(bfhip_pool_ctx(pool, i), ...) — any i — between
+ * batches (a sub-context must not be used by the caller while a batch runs). n_in_flight in [1, 16]; 2-3 is where the gain saturates. */
+typedef struct bfhip_pool bfhip_pool;
+int32_t bfhip_pool_create(int32_t device_id, uint32_t n_in_flight, uint32_t max_log_domain, bfhip_pool** out);
+int32_t bfhip_pool_destroy(bfhip_pool* pool);
+int32_t bfhip_pool_size(bfhip_pool* pool, uint32_t* n_in_flight);
+/* Sub-context i (borrowed: owned by the pool, never pass it to bfhip_ctx_destroy): for bfhip_trace_create*, per-context settings, memory queries. */
+int32_t bfhip_pool_ctx(bfhip_pool* pool, uint32_t i, bfhip_ctx** out);
+/* bfhip_ctx_set_conventions on every sub-context and on the builder of the shared preprocessed tree (conv == NULL: the defaults). */
+int32_t bfhip_pool_set_conventions(bfhip_pool* pool, const bfhip_conventions* conv);
+int32_t bfhip_pool_set_preprocessed(bfhip_pool* pool, int32_t mode);
+/* n x bfhip_prove_trace. Outputs are arrays of n entries, each optional (NULL): proofs_json[i] (malloc'd, bfhip_free_host; NULL when proof i failed),
+ * proof_lens[i], statuses[i] (0 = ok, < 0 = that proof's error). seconds (optional) has n + 1 entries: each proof's own wall time from its start on
+ * its worker, then the wall time of the whole batch. Returns 0 when every proof succeeded, -1 otherwise (bfhip_last_error: the first failed
+ * proof's message); the other proofs of the batch are still delivered. */
+int32_t bfhip_prove_batch(bfhip_pool* pool, const bfhip_trace* const* traces, uint32_t n, uint32_t log_max_rows, char** proofs_json, size_t* proof_lens,
+                          int32_t* statuses, double* seconds);
+/* n x bfhip_prove_brainfuck: VM run, table build and upload of proof i happen inside its worker, beside the other workers' GPU work.
+ * inputs_h may be NULL (no program reads input); n_inputs[i] bytes at inputs_h[i] otherwise. Outputs as above. */
+int32_t bfhip_prove_batch_brainfuck(bfhip_pool* pool, const char* const* codes, const uint8_t* const* inputs_h, const size_t* n_inputs, uint32_t n,
+                                    uint32_t log_max_rows, char** proofs_json, size_t* proof_lens, int32_t* statuses, double* seconds);
 
 /* verify_brainfuck (mod.rs:738-797): replays the channel, checks the logUp sum (mod.rs:207-227), the OODS consistency, the proof of work,
  * every Merkle decommitment and FRI. Host only (the reference verifies on the CPU as well). Returns 0 = accepted, 1 = rejected with the

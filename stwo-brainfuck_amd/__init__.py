@@ -11,7 +11,10 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("BFHIP_LIBRARY") or os.path.join(_HERE, "libbfhip.so")   # BFHIP_LIBRARY: A/B runs of another build
+# BFHIP_LIBRARY: another build of the library (A/B runs; tests of the late-host and RCCL-double paths name libbfhip_testhooks.so, the
+# -DBFHIP_TEST_HOOKS build — the default library has no test hooks)
+_LIB_PATH = os.environ.get("BFHIP_LIBRARY") or os.path.join(_HERE, "libbfhip.so")
+TESTHOOKS_LIBRARY = os.path.join(_HERE, "libbfhip_testhooks.so")
 _lib = None
 
 P = (1 << 31) - 1
@@ -39,6 +42,13 @@ def _check(rc):
 
 def device_count():
     return lib().bfhip_device_count()
+
+
+def device_memory(device_id=0):
+    """bfhip_device_memory: (free, total) bytes of one GPU right now."""
+    f, t = ctypes.c_uint64(), ctypes.c_uint64()
+    _check(lib().bfhip_device_memory(device_id, ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
 
 
 def rccl_unique_id() -> bytes:
@@ -132,8 +142,9 @@ class Context:
         """bfhip_ctx_set_sync_policy: True = the host sleeps in its waits (more waiting contexts than cores), False (default) = polls first."""
         _check(lib().bfhip_ctx_set_sync_policy(self._h, 1 if blocking else 0))
 
-    def set_mailbox(self, mode=-1, timeout_ms=0, test_delay_ms=-1):
-        """bfhip_ctx_set_mailbox: mode -1 automatic / 0 off / 1 on; timeout_ms 0 keeps the timeout; test_delay_ms < 0 keeps the (test) delay."""
+    def set_mailbox(self, mode=-2, timeout_ms=0, test_delay_ms=-1):
+        """bfhip_ctx_set_mailbox: mode -2 keeps the mode / -1 automatic / 0 off / 1 on; timeout_ms 0 keeps the timeout; test_delay_ms < 0 keeps
+        the (test) delay — a positive delay needs the test-hooks build of the library."""
         _check(lib().bfhip_ctx_set_mailbox(self._h, int(mode), int(timeout_ms), int(test_delay_ms)))
 
     def memory(self):
@@ -301,6 +312,93 @@ class Context:
         tw, itw, rl = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
         _check(lib().bfhip_twiddles(self._h, ctypes.byref(tw), ctypes.byref(itw), ctypes.byref(rl)))
         return tw.value, itw.value, rl.value
+
+
+class Pool:
+    """bfhip_pool_create: `n_in_flight` sub-contexts on one GPU behind ONE caller thread — prove_batch() hands the library a batch of resident
+    traces and returns when all are proved, n_in_flight at a time on the library's own worker threads. The sub-contexts share one twiddle
+    tree and (preprocessed=1, default) one preprocessed commitment per batch; 0 = every proof recommits it like the reference
+    (mod.rs:495-500), 2 = kept across batches."""
+
+    def __init__(self, device_id=0, n_in_flight=2, max_log_domain=24, preprocessed=1):
+        self._h = ctypes.c_void_p()
+        _check(lib().bfhip_pool_create(device_id, n_in_flight, max_log_domain, ctypes.byref(self._h)))
+        self.n_in_flight, self.max_log_domain = n_in_flight, max_log_domain
+        self._subs = {}
+        if preprocessed != 1:
+            self.set_preprocessed(preprocessed)
+        if _default_conventions != (0, 0, 0, 0):
+            self.set_conventions(*_default_conventions)
+
+    def close(self):
+        if self._h:
+            for c in self._subs.values():
+                c._h = ctypes.c_void_p()          # borrowed handles die with the pool
+            lib().bfhip_pool_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ctx(self, i=0):
+        """Sub-context i as a (borrowed) Context: for Trace(...) on the pool's device between batches, per-context settings, memory()."""
+        if i not in self._subs:
+            h = ctypes.c_void_p()
+            _check(lib().bfhip_pool_ctx(self._h, i, ctypes.byref(h)))
+            c = Context.__new__(Context)
+            c._h, c.max_log_domain = h, self.max_log_domain
+            c.close = lambda: None                # owned by the pool
+            self._subs[i] = c
+        return self._subs[i]
+
+    def set_conventions(self, merkle_node_hash=0, mix_u64=0, logup_mask_order=0, merkle_channel=0):
+        cv = Conventions(merkle_node_hash, mix_u64, logup_mask_order, merkle_channel)
+        _check(lib().bfhip_pool_set_conventions(self._h, ctypes.byref(cv)))
+
+    def set_preprocessed(self, mode):
+        _check(lib().bfhip_pool_set_preprocessed(self._h, int(mode)))
+
+    def _outputs(self, n, want_json):
+        js = (ctypes.c_void_p * n)() if want_json else None
+        return js, (ctypes.c_size_t * n)(), (ctypes.c_int32 * n)(), (ctypes.c_double * (n + 1))()
+
+    def _collect(self, rc, n, js, lens, st, sec, want_json):
+        proofs = []
+        for i in range(n):
+            if want_json and js[i]:
+                proofs.append(ctypes.string_at(js[i], lens[i]))
+                lib().bfhip_free_host(ctypes.c_void_p(js[i]))
+            else:
+                proofs.append(None)
+        info = {"statuses": [int(v) for v in st], "seconds": [float(v) for v in sec[:n]], "batch_seconds": float(sec[n])}
+        if rc != 0:
+            err = BfhipError(lib().bfhip_last_error().decode())
+            err.proofs, err.info = proofs, info
+            raise err
+        return proofs, info
+
+    def prove_batch(self, traces, log_max_rows=24, want_json=True):
+        """bfhip_prove_batch: returns (proofs, info) — proofs[i] = JSON bytes of traces[i]'s proof; info = per-proof seconds + batch_seconds.
+        Raises BfhipError when a proof failed (its .proofs / .info hold what the rest of the batch produced)."""
+        n = len(traces)
+        arr = (ctypes.c_void_p * max(n, 1))(*[t._h for t in traces])
+        js, lens, st, sec = self._outputs(n, want_json)
+        rc = lib().bfhip_prove_batch(self._h, arr, n, log_max_rows, js, lens, st, sec)
+        return self._collect(rc, n, js, lens, st, sec, want_json)
+
+    def prove_batch_brainfuck(self, programs, log_max_rows=24, want_json=True):
+        """bfhip_prove_batch_brainfuck: programs = [(code, input_bytes), ...]; VM, table build and upload run inside the workers."""
+        n = len(programs)
+        codes = (ctypes.c_char_p * max(n, 1))(*[c.encode() for c, _ in programs])
+        bufs = [ctypes.create_string_buffer(bytes(i), max(len(i), 1)) for _, i in programs]
+        inputs = (ctypes.c_void_p * max(n, 1))(*[ctypes.addressof(b) for b in bufs])
+        nin = (ctypes.c_size_t * max(n, 1))(*[len(i) for _, i in programs])
+        js, lens, st, sec = self._outputs(n, want_json)
+        rc = lib().bfhip_prove_batch_brainfuck(self._h, codes, inputs, nin, n, log_max_rows, js, lens, st, sec)
+        return self._collect(rc, n, js, lens, st, sec, want_json)
 
 
 PHASES = ("preprocessed", "tables_host", "main_trace", "interaction", "composition", "oods", "quotients", "fri", "decommit", "total")

@@ -19,8 +19,12 @@ void bfhip_set_error(const std::string& s) { g_err = s; }
 namespace bf {
 
 void Ctx::ensure_aux() { for (auto& a : aux) if (!a) BF_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking)); }
+void Ctx::ensure_side() { if (!stream2) BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking)); }
 
-void Ctx::init(int dev, u32 max_log_domain) {
+// A throw anywhere in here leaves a partially built context: the caller (bfhip_ctx_create, pool.hip) lets the destructor run destroy(), which
+// releases exactly what exists (r06; before, a failed creation — e.g. out of memory at the twiddle tree — leaked its streams, events, pinned
+// buffers and device allocations).
+void Ctx::init(int dev, u32 max_log_domain, const Ctx* tables_from) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device: the bfhip backend has no CPU fallback");
     if (dev < 0 || dev >= n) throw HipError("bad device id");
@@ -29,14 +33,15 @@ void Ctx::init(int dev, u32 max_log_domain) {
     device = dev;
     BF_HIP(hipSetDevice(dev));
     BF_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    BF_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
     id_main = stream;
     if (const char* v = getenv("BFHIP_SYNC")) sync_blocking = v[0] == 'b';
     if (const char* v = getenv("BFHIP_SINGLE_STREAM")) single_stream = atoi(v) != 0;
     if (const char* v = getenv("BFHIP_OVERLAP")) { overlap = (u32)atoi(v) & 7u; overlap_user_set = true; }
     if (const char* v = getenv("BFHIP_MAILBOX")) mailbox_mode = atoi(v) != 0 ? 1 : 0;
     if (const char* v = getenv("BFHIP_MAILBOX_TIMEOUT_MS")) mailbox_timeout = std::max(1, atoi(v)) * 1e-3;
+#ifdef BFHIP_TEST_HOOKS      // libbfhip_testhooks.so only (Makefile): the late-host path of the mailboxes needs a host that is late on purpose
     if (const char* v = getenv("BFHIP_MAILBOX_TEST_DELAY_MS")) mailbox_test_delay_ms = std::max(0, atoi(v));
+#endif
     if (overlap) ensure_aux();      // the partner streams exist only for contexts that use them (ctx.h: ensure_aux)
     for (auto& e : evp) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : reap_ev) BF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -51,6 +56,16 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipMalloc((void**)&d_stage, stage_bytes));
     BF_HIP(hipMalloc((void**)&d_counters, 4 * 64 * sizeof(u32)));
     BF_HIP(hipMemset(d_counters, 0, 4 * 64 * sizeof(u32)));
+    tw_root_log = max_log_domain - 1;
+    if (tables_from) {
+        // sub-context of a pool: the twiddle tree and the point tables are read-only after creation and the same for every context of a device
+        if (tables_from->device != dev) throw HipError("shared tables live on another device");
+        if (tables_from->tw_root_log < tw_root_log || !tables_from->d_tw) throw HipError("shared twiddle tree is too small");
+        owns_tables = false;
+        tw_root_log = tables_from->tw_root_log;      // a tree rooted higher serves every smaller domain (the layers nest: SURVEY.md B.2 item 9)
+        d_tw = tables_from->d_tw; d_itw = tables_from->d_itw; d_tlo = tables_from->d_tlo; d_thi = tables_from->d_thi;
+        return;
+    }
     // point tables: G^a and G^(b << 16) for the M31 circle generator G = (2, 1268011823)
     std::vector<uint2> tlo(1 << 16), thi(1 << 15);
     auto mulp = [](uint2 p, uint2 q) { return uint2{m_sub(m_mul(p.x, q.x), m_mul(p.y, q.y)), m_add(m_mul(p.x, q.y), m_mul(p.y, q.x))}; };
@@ -63,7 +78,6 @@ void Ctx::init(int dev, u32 max_log_domain) {
     BF_HIP(hipMalloc((void**)&d_thi, thi.size() * sizeof(uint2)));
     BF_HIP(hipMemcpy(d_tlo, tlo.data(), tlo.size() * sizeof(uint2), hipMemcpyHostToDevice));
     BF_HIP(hipMemcpy(d_thi, thi.data(), thi.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    tw_root_log = max_log_domain - 1;
     BF_HIP(hipMalloc((void**)&d_tw, sizeof(u32) << tw_root_log));
     BF_HIP(hipMalloc((void**)&d_itw, sizeof(u32) << tw_root_log));
     gen_twiddles(stream, d_tw, d_itw, tw_root_log, d_tlo, d_thi);
@@ -72,23 +86,30 @@ void Ctx::init(int dev, u32 max_log_domain) {
 }
 
 void Ctx::destroy() {
+    if (stream || stream2 || h_stage || h_small || d_stage) (void)hipSetDevice(device);      // may run on any thread (a destructor)
     if (stream) (void)hipStreamSynchronize(stream);
     if (stream2) (void)hipStreamSynchronize(stream2);
     for (auto& a : aux) if (a) { (void)hipStreamSynchronize(a); prof_forget(a); (void)hipStreamDestroy(a); a = nullptr; }
     for (auto& e : evp) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : reap_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     shard = ShardGroup();
+    shared_pre = nullptr;
     if (stream) prof_forget(stream);
     if (stream2) prof_forget(stream2);
     arena.release();
-    (void)hipFree(d_counters); (void)hipFree(d_tw); (void)hipFree(d_itw); (void)hipFree(d_tlo); (void)hipFree(d_thi); (void)hipFree(d_stage);
-    if (h_stage) (void)hipHostFree(h_stage);
-    if (h_small) (void)hipHostFree(h_small);
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    auto dfree = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    dfree(d_counters); dfree(d_stage);
+    if (owns_tables) { dfree(d_tw); dfree(d_itw); dfree(d_tlo); dfree(d_thi); }
+    else d_tw = d_itw = nullptr, d_tlo = d_thi = nullptr;
+    if (h_stage) { (void)hipHostFree(h_stage); h_stage = nullptr; }
+    if (h_small) { (void)hipHostFree(h_small); h_small = nullptr; }
+    d_small_alias = d_hstage_alias = nullptr;
+    for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sync_ev) { (void)hipEventDestroy(sync_ev); sync_ev = nullptr; }
     if (block_ev) { (void)hipEventDestroy(block_ev); block_ev = nullptr; }
-    if (stream2) (void)hipStreamDestroy(stream2);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
+    if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+    id_main = nullptr;
 }
 
 }  // namespace bf
@@ -99,15 +120,30 @@ const char* bfhip_last_error(void) { return g_err.c_str(); }
 
 int32_t bfhip_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+int32_t bfhip_device_memory(int32_t device_id, uint64_t* free_bytes, uint64_t* total_bytes) {
+    API_TRY
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device: the bfhip backend has no CPU fallback");
+    if (device_id < 0 || device_id >= n) throw HipError("bad device id");
+    BF_HIP(hipSetDevice(device_id));
+    size_t f = 0, t = 0;
+    BF_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+    API_CATCH
+}
+
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out) {
     API_TRY
+    if (!out) throw HipError("null argument");
     auto* c = new bfhip_ctx();
-    try { c->c.init(device_id, max_log_domain); } catch (...) { delete c; throw; }
+    try { c->c.init(device_id, max_log_domain); } catch (...) { delete c; throw; }     // ~Ctx releases whatever init() had created
     *out = c;
     return 0;
     API_CATCH
 }
-int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); ctx->c.destroy(); delete ctx; } return 0; API_CATCH }
+int32_t bfhip_ctx_destroy(bfhip_ctx* ctx) { API_TRY if (ctx) { bfhip_ctx_reuse_preprocessed(ctx, 0); delete ctx; } return 0; API_CATCH }
 // ---- shard groups: one proof over several GPUs (comm.h) ------------------------------------------------------------------------------
 struct bfhip_local_group { std::shared_ptr<LocalGroup> g; uint32_t count; };
 static void join_group(bfhip_ctx* ctx, std::unique_ptr<Comm> comm) {
@@ -240,10 +276,14 @@ int32_t bfhip_ctx_set_conventions(bfhip_ctx* ctx, const bfhip_conventions* conv)
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking) { API_CTX(ctx) ctx->c.sync_blocking = blocking != 0; return 0; API_CATCH }
 int32_t bfhip_ctx_set_mailbox(bfhip_ctx* ctx, int32_t mode, uint32_t timeout_ms, int32_t test_delay_ms) {
     API_CTX(ctx)
-    if (mode < -1 || mode > 1) throw HipError("bfhip_ctx_set_mailbox: mode must be -1, 0 or 1");
-    ctx->c.mailbox_mode = mode;
+    if (mode < -2 || mode > 1) throw HipError("bfhip_ctx_set_mailbox: mode must be -2 (keep), -1, 0 or 1");
+    if (mode != -2) ctx->c.mailbox_mode = mode;
     if (timeout_ms) ctx->c.mailbox_timeout = timeout_ms * 1e-3;
+#ifdef BFHIP_TEST_HOOKS
     if (test_delay_ms >= 0) ctx->c.mailbox_test_delay_ms = test_delay_ms;
+#else
+    if (test_delay_ms > 0) throw HipError("bfhip_ctx_set_mailbox: test_delay_ms needs the test-hooks build of the library (libbfhip_testhooks.so)");
+#endif
     return 0;
     API_CATCH
 }
@@ -262,7 +302,7 @@ int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]) {
     if (!out) throw HipError("null argument");
     uint64_t reserved = 0;
     for (auto& ch : ctx->c.arena.chunks) reserved += ch.size;
-    out[0] = reserved; out[1] = ctx->c.arena.peak; out[2] = (uint64_t)(2 * sizeof(u32)) << ctx->c.tw_root_log; out[3] = ctx->c.arena.total_used;
+    out[0] = reserved; out[1] = ctx->c.arena.peak; out[2] = ctx->c.owns_tables ? (uint64_t)(2 * sizeof(u32)) << ctx->c.tw_root_log : 0;      // a pool's sub-contexts borrow the first one's out[3] = ctx->c.arena.total_used;
     return 0;
     API_CATCH
 }

@@ -327,16 +327,27 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
-    // Only a test double exports this (tests/mock_rccl.c, selected with BFHIP_RCCL_LIBRARY): copies between HOST buffers, so that
-    // RcclComm's bookkeeping can be driven on a box without a GPU. The real transport copies a block to oneself with hipMemcpyAsync.
+#ifdef BFHIP_TEST_HOOKS
+    // libbfhip_testhooks.so only. A test double exports this (tests/mock_rccl.c, selected with BFHIP_RCCL_LIBRARY): copies between HOST buffers,
+    // so that RcclComm's bookkeeping can be driven on a box without a GPU. The real transport copies a block to oneself with hipMemcpyAsync.
     int (*MockSelfCopy)(void*, const void*, size_t) = nullptr;
+#endif
 };
+// The default build loads librccl and nothing else. The test-hooks build (-DBFHIP_TEST_HOOKS, libbfhip_testhooks.so) lets the environment
+// name a stand-in for the RCCL entry points: an environment variable that makes a library dlopen an arbitrary path has no place in a release.
+static const char* rccl_library_override() {
+#ifdef BFHIP_TEST_HOOKS
+    return getenv("BFHIP_RCCL_LIBRARY");
+#else
+    return nullptr;
+#endif
+}
 static RcclApi& rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        if (const char* over = getenv("BFHIP_RCCL_LIBRARY")) api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);      // a test double of the 10 entry points
+        if (const char* over = rccl_library_override()) api.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);      // a test double of the 10 entry points
         else for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
         if (!api.lib) return;
         auto sym = [&](const char* n) { return dlsym(api.lib, n); };
@@ -352,7 +363,9 @@ static RcclApi& rccl() {
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
         api.CommGetAsyncError = (decltype(api.CommGetAsyncError))sym("ncclCommGetAsyncError");
         api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
+#ifdef BFHIP_TEST_HOOKS
         api.MockSelfCopy = (decltype(api.MockSelfCopy))sym("bfhip_mock_self_copy");
+#endif
     });
     if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.AllReduce || !api.Send || !api.Recv || !api.GroupStart || !api.GroupEnd)
         throw HipError("RCCL is not available (librccl.so.1 could not be loaded): a multi-process shard group needs it");
@@ -386,7 +399,7 @@ struct RcclComm : Comm {
     bool spans_devices() const override { return count > 1; }
     const char* transport() const override {
         // an overridden library path is visible to whoever asks which transport a group runs on (bfhip_ctx_group_info)
-        static const std::string over = [] { const char* v = getenv("BFHIP_RCCL_LIBRARY"); return v ? std::string("RCCL entry points from BFHIP_RCCL_LIBRARY=") + v : std::string(); }();
+        static const std::string over = [] { const char* v = rccl_library_override(); return v ? std::string("RCCL entry points from BFHIP_RCCL_LIBRARY=") + v : std::string(); }();
         return over.empty() ? "RCCL (one process per GPU, collectives on the context's stream over xGMI)" : over.c_str();
     }
     void all_gather(hipStream_t s, void* buf, size_t bpr) override {
@@ -412,8 +425,10 @@ struct RcclComm : Comm {
             if (!self_s[i]->bytes) continue;
             // host-memory blocks exist only behind the raw test entry (bfhip_rccl_exchange_raw: null stream) with a test double loaded; a
             // prover's exchange always carries its stream and always copies on the device, whatever library BFHIP_RCCL_LIBRARY named
-            if (!s && rccl().MockSelfCopy) { if (rccl().MockSelfCopy(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes) != 0) throw HipError("shard group: self copy failed"); }
-            else BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
+#ifdef BFHIP_TEST_HOOKS
+            if (!s && rccl().MockSelfCopy) { if (rccl().MockSelfCopy(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes) != 0) throw HipError("shard group: self copy failed"); continue; }
+#endif
+            BF_HIP(hipMemcpyAsync(self_r[i]->ptr, self_s[i]->ptr, self_s[i]->bytes, hipMemcpyDeviceToDevice, s));
         }
         BF_NCCL(rccl().GroupStart());
         for (auto& x : sends) if (x.peer != rank && x.bytes) BF_NCCL(rccl().Send(x.ptr, x.bytes, ncclUint8, (int)x.peer, comm, s));

@@ -49,7 +49,11 @@ struct Ctx {
     bool tables_on_gpu = true;      // where the 13 component tables are built (bfhip_ctx_set_table_builder)
     ShardGroup shard;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase
+    // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase. Created by the first proof that uses it
+    // (ensure_side): a pool worker whose proofs take the pool's shared preprocessed tree never does, and every stream a process creates takes a
+    // share of the few hardware queues (see aux below)
+    hipStream_t stream2 = nullptr;
+    void ensure_side();
     bool side_busy = false;         // work enqueued on stream2 may still read parameter blocks from the staging ring
     // Partner streams for overlap INSIDE a tree commitment: the VALU-bound Merkle layers of the largest columns run on the partner while the
     // HBM-bound transforms of the smaller columns continue on the stream itself (aux[0] beside the main stream, aux[1] beside the side stream).
@@ -82,6 +86,11 @@ struct Ctx {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries (GPU-side phase times without extra host syncs)
     u32 tw_root_log = 0;           // twiddle tree rooted at Coset::half_odds(tw_root_log)
     u32* d_tw = nullptr; u32* d_itw = nullptr;
+    // false: twiddle tree and point tables are another context's (the sub-contexts of a pool share the first one's: include/bfhip.h
+    // bfhip_pool_create) — read-only after creation, never freed here
+    bool owns_tables = true;
+    // Set by a pool for the duration of a batch (pool.hip): the preprocessed tree every proof of the batch takes instead of committing its own.
+    const struct SharedPreprocessed* shared_pre = nullptr;
     uint2* d_tlo = nullptr; uint2* d_thi = nullptr;   // G^a (a < 2^16) and G^(b << 16) (b < 2^15) point tables
     Arena arena;
     // pinned staging for pointer arrays / small parameter blocks
@@ -124,8 +133,12 @@ struct Ctx {
     void post_stamp(int k);           // enqueue: "everything before this point on the stream is done" -> stamp k = proof_seq
     void wait_stamp(int k);           // host: poll stamp k (with the stream's health checked now and then)
 
-    void init(int dev, u32 max_log_domain);
-    void destroy();
+    // tables_from != nullptr: a context on the same device whose twiddle tree (at least as large) and point tables this one borrows
+    void init(int dev, u32 max_log_domain, const Ctx* tables_from = nullptr);
+    void destroy();                 // idempotent: also what the destructor and a failed init() run
+    Ctx() = default;
+    Ctx(const Ctx&) = delete; Ctx& operator=(const Ctx&) = delete;
+    ~Ctx() { destroy(); }
     // HIP's current device is per host thread: every C-ABI entry binds the calling thread to this context's GPU first, so that
     // allocations (arena chunks, hipMalloc) land on the device the stream belongs to whichever thread drives the context.
     void bind() { BF_HIP(hipSetDevice(device)); }
@@ -204,7 +217,7 @@ struct Ctx {
             }
             // every stream of the context may still read parameter blocks from the ring (`stream` may currently be a partner stream)
             sync();
-            BF_HIP(hipStreamSynchronize(stream2));
+            if (stream2) BF_HIP(hipStreamSynchronize(stream2));
             if (id_main) BF_HIP(hipStreamSynchronize(id_main));
             for (auto a : aux) if (a) BF_HIP(hipStreamSynchronize(a));
             stage_used = 0;
@@ -225,6 +238,13 @@ struct Ctx {
 
 // Scope of one staging batch: blocks staged inside are moved by one copy at end(); an exception unwinds the batch without copying.
 void preprocessed_cache_invalidate(Ctx* c);   // prover.hip: called when the context joins or leaves a shard group
+// prover.hip, for pool.hip: the preprocessed tree a pool's builder context commits once for all proofs of a batch (Ctx::shared_pre)
+struct SharedPreprocessed;
+SharedPreprocessed* shared_preprocessed_create(Ctx& builder);
+void shared_preprocessed_destroy(SharedPreprocessed* sp);
+bool shared_preprocessed_matches(const SharedPreprocessed* sp, const Ctx& c, u32 log_max_rows);
+void shared_preprocessed_build(SharedPreprocessed* sp, Ctx& builder, u32 log_max_rows);      // enqueues, records sp->ready, returns without waiting
+void shared_preprocessed_invalidate(SharedPreprocessed* sp);
 
 void mailbox_launch(hipStream_t s, const u32* d_flag, u32 expect, const void* src_pinned_alias, void* dst, size_t bytes, u32* d_err, double timeout_seconds);
 void post_stamp_launch(hipStream_t s, u32* d_stamp, u32 value);

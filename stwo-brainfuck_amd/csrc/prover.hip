@@ -125,6 +125,21 @@ void preprocessed_cache_invalidate(Ctx* c) {
     if (it != preprocessed_caches().end()) it->second.valid = false;
 }
 
+// A pool's shared preprocessed tree (include/bfhip.h: bfhip_pool_*; pool.hip): committed ONCE per batch (or once per pool) by the pool's
+// builder context and read by every proof of the batch instead of being recommitted by each — byte-neutral, the tree depends on LOG_MAX_ROWS
+// and the hasher only. The builder enqueues the commitment and records `ready` behind it BEFORE the workers are woken; a proof copies the
+// layout at its start and waits (host side) for `ready` where it would have joined its own side stream, so the commitment runs beside the
+// batch's first main-trace phases like a proof's own would.
+struct SharedPreprocessed {
+    bool valid = false; u32 lmr = 0, node_conv = 0, channel = 0;
+    DTree tree;                         // storage: the builder context's arena (not reset while a batch can read it)
+    hipEvent_t ready = nullptr;         // recorded on the builder's stream behind the tree (and the root's copy into pinned memory)
+    const Hash32* pinned_root = nullptr;
+    bool matches(const Ctx& c, u32 log_max_rows) const {
+        return valid && lmr == log_max_rows && node_conv == c.conv.merkle_node_hash && channel == c.conv.merkle_channel && c.shard.count == 1;
+    }
+};
+
 struct PhaseTimes { double preprocessed = 0, main_trace = 0, interaction = 0, composition = 0, oods = 0, quotients = 0, fri = 0, decommit = 0, tables = 0, total = 0; };
 
 struct HipProver {
@@ -695,6 +710,45 @@ struct HipProver {
         c.sync();
     }
 
+    // Phase 0 of prove_brainfuck: the preprocessed tree IsFirst(LOG_MAX_ROWS ..= LOG_N_LANES) (mod.rs:495-500) — polynomials in closed form,
+    // LDE, Merkle tree; the root goes to *pinned_root behind the tree (no host wait). Storage from the context's current arena.
+    void build_preprocessed(DTree& tree, Hash32* pinned_root) {
+        for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
+            DCol p; p.log_size = log; p.shift = 0; p.ptr = nullptr;
+            tree.polys.push_back(p);
+        }
+        // shard group: the big IsFirst columns are column-sharded like the interaction tree's (owner interpolates and extends,
+        // every rank receives its row range of the LDE)
+        tree.owner = assign_owners(tree.polys, cfg.log_blowup);
+        // interpolate(gen_is_first(log)) for every size in closed form, one launch (fft.hip: k_is_first_coeffs)
+        IsFirstCols ifc{}; ifc.log_min = LOG_N_LANES; ifc.log_max = log_max_rows;
+        if (log_max_rows - LOG_N_LANES >= 28) throw HipError("log_max_rows too large");
+        for (size_t i = 0; i < tree.polys.size(); i++) {
+            if (tree.owner[i] != OWNER_ALL && tree.owner[i] != c.shard.rank) continue;
+            DCol& p = tree.polys[i];
+            p.ptr = c.alloc_u32(p.stored());
+            ifc.ptr[p.log_size - LOG_N_LANES] = p.ptr;
+        }
+        is_first_coeffs(c.stream, ifc, c.d_itw, c.tw_root_log);
+        if (sharded()) commit_tree(tree, pinned_root); else commit_tree_overlapped(tree, pinned_root);
+    }
+    // The pool's builder (pool.hip): commits the preprocessed tree on this (otherwise idle) context for every proof of a batch and returns
+    // without waiting — sp.ready is recorded behind the tree and the root's store into pinned memory.
+    void build_shared_preprocessed(SharedPreprocessed& sp) {
+        if (sharded()) throw HipError("pool: the builder context must not be a member of a shard group");
+        if (log_max_rows < LOG_N_LANES) throw HipError("log_max_rows must be at least LOG_N_LANES (4)");
+        if (log_max_rows + cfg.log_blowup + 1 > c.tw_root_log + 1) throw HipError("context twiddle tree too small for log_max_rows");
+        sp.valid = false;
+        c.sync();                       // nothing of an earlier batch's build is in flight (its readers are done: the pool's batches are serial)
+        c.arena.reset(); c.stage_used = 0; c.use_mailbox = false;
+        BF_HIP(hipMemsetAsync(c.d_counters, 0, 4 * 64 * sizeof(u32), c.stream));
+        sp.tree = DTree();
+        Hash32* root = reinterpret_cast<Hash32*>(c.h_small);
+        build_preprocessed(sp.tree, root);
+        BF_HIP(hipEventRecord(sp.ready, c.stream));
+        sp.pinned_root = root; sp.lmr = log_max_rows; sp.node_conv = c.conv.merkle_node_hash; sp.channel = c.conv.merkle_channel; sp.valid = true;
+    }
+
     BrainfuckProof prove(const TraceInput& in) { return prove([&]() -> const TraceInput& { return in; }); }
 
     // get_input() runs on the host AFTER the (trace-independent) preprocessed phase has been enqueued, so a caller that still has to
@@ -726,7 +780,7 @@ struct HipProver {
         if (++c.proof_seq == 0) c.proof_seq = 1;
         c.reap_some();
         if (mb && c.stage_used > c.stage_bytes / 4) {
-            c.sync(); BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a));
+            c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a));
             c.stage_used = 0;
         }
         for (int k = 0; k <= 5; k++) c.mailbox_err_host()[2 * k] = 0;
@@ -745,37 +799,24 @@ struct HipProver {
         PreprocessedCache& cache = preprocessed_cache_of(&c);
         Hash32* pinned_root0 = reinterpret_cast<Hash32*>(c.h_small);
         Hash32* pinned_root1 = pinned_root0 + 1;
-        const bool reuse = cache.matches(c, log_max_rows);
+        // a pool's batch (pool.hip): the tree its builder context commits once for all proofs of the batch
+        const SharedPreprocessed* shared = c.shared_pre && c.shared_pre->matches(c, log_max_rows) ? c.shared_pre : nullptr;
+        const bool reuse = shared || cache.matches(c, log_max_rows);
         BF_HIP(hipMemsetAsync(c.d_counters, 0, 4 * 64 * sizeof(u32), c.stream));      // ticket counters (a failed proof may have left one mid-count)
         BF_HIP(hipEventRecord(c.ev[0], c.stream));
         // In a shard group everything stays on the main stream: the group's exchanges are issued in one order on one stream per rank.
         const bool use_side = !sharded() && !c.single_stream;
-        if (reuse) trees[0] = cache.tree;
+        if (shared) trees[0] = shared->tree;        // layout only: complete (and its root known) once shared->ready has completed — awaited below
+        else if (reuse) trees[0] = cache.tree;
         else {
             if (use_side) {
+                c.ensure_side();
                 BF_HIP(hipStreamWaitEvent(c.stream2, c.ev[0], 0));   // stream2 starts after whatever preceded this proof on the main stream
                 std::swap(c.stream, c.stream2); c.side_busy = true;
             }
             try {
                 if (cache.enabled) { cache.keep.reset(); std::swap(c.arena, cache.keep); }   // build the tree in memory that survives arena.reset()
-                for (u32 log = log_max_rows; log >= LOG_N_LANES; log--) {
-                    DCol p; p.log_size = log; p.shift = 0; p.ptr = nullptr;
-                    trees[0].polys.push_back(p);
-                }
-                // shard group: the big IsFirst columns are column-sharded like the interaction tree's (owner interpolates and extends,
-                // every rank receives its row range of the LDE)
-                trees[0].owner = assign_owners(trees[0].polys, cfg.log_blowup);
-                // interpolate(gen_is_first(log)) for every size in closed form, one launch (fft.hip: k_is_first_coeffs)
-                IsFirstCols ifc{}; ifc.log_min = LOG_N_LANES; ifc.log_max = log_max_rows;
-                if (log_max_rows - LOG_N_LANES >= 28) throw HipError("log_max_rows too large");
-                for (size_t i = 0; i < trees[0].polys.size(); i++) {
-                    if (trees[0].owner[i] != OWNER_ALL && trees[0].owner[i] != c.shard.rank) continue;
-                    DCol& p = trees[0].polys[i];
-                    p.ptr = c.alloc_u32(p.stored());
-                    ifc.ptr[p.log_size - LOG_N_LANES] = p.ptr;
-                }
-                is_first_coeffs(c.stream, ifc, c.d_itw, c.tw_root_log);
-                if (sharded()) commit_tree(trees[0], pinned_root0); else commit_tree_overlapped(trees[0], pinned_root0);
+                try { build_preprocessed(trees[0], pinned_root0); } catch (...) { if (cache.enabled) std::swap(c.arena, cache.keep); throw; }
                 if (cache.enabled) std::swap(c.arena, cache.keep);
                 BF_HIP(hipEventRecord(c.ev[1], c.stream));
             } catch (...) { if (use_side) { std::swap(c.stream, c.stream2); (void)hipStreamSynchronize(c.stream2); c.side_busy = false; } throw; }
@@ -896,6 +937,21 @@ struct HipProver {
         } catch (...) { join_side(); throw; }
         join_side();
         mark("side stream joined");
+        if (shared) {
+            // The batch's tree: its commitment was enqueued on the builder's stream before this proof started. Nothing of this proof has read it
+            // yet; from here on the constraint, sampling, quotient and decommitment launches do, so the host waits for it here (normally long done).
+            const auto w0 = std::chrono::steady_clock::now();
+            for (u32 polls = 0;; polls++) {
+                hipError_t e = hipEventQuery(shared->ready);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) BF_HIP(e);
+                if (polls > 64) std::this_thread::yield();
+                if ((polls & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() > 120.0)
+                    throw HipError("pool: the batch's shared preprocessed commitment did not complete");
+            }
+            trees[0].mk.root = *shared->pinned_root;
+            mark("shared preprocessed tree ready");
+        }
         if (!reuse) {
             trees[0].mk.root = *pinned_root0;
             if (cache.enabled) {
@@ -1889,6 +1945,21 @@ struct HipProver {
     }
 };
 
+// ---- what pool.hip needs of the prover (declared in ctx.h) ----------------------------------------------------------------------------
+SharedPreprocessed* shared_preprocessed_create(Ctx& builder) {
+    auto* sp = new SharedPreprocessed();
+    try { builder.bind(); BF_HIP(hipEventCreateWithFlags(&sp->ready, hipEventDisableTiming)); } catch (...) { delete sp; throw; }
+    return sp;
+}
+void shared_preprocessed_destroy(SharedPreprocessed* sp) { if (sp) { if (sp->ready) (void)hipEventDestroy(sp->ready); delete sp; } }
+bool shared_preprocessed_matches(const SharedPreprocessed* sp, const Ctx& c, u32 log_max_rows) { return sp && sp->matches(c, log_max_rows); }
+void shared_preprocessed_build(SharedPreprocessed* sp, Ctx& builder, u32 log_max_rows) {
+    builder.bind();
+    HipProver pv(builder, log_max_rows);
+    try { pv.build_shared_preprocessed(*sp); } catch (...) { sp->valid = false; (void)hipStreamSynchronize(builder.stream); throw; }
+}
+void shared_preprocessed_invalidate(SharedPreprocessed* sp) { if (sp) sp->valid = false; }
+
 }  // namespace bf
 
 using namespace bf;
@@ -2114,11 +2185,11 @@ extern "C" int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, cons
 // Profiler state is per stream, i.e. per context: contexts on other threads are not affected (prof.hip).
 static void sync_both(Ctx& c) { c.sync(); if (c.stream2) BF_HIP(hipStreamSynchronize(c.stream2)); for (auto a : c.aux) if (a) BF_HIP(hipStreamSynchronize(a)); }
 extern "C" int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode) {
-    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); for (auto a : ctx->c.aux) if (a) prof_enable(a, mode); return 0; }
+    try { if (!ctx) throw HipError("null context"); if (mode < 0 || mode > 2) throw HipError("bad profile mode"); ctx->c.bind(); ctx->c.ensure_side(); sync_both(ctx->c); prof_enable(ctx->c.stream, mode); prof_enable(ctx->c.stream2, mode); for (auto a : ctx->c.aux) if (a) prof_enable(a, mode); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_reset(bfhip_ctx* ctx) {
-    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); prof_reset(ctx->c.stream2); for (auto a : ctx->c.aux) if (a) prof_reset(a); return 0; }
+    try { if (!ctx) throw HipError("null context"); ctx->c.bind(); sync_both(ctx->c); prof_reset(ctx->c.stream); if (ctx->c.stream2) prof_reset(ctx->c.stream2); for (auto a : ctx->c.aux) if (a) prof_reset(a); return 0; }
     catch (const std::exception& e) { bfhip_set_error(e.what()); return -1; }
 }
 extern "C" int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json) {

@@ -34,16 +34,29 @@ def pytest_generate_tests(metafunc):
         metafunc.parametrize("conv", ["stwo"] if single else names, indirect=True, scope="function")
 
 
-def load_package():
-    """Import the hyphenated package directory `stwo-brainfuck_amd/` under the module name stwo_brainfuck_amd."""
-    name = "stwo_brainfuck_amd"
+def load_package(name="stwo_brainfuck_amd", library=None):
+    """Import the hyphenated package directory `stwo-brainfuck_amd/` under the module name stwo_brainfuck_amd.
+    library: bind this copy of the mirror to another build of the library (the mirror reads BFHIP_LIBRARY when it is imported)."""
     if name in sys.modules:
         return sys.modules[name]
     spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "stwo-brainfuck_amd", "__init__.py"))
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
-    spec.loader.exec_module(mod)
+    saved = os.environ.get("BFHIP_LIBRARY")
+    if library:
+        os.environ["BFHIP_LIBRARY"] = library
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        if library:
+            if saved is None:
+                os.environ.pop("BFHIP_LIBRARY", None)
+            else:
+                os.environ["BFHIP_LIBRARY"] = saved
     return mod
+
+
+TESTHOOKS_LIBRARY = os.path.join(ROOT, "stwo-brainfuck_amd", "libbfhip_testhooks.so")
 
 
 class Oracle:
@@ -208,6 +221,15 @@ def pkg():
     if not os.path.exists(lib_path):   # normally built by __graft_entry__.build(); hipcc cross-compiles gfx950 without a GPU
         subprocess.check_call(["make", "-j", "8", "-C", os.path.join(ROOT, "stwo-brainfuck_amd", "csrc")])
     return load_package()
+
+
+@pytest.fixture(scope="session")
+def hooks_pkg(pkg):
+    """A second copy of the Python mirror bound to libbfhip_testhooks.so — the -DBFHIP_TEST_HOOKS build of the library (csrc/Makefile): the only
+    build in which BFHIP_MAILBOX_TEST_DELAY_MS / set_mailbox(test_delay_ms) and BFHIP_RCCL_LIBRARY exist. Tests of those paths use it; everything
+    else runs on the default library, which has no test hooks."""
+    assert os.path.exists(TESTHOOKS_LIBRARY), "libbfhip_testhooks.so is missing: make -C stwo-brainfuck_amd/csrc"
+    return load_package("stwo_brainfuck_amd_testhooks", TESTHOOKS_LIBRARY)
 
 
 @pytest.fixture(scope="session")

@@ -8,7 +8,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, TESTHOOKS_LIBRARY
 
 
 def declared_symbols():
@@ -23,6 +23,23 @@ def test_library_exports_every_declared_symbol(pkg):
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(L, s), f"libbfhip.so does not export {s}"
+
+
+def test_default_library_has_no_test_hooks():
+    """The release build must not contain the test hooks: no lookup of a mock's symbol, no environment variable that makes it
+    dlopen an arbitrary path, no host delay for the mailboxes. The hooks build (same sources, -DBFHIP_TEST_HOOKS in api.hip / comm.hip) has them and
+    exports the same entry points."""
+    pkg_dir = os.path.join(ROOT, "stwo-brainfuck_amd")
+    blob = open(os.path.join(pkg_dir, "libbfhip.so"), "rb").read()
+    for needle in (b"bfhip_mock_self_copy", b"BFHIP_RCCL_LIBRARY", b"BFHIP_MAILBOX_TEST_DELAY_MS"):
+        assert needle not in blob, f"the default libbfhip.so contains the test hook {needle!r}"
+    assert b"mock" not in blob.lower().replace(b"mockingbird", b""), "the default libbfhip.so mentions a mock"
+    hooks = open(TESTHOOKS_LIBRARY, "rb").read()
+    for needle in (b"bfhip_mock_self_copy", b"BFHIP_RCCL_LIBRARY", b"BFHIP_MAILBOX_TEST_DELAY_MS"):
+        assert needle in hooks
+    H = ctypes.CDLL(TESTHOOKS_LIBRARY)
+    for s in declared_symbols():
+        assert hasattr(H, s), f"libbfhip_testhooks.so does not export {s}"
 
 
 def test_header_cites_reference_lines():
@@ -158,12 +175,21 @@ def test_host_entries_survive_null_and_invalid_arguments():
             "trace_destroy_null": lambda: L.bfhip_trace_destroy(None, None),
             "free_host_null": lambda: L.bfhip_free_host(None),
             "component_shape_null": lambda: L.bfhip_component_shape(0, None, None, None),
+            "ctx_create_null_out": lambda: L.bfhip_ctx_create(0, 20, None),
+            "pool_create_null_out": lambda: L.bfhip_pool_create(0, 2, 20, None),
+            "pool_create_zero": lambda: L.bfhip_pool_create(0, 0, 20, ctypes.byref(ctypes.c_void_p())),
+            "pool_destroy_null": lambda: L.bfhip_pool_destroy(None),
+            "pool_batch_null": lambda: L.bfhip_prove_batch(None, None, 0, 20, None, None, None, None),
+            "pool_programs_null": lambda: L.bfhip_prove_batch_brainfuck(None, None, None, None, 0, 20, None, None, None, None),
+            "pool_ctx_null": lambda: L.bfhip_pool_ctx(None, 0, None),
         }
         print(calls[sys.argv[1]]())
     """) % os.path.join(root, "tests")
-    expect = {"compile_null": -1, "run_null_code": -1, "table_bad_component": -1, "verify_null": 1, "verify_no_error_buffer": 1}
+    expect = {"compile_null": -1, "run_null_code": -1, "table_bad_component": -1, "verify_null": 1, "verify_no_error_buffer": 1, "ctx_create_null_out": -1,
+              "pool_create_null_out": -1, "pool_create_zero": -1, "pool_destroy_null": 0, "pool_batch_null": -1, "pool_programs_null": -1, "pool_ctx_null": -1}
     for name in ["compile_null", "run_null_code", "run_null_counts", "table_null", "table_bad_component", "verify_null", "verify_no_error_buffer",
-                 "ctx_destroy_null", "trace_destroy_null", "free_host_null", "component_shape_null"]:
+                 "ctx_destroy_null", "trace_destroy_null", "free_host_null", "component_shape_null", "ctx_create_null_out", "pool_create_null_out",
+                 "pool_create_zero", "pool_destroy_null", "pool_batch_null", "pool_programs_null", "pool_ctx_null"]:
         r = subprocess.run([sys.executable, "-c", prog, name], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, (name, r.returncode, r.stderr[-300:])
         if name in expect:
@@ -231,7 +257,8 @@ def test_rccl_exchange_bookkeeping_through_a_mock_library(tmp_path):
                 uid = (ctypes.c_uint8 * 128)(); assert L.bfhip_rccl_unique_id(uid) == 0     # a fresh group for the failing round
         print("ok")
     """) % os.path.join(root, "tests")
-    env = dict(os.environ, BFHIP_RCCL_LIBRARY=str(mock))
+    # BFHIP_RCCL_LIBRARY is a test hook: only libbfhip_testhooks.so (-DBFHIP_TEST_HOOKS) reads it
+    env = dict(os.environ, BFHIP_RCCL_LIBRARY=str(mock), BFHIP_LIBRARY=TESTHOOKS_LIBRARY)
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
 

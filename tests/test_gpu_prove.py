@@ -486,12 +486,13 @@ def test_overlap_modes_do_not_change_the_proof(pkg, oracle):
 
 
 @pytest.mark.single_conv
-def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pkg, oracle, monkeypatch):
+def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pkg, hooks_pkg, oracle, monkeypatch):
     """csrc/mailbox.hip: for proofs with LOG_MAX_ROWS <= 21 (or with BFHIP_MAILBOX=1) the launches behind a Fiat-Shamir point are on the stream before
     the host knows the challenge (a one-workgroup kernel waits for the host's flag and copies the challenge-dependent tables); BFHIP_MAILBOX=0
     (and larger proofs) keep wait -> compute -> copy -> launch.
     Same bytes either way. A host that is later than the kernel's patience (1 ms of patience, 30 ms of test delay before every post) must end
-    in an ERROR — the kernels ran on stale challenge words — never in a hang or in a proof, and the context proves correctly afterwards."""
+    in an ERROR — the kernels ran on stale challenge words — never in a hang or in a proof, and the context proves correctly afterwards.
+    The delay is a test hook: it exists only in libbfhip_testhooks.so (hooks_pkg); the default library refuses it."""
     code = _prog("collatz.bf")
     want, _, _ = oracle.prove(code, b"7\n", log_max_rows=21)
     for env in ("1", "0"):
@@ -505,6 +506,15 @@ def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pk
     monkeypatch.setenv("BFHIP_MAILBOX", "1")
     monkeypatch.setenv("BFHIP_MAILBOX_TIMEOUT_MS", "1")
     monkeypatch.setenv("BFHIP_MAILBOX_TEST_DELAY_MS", "30")
+    c = pkg.Context(0, max_log_domain=23)       # the default library: the environment's test delay does not exist there
+    try:
+        with pytest.raises(pkg.BfhipError, match="test-hooks build"):
+            c.set_mailbox(1, 10000, 30)
+        c.set_mailbox(1, 10000, -1)
+        assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want
+    finally:
+        c.close()
+    pkg = hooks_pkg                              # from here on: the test-hooks build
     c = pkg.Context(0, max_log_domain=23)
     try:
         # the error names its cause (a late host), not the constraint mismatch the stale challenge words produce

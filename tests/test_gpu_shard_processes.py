@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROGS = os.path.join(ROOT, "tests", "golden", "programs")
+# BFHIP_RCCL_LIBRARY (the RCCL double) is a test hook: only the -DBFHIP_TEST_HOOKS build of the library reads it (csrc/Makefile)
+TESTHOOKS_LIBRARY = os.path.join(ROOT, "stwo-brainfuck_amd", "libbfhip_testhooks.so")
 
 
 def build_ipc_double():
@@ -43,7 +45,7 @@ def start_ranks(tmp_path, world, program, inp, lmr, proofs=1, extra_env=None, co
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+                   BFHIP_RCCL_LIBRARY=build_ipc_double(), BFHIP_LIBRARY=TESTHOOKS_LIBRARY, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         out = str(tmp_path / f"rank{r}.json")
         log = open(str(tmp_path / f"rank{r}.log"), "w")
         p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), "--program", os.path.join(PROGS, program), "--input-hex", inp.hex(),
@@ -149,7 +151,7 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     device 0 through the process-per-rank double, torch.distributed over gloo), and rank 0's ONE line reports n_gpus 2, scaling "strong", the
     group's proof with the SHA-256 of the one-GPU proof, the replicas beside it."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), BFHIP_LIBRARY=TESTHOOKS_LIBRARY, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
                         "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "900"], env=env, capture_output=True, text=True, timeout=1000)
     for f in glob.glob("/dev/shm/bfhip_mock_*"):
@@ -172,7 +174,7 @@ def test_bench_prints_the_replicas_line_when_the_group_never_comes_back():
     """--group-timeout: a shard group that does not finish in time (here: a limit of 0 s) cannot be interrupted — rank 0 prints the replicas line it measured
     before the group formed (contract protocol, K steps), flagged with shard_group_error, and every rank leaves with code 0: a multi-GPU run always yields a line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), BFHIP_LIBRARY=TESTHOOKS_LIBRARY, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
                         "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--group-timeout", "0", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
     for f in glob.glob("/dev/shm/bfhip_mock_*"):
@@ -196,7 +198,7 @@ def test_bench_falls_back_to_the_replicas_when_the_group_cannot_be_formed(tmp_pa
     """The RCCL entry points cannot be loaded (BFHIP_RCCL_LIBRARY names a file that does not exist): joining fails on every rank, the ranks agree on that over
     torch.distributed, and the line is the replicas' (weak scaling) with shard_group_error saying why — exit code 0, one line."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(BFHIP_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"))
+    env.update(BFHIP_RCCL_LIBRARY=str(tmp_path / "no_such_librccl.so"), BFHIP_LIBRARY=TESTHOOKS_LIBRARY)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
                         "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
