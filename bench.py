@@ -11,21 +11,19 @@ N independent replicas (weak scaling, no data-path collective) ride in the `repl
 touches the GPU; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the launcher's. --gpus and
 WORLD_SIZE must agree.
 
-Prints ONE JSON line on rank 0 (driver contract). Checked and measured inside this run:
+This file holds the contract path only (W warm-up proofs, barrier, K timed proofs, barrier, MAX over ranks, ONE JSON line on rank 0); everything
+that rides beside it lives in tools/benchlib/ (one paragraph per module in its __init__.py). Checked and measured inside this run:
   parity_checked  SHA-256 of the last timed proof == the committed digest of the CPU oracle's proof of the same workload
-  roofline        dominant kernel, HIP events on the library's own stream over the timed region (k_merkle_layer: integer-VALU bound,
-                  Blake2s compressions counted from the launch shapes; HBM figure beside it)
-  fft             the circle-FFT kernels' moved and algorithmic GB/s (north-star figure), from one extra untimed, fully instrumented proof
-  sweep           synthetic nested-counter traces of 2^20..2^26 domain rows (BASELINE metric "at 2^22 rows": config.headline_2^22)
-  poseidon252     BASELINE config 5 on one GPU: the 2^26-row synthetic trace with the Poseidon252 MerkleChannel variant
-  strong_scaling  N > 1 only: per workload (fib19 = the headline; the synthetic 2^24-row trace of configs 3/4; the 2^26-row Poseidon252 trace of
-                  config 5) ms_per_proof over the group, the one-GPU time of the same proof in the same run, speedup_vs_n1, comm share, SHA-256
-  shard_group_single_process   N > 1 only: the same stages with ONE process driving all N GPUs over the in-process transport (peer copies),
-                  taken in a child process before the ranks touch their GPUs
-  cpu_baseline    the CPU oracle ("port") — see cpu_baseline()
+  roofline        dominant kernel, HIP events on the library's own stream over the timed region (k_merkle_layer: integer-VALU bound, Blake2s compressions
+                  counted from the launch shapes; HBM figure beside it); sustained_clock_ghz / frac_at_sustained_clock from the library's in-run clock probe
+  config          (the driver's record keeps `config` whole) metric_point = the metric's own size, 2^22 rows; batch = that size through the library's pool,
+                  one caller thread; sweep_ms = ms per proof at 2^20..2^26 rows
+  fft             the circle-FFT kernels against both of their bounds (HBM bytes moved; VALU lane-ops), from one extra untimed, fully instrumented proof
+  sweep, poseidon252, pipelined   the details behind config.*: synthetic traces 2^20..2^26, BASELINE config 5 on one GPU, proofs in flight per size
+  strong_scaling  N > 1 only: per workload ms_per_proof over the group, the one-GPU time of the same proof in the same run, speedup_vs_n1, comm share
+  cpu_baseline    the CPU oracle ("port") — tools/benchlib/cpu.py
 """
 import argparse
-import ctypes
 import hashlib
 import importlib.util
 import json
@@ -34,775 +32,18 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-
-# Integer-VALU roofline of the Blake2s kernel: one compression = 977 VALU lane-ops in the compiled kernel (v_add3_u32 / v_xor_b32 /
-# v_alignbit_b32; llvm-objdump of k_merkle_layer), and the chip retires 256 CU x 4 SIMD x 16 int lanes/clk x 2.4 GHz = 39.3 T such
-# lane-ops/s (half the fp32-FMA issue rate; tools/ubench_blake.hip measures 39.9 G compressions/s = 39.0 T lane-ops/s in registers).
-VALU_OPS_PER_COMPRESSION = 977
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
-
-FIB19 = "+++++++++++++++++>+>+<<[->>[->+>+<<]<[->>+<<]>>[-<+>]>[-<<<+>>>]<<<<]>>."  # tests/golden/programs/fib19.bf (workload input)
-
-# Synthetic padded traces: "+"*a "[>" "+"*b "[>+<-]<-]" — the Memory component lands exactly on
-# 2^k domain rows for (a, b) = (14, 250 * 2^(k-20)); proved with LOG_MAX_ROWS = k.
-SWEEP = {k: (14, 250 << (k - 20)) for k in range(20, 27)}
-
-
-def sweep_program(k):
-    a, b = SWEEP[k]
-    return "+" * a + "[>" + "+" * b + "[>+<-]<-]"
-
-
-def load_package():
-    name = "stwo_brainfuck_amd"
-    if name in sys.modules:
-        return sys.modules[name]
-    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "stwo-brainfuck_amd", "__init__.py"))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
-
-
-def kernel_sources_sha256():
-    """SHA-256 over the sources of the dominant kernel (what a committed counter file must have been measured on)."""
-    h = hashlib.sha256()
-    for rel in ("stwo-brainfuck_amd/csrc/merkle.hip", "stwo-brainfuck_amd/csrc/kernels.h", "stwo-brainfuck_amd/csrc/m31.h"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
-    return h.hexdigest()
-
-
-def committed_digests():
-    try:
-        return json.load(open(os.path.join(ROOT, "tests", "golden", "fib19_lmr24_oracle_proof.json")))
-    except Exception:
-        return {}
-
-
-def roofline_from_committed_rocprof(compressions_per_proof, launches_per_proof):
-    """frac_rocprof: k_merkle_layer's VALU fraction recomputed from the latest committed profiles/rNN_roofline_single_stream_kernel_stats.csv (average
-    launch duration by rocprofv3) — next to `frac` (HIP events of THIS run). The JSON line of the profiled run lies beside the CSV and carries the
-    SHA-256 of the kernel sources; a mismatch reports null with the reason. frac_range_this_round: min..max of `frac` over the round's committed lines."""
-    import csv
-    import glob
-    out = {"frac_rocprof": None, "frac_rocprof_source": None, "frac_range_this_round": None}
-    if not compressions_per_proof:
-        return out
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_roofline_single_stream_kernel_stats.csv")))
-    if not cands:
-        out["frac_rocprof_source"] = "no committed rocprofv3 summary (tools/profile_round.sh rNN roofline)"
-        return out
-    path = cands[-1]
-    rnd = os.path.basename(path).split("_")[0]
-    try:
-        line = json.loads(open(path.replace("_kernel_stats.csv", "_under_rocprof.json")).read().strip().split("\n")[-1])
-        if line["roofline"].get("kernel_sources_sha256") != kernel_sources_sha256():
-            out["frac_rocprof_source"] = os.path.relpath(path, ROOT) + " is STALE: taken on other kernel sources — rerun tools/profile_round.sh roofline"
-            return out
-        row = next(r for r in csv.DictReader(open(path)) if r["Name"].split("(")[0].replace("void ", "").replace("bf::", "") == "k_merkle_layer")
-        avg_us = float(row["AverageNs"]) / 1e3
-        ms_per_proof = avg_us * launches_per_proof / 1e3
-        out["frac_rocprof"] = round(compressions_per_proof * VALU_OPS_PER_COMPRESSION / (ms_per_proof * 1e-3) / 1e12 / VALU_PEAK_TOPS, 4)
-        out["avg_launch_us_rocprof"] = round(avg_us, 2)
-        out["frac_rocprof_source"] = (os.path.relpath(path, ROOT) + f": {row['Calls']} launches, average {avg_us:.1f} us (rocprofv3 --kernel-trace --stats of bench.py --steps 20 --warmup 5 "
-                                      "on one stream, same kernel sources; that run's own HIP events: frac " + str(line["roofline"].get("frac")) + ")")
-        fr = []
-        for f in glob.glob(os.path.join(ROOT, "profiles", rnd + "_*.json")):
-            try:
-                d = json.loads(open(f).read().strip().split("\n")[-1])
-                if isinstance(d, dict) and isinstance(d.get("roofline"), dict) and d["roofline"].get("kernel") == "k_merkle_layer" and d.get("n_gpus") == 1:
-                    fr.append(d["roofline"]["frac"])
-            except Exception:
-                pass
-        if fr:
-            out["frac_range_this_round"] = {"min": min(fr), "max": max(fr), "lines": len(fr), "what": f"`frac` (HIP events) over the {rnd} bench lines committed under profiles/ (boxes and run modes differ)"}
-    except Exception as e:
-        out["frac_rocprof_source"] = f"{os.path.relpath(path, ROOT)}: {e!r}"
-    return out
-
-
-def host_cpu_budget():
-    """What this process may use of the host: hardware threads in its affinity mask, the cgroup CPU quota (cores) if one is set, SMT width.
-    cores_effective = min(affinity threads, quota): a team of more threads than that only time-shares the granted cores."""
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota = None
-    try:
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q[0] == "max" else int(q[0]) / int(q[1])
-    except Exception:
-        try:
-            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            quota = q / per if q > 0 else None
-        except Exception:
-            pass
-    effective = max(1, int(min(avail, quota) if quota else avail))
-    return {"affinity_threads": avail, "quota_cores": round(quota, 1) if quota else None, "cores_effective": effective}
-
-
-def cpu_baseline(cells_per_proof, full=False):
-    """CPU baseline: the CPU port (oracle/) in its SIMD mode, kind "port-simd" — the stated stand-in for the reference's parallel CPU path
-    (stwo SimdBackend + rayon: `cargo build --features parallel --release`, README.md:23-36; the time it prints: bin/brainfuck_prover.rs:
-    137-139), which cannot be built on this image (no cargo, stwo not vendored). In that mode the port's Merkle layer loop, circle FFT / iFFT
-    and FRI-quotient row loop run on AVX-512 (16 u32 lanes per instruction, like PackedM31 / compress16; oracle/simd_port.cpp), every loop
-    threaded with OpenMP; constraint evaluation, logUp, sampling and the FRI folds stay scalar (threaded). The proof is the SAME BYTES as the
-    scalar port's and the GPU's (SHA-256 reported). threads = min(affinity, cgroup quota): a larger team only time-shares the granted cores.
-
-    value = the SIMD port on THE BENCH WORKLOAD ITSELF (fib19.bf, LOG_MAX_ROWS 24), timed LIVE in this run when the host has the cores and the
-    memory (`full`); on a small host (the 8-core build container) the committed scalar measurement stands in and `live` holds a bounded sample.
-    scalar_value = the same proof by the scalar port (committed measurement, or live with --cpu-baseline full-both)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import Oracle
-    orc = Oracle()
-    budget = host_cpu_budget()
-    threads = max(1, min(budget["cores_effective"], 64))
-    simd_ok = bool(orc.L.orc_simd_available())
-    out = {"unit": "trace cells/s", "kind": "port-simd" if simd_ok else "port", "cores": budget["cores_effective"], "cores_effective": budget["cores_effective"],
-           "threads": threads, "quota_cores": budget["quota_cores"], "host_threads_in_affinity_mask": budget["affinity_threads"],
-           "instruction_set": "AVX-512 (Merkle layers, circle FFT / iFFT, FRI-quotient rows; the rest scalar + OpenMP)" if simd_ok else "scalar (the host has no AVX-512)",
-           "stands_in_for": "brainfuck_prover prove --features parallel (stwo SimdBackend + rayon; README.md:23-36, 'Proof generation time' bin/brainfuck_prover.rs:137-139): not buildable here"}
-    fx = committed_digests().get("stwo")
-    if fx:
-        out["scalar_value"] = cells_per_proof / fx["oracle_seconds"]
-        out["scalar_sample"] = f"the scalar port on the same proof: {fx['oracle_seconds']} s on the 8 cores of the build container (tests/golden/fib19_lmr24_oracle_proof.json); not timed in this run"
-    orc.L.orc_set_threads(threads)
-    orc.L.orc_set_simd(1 if simd_ok else 0)
-    try:
-        if full:
-            t0 = time.time()
-            proof, _, _ = orc.prove(FIB19, b"", log_max_rows=24)
-            sec = time.time() - t0
-            out.update({"value": cells_per_proof / sec, "seconds": round(sec, 2),
-                        "sample": f"fib19.bf at LOG_MAX_ROWS 24 (the bench workload itself, {cells_per_proof} cells), one proof timed live on this box: {sec:.1f} s with {threads} OpenMP threads on {budget['cores_effective']} effective cores",
-                        "proof_sha256": hashlib.sha256(proof).hexdigest()})
-            return out
-        # bounded live sample on this box's cores
-        code = open(os.path.join(ROOT, "tests", "golden", "programs", "collatz.bf")).read()
-        log_sizes, steps = orc.log_sizes(code, b"7\n")
-        cells = sum((m + 4 * i) << l for m, i, l in zip(MAIN_COLS, LOGUP_COLS, log_sizes))
-        _, _, sec = orc.prove(code, b"7\n", log_max_rows=max(log_sizes))
-        out.update({"value": cells / sec, "seconds": round(sec, 2),
-                    "sample": f"collatz.bf input '7\\n' ({steps} VM steps, {cells} cells, LOG_MAX_ROWS={max(log_sizes)}) — a 20x smaller trace than the bench workload (small host: the "
-                              f"full-size proof needs ~20 GB and minutes here; use --cpu-baseline full): {sec:.1f} s with {threads} OpenMP threads"})
-        return out
-    finally:
-        orc.L.orc_set_simd(0)
-
-
-MAIN_COLS = [8, 8, 4, 9, 13, 13, 11, 11, 11, 11, 11, 11, 7]      # TraceColumn::count().0 per component, claim order (mod.rs:85-99)
-LOGUP_COLS = [1, 1, 1, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1]
-
-
-def simdbackend_work_counts(log_sizes, lmr):
-    """Blake2s compressions and radix-2 butterflies a SimdBackend-shaped prover performs for one proof of a trace with these component sizes:
-    every column FULL SIZE (the reference broadcasts each table row into 16 lanes and its backend does not know it: memory/table.rs:95-104),
-    mixed-degree Merkle trees with one compression per 64 message bytes (children 64 B, then 16 column words per block), interpolate +
-    evaluate-on-the-blowup-domain per committed column (mod.rs:497,550-583,690-723 and the composition commit inside prover::prove). Only these
-    two loops are counted — a lower bound of the work."""
-    def tree(col_logs):
-        mx, total = max(col_logs), 0
-        for lg in range(mx, -1, -1):
-            ncols = sum(1 for c in col_logs if c == lg)
-            msg = (64 if lg < mx else 0) + 4 * ncols
-            total += (1 << lg) * max(1, -(-msg // 64))
-        return total
-    pre = [l + 1 for l in range(lmr, 3, -1)]
-    main = [l + 1 for l, m in zip(log_sizes, MAIN_COLS) for _ in range(m)]
-    inter = [l + 1 for l, n in zip(log_sizes, LOGUP_COLS) for _ in range(4 * n)]
-    comp_log = max(log_sizes) + 1
-    comp = [comp_log + 1] * 4
-    sizes = sorted(set(pre + main + inter + comp), reverse=True)
-    trees = [pre, main, inter, comp, [sz for sz in sizes for _ in range(4)]] + [[line] * 4 for line in range(sizes[0] - 1, 1, -1)]
-    compressions = sum(tree(t) for t in trees)
-    butterflies = 0
-    for lde in pre + main + inter + comp:      # iFFT on 2^(lde-1) points, FFT on 2^lde points: n/2 butterflies per layer
-        n = lde - 1
-        butterflies += n * (1 << (n - 1)) + lde * (1 << (lde - 1))
-    return compressions, butterflies
-
-
-def simd_bound(gpu_seconds_per_proof, log_sizes, lmr, seconds_each=4.0):
-    """cpu_baseline.simd_bound: the host's vector units on the two loops the reference's SimdBackend + rayon prover cannot avoid (oracle/
-    simd_bound.cpp: 16-lane Blake2s compression, packed M31 butterfly; AVX-512 if the host has it, else AVX2; every hardware thread busy,
-    operands in registers) -> a LOWER bound of the reference's proving time on this host and the speedup the GPU has over that bound."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import Oracle
-    L = Oracle().L
-    L.orc_simd_bound.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    out = (ctypes.c_double * 4)()
-    L.orc_simd_bound(avail, seconds_each, out)
-    comp_rate, bfly_rate, width, threads = out[0], out[1], int(out[2]), int(out[3])
-    if width == 0 or comp_rate <= 0 or bfly_rate <= 0:
-        return {"error": "the host has neither AVX-512 nor AVX2"}
-    # One thread alone: what a core of this host does when nothing else competes. The all-thread run above is what the box GIVES this process
-    # (cgroup CPU quotas and the other tenants of the host included); `threads x single-thread rate` is what the hardware could do at most
-    # (SMT siblings do not double a vector loop, so it overstates the host) — the stricter of the two bounds decides the north-star sentence.
-    one = (ctypes.c_double * 4)()
-    L.orc_simd_bound(1, min(seconds_each, 2.0), one)
-    try:
-        quota = open("/sys/fs/cgroup/cpu.max").read().split()
-        cpu_quota = None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 1)
-    except Exception:
-        cpu_quota = None
-    try:
-        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
-        smt = max(1, len([x for part in sib.split(",") for x in ([part] if "-" not in part else range(int(part.split("-")[0]), int(part.split("-")[1]) + 1))]))
-    except Exception:
-        smt = 1
-    physical = max(1, avail // smt)
-    comps, bflies = simdbackend_work_counts(log_sizes, lmr)
-    t_hash, t_fft = comps / comp_rate, bflies / bfly_rate
-    # whole host: every PHYSICAL core at the rate one thread reaches alone (SMT siblings share the vector ports), or the all-thread run if faster
-    ideal_comp, ideal_bfly = max(comp_rate, one[0] * physical), max(bfly_rate, one[1] * physical)
-    t_ideal = comps / ideal_comp + bflies / ideal_bfly
-    ratio_measured = (t_hash + t_fft) / gpu_seconds_per_proof
-    ratio = t_ideal / gpu_seconds_per_proof
-    granted = ("the %s cores the box's CPU quota grants this process" % cpu_quota) if cpu_quota else "all %d hardware threads" % threads
-    return {"instruction_set": "AVX-512 (16 x u32 per register)" if width == 512 else "AVX2 (two 8-lane halves per 16 lanes)", "threads": threads, "host_cores_available": avail,
-            "physical_cores": physical, "smt_threads_per_core": smt,
-            "blake2s_compressions_per_s": comp_rate, "m31_butterflies_per_s": bfly_rate,
-            "single_thread": {"blake2s_compressions_per_s": one[0], "m31_butterflies_per_s": one[1]}, "cgroup_cpu_quota_cores": cpu_quota,
-            "seconds_lower_bound_whole_host": t_ideal,
-            "gpu_over_simd_bound_as_measured_on_all_threads": round(ratio_measured, 2),
-            "work_counted": {"blake2s_compressions": comps, "m31_butterflies": bflies,
-                             "note": "full-size columns (the reference's SimdBackend does not exploit the 16x lane broadcast), Merkle + channel hashing and the column transforms only"},
-            "seconds_lower_bound": {"hashing": t_hash, "transforms": t_fft, "total": t_hash + t_fft},
-            "cells_per_s_upper_bound": None,
-            "gpu_over_simd_bound": round(ratio, 2),       # against the STRICTER bound (physical cores x single-thread rate, or the all-thread run if faster)
-            "north_star_10x": {
-                "on_the_cpu_this_box_grants": ("%s: the GPU proof is %.1fx faster than the fastest the vector units could hash and transform this trace as run on %s"
-                                               % ("met" if ratio_measured >= 10.0 else "not determined by the bound", ratio_measured, granted)),
-                "on_the_whole_host": ("%s: against %d physical cores each at the rate one thread reaches alone (registers only, perfect scaling, no memory traffic) the GPU proof is %.1fx faster; "
-                                      "the real reference (constraints, quotients, logUp, memory traffic, rayon) is slower than this bound by an unknown factor"
-                                      % ("met" if ratio >= 10.0 else "not determined by the bound", physical, ratio))},
-            "stands_in_for": "brainfuck_prover prove --features parallel (README.md:23-36), 'Proof generation time' (bin/brainfuck_prover.rs:137-139): not buildable here"}
-
-
-def pick_device(local_rank, n_visible, override=None):
-    """One process per GPU: rank r drives device LOCAL_RANK. A launcher that narrows each rank's view to its own GPU
-    (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) leaves one visible device, numbered 0, on every rank."""
-    if override is not None:
-        return override
-    return local_rank if local_rank < n_visible else local_rank % max(n_visible, 1)
-
-
-def profile_report(lib, ctx):
-    js = ctypes.c_void_p()
-    lib.bfhip_profile_report(ctx._h, ctypes.byref(js))
-    rep = json.loads(ctypes.string_at(js).decode())
-    lib.bfhip_free_host(js)
-    return rep
-
-
-def point_roofline(pkg, c, tr, lmr, sec_per_proof):
-    """The metric's own size (BASELINE 'at 2^22 rows'): kernel-time split, GPU-busy fraction and the dominant kernel's roofline of that proof, from
-    two extra untimed proofs — one with the dominant kernel bracketed by HIP events per run of launches (as in the timed region of the main
-    workload), one with every kernel bracketed (time split; the event pairs themselves stretch small proofs, so the busy fraction is the sum of
-    the kernel times over the UN-instrumented wall time and is an upper estimate when streams overlap)."""
-    lib = pkg.lib()
-    lib.bfhip_profile_enable(c._h, 2); lib.bfhip_profile_reset(c._h)
-    tr.prove(lmr, want_json=False); c.sync()
-    dom = profile_report(lib, c)
-    lib.bfhip_profile_enable(c._h, 1); lib.bfhip_profile_reset(c._h)
-    tr.prove(lmr, want_json=False); c.sync()
-    full = profile_report(lib, c)
-    lib.bfhip_profile_enable(c._h, 0)
-    out = {"kernels_ms_per_proof_instrumented": {k: round(v["total_ms"], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1]["total_ms"])}}
-    tot = sum(v["total_ms"] for v in full.values())
-    out["sum_of_kernel_ms"] = round(tot, 3)
-    out["gpu_busy_frac_estimate"] = round(min(1.0, tot / (sec_per_proof * 1e3)), 3)
-    d = dom.get("k_merkle_layer")
-    if d and d.get("units", 0) > 0 and d["total_ms"] > 0:
-        tops = d["units"] * VALU_OPS_PER_COMPRESSION / (d["total_ms"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "k_merkle_layer", "bound": "valu", "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tops/s (int32 VALU lane-ops)",
-                           "frac": round(tops / VALU_PEAK_TOPS, 4), "launches": d["calls"], "avg_launch_us": round(d["total_ms"] / d["calls"] * 1e3, 2),
-                           "compressions_per_proof": round(d["units"]), "kernel_ms_per_proof": round(d["total_ms"], 3),
-                           "share_of_proof": round(d["total_ms"] / (sec_per_proof * 1e3), 3),
-                           "hbm": {"achieved": round(d["bytes"] / d["total_ms"] / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d["bytes"] / d["total_ms"] / 1e6 / HBM_PEAK_GBS, 4)}}
-    return out
-
-
-def run_sweep(pkg, device, steps, logs):
-    """Synthetic padded traces of 2^k domain rows, k in `logs`: one context sized for the largest, LOG_MAX_ROWS = k per point."""
-    out = []
-    c = pkg.Context(device, max_log_domain=max(logs) + 2)
-    try:
-        for k in logs:
-            tr = pkg.Trace(c, sweep_program(k), b"")
-            try:
-                assert max(tr.log_sizes) == k, (k, tr.log_sizes)
-                proof, _ = tr.prove(k)            # warm-up (the arena grows on the first proof of a size)
-                c.sync()
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    proof, _ = tr.prove(k)
-                c.sync()
-                dt = (time.perf_counter() - t0) / steps
-                ok, why = pkg.verify_brainfuck(proof, k)
-                row = {"log_domain_rows": k, "log_max_rows": k, "vm_steps": tr.n_steps, "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 3),
-                       "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok)}
-                if k == 22:
-                    row.update(point_roofline(pkg, c, tr, k, dt))
-                out.append(row)
-            finally:
-                tr.close()
-    finally:
-        c.close()
-    return out
-
-
-def run_poseidon_point(pkg, device, log):
-    """BASELINE config 5 on one GPU: the synthetic 2^log-row trace proved with the Poseidon252 MerkleChannel variant (one warm-up, one timed
-    proof; the shard probe proves the same trace over N GPUs and reports the same SHA-256)."""
-    conv = (0, 0, 0, 1)
-    c = pkg.Context(device, max_log_domain=log + 2)
-    try:
-        c.set_conventions(*conv)
-        tr = pkg.Trace(c, sweep_program(log), b"")
-        try:
-            tr.prove(log)
-            c.sync()
-            t0 = time.perf_counter()
-            proof, phases = tr.prove(log)
-            c.sync()
-            dt = time.perf_counter() - t0
-            ok, _ = pkg.verify_brainfuck(proof, log, conv)
-            return {"log_domain_rows": log, "log_max_rows": log, "conventions": list(conv), "cells": tr.cells, "ms_per_proof": round(dt * 1e3, 1),
-                    "cells_per_s": tr.cells / dt, "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified": bool(ok),
-                    "phase_ms": {k: round(v * 1e3, 1) for k, v in phases.items()}}
-        finally:
-            tr.close()
-    finally:
-        c.close()
-
-
-def probe_stages(args):
-    """(name, program, LOG_MAX_ROWS, conventions, warm-up proofs, timed proofs, overlap mask): the bench workload, then BASELINE configs 3/4 (a
-    2^24-row synthetic trace) and 5 (a 2^26-row trace with the Poseidon252 MerkleChannel) proved by the whole group, and last the bench workload
-    again with the column -> row exchanges on the partner stream (bfhip_ctx_set_overlap bit 2: unmeasured on hardware until a multi-GPU run)."""
-    conv = tuple((([int(v) for v in args.conventions.split(",")]) + [0, 0, 0, 0])[:4])
-    stages = [("fib19", FIB19, args.log_max_rows, conv, 2, args.probe_steps, 0)]
-    if not args.probe_fib19_only:
-        stages.append(("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, 0))
-        stages.append(("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, 0))
-        stages.append(("fib19_exchange_overlap", FIB19, args.log_max_rows, conv, 1, args.probe_steps, 4))
-    return stages
-
-
-def probe_n1_reference(pkg, device, code, lmr, conv, max_log, steps):
-    """The same workload proved by ONE GPU alone (a context of its own, outside the group), timed right before the group proves it: what
-    `speedup_vs_n1` divides by. Every rank does this on its own GPU at the same time, so it costs the probe one proof's time, not N."""
-    c = pkg.Context(device, max_log_domain=max_log)
-    try:
-        c.set_conventions(*conv)
-        tr = pkg.Trace(c, code, b"")
-        try:
-            tr.prove(lmr); c.sync()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                proof, _ = tr.prove(lmr)
-            c.sync()
-            return (time.perf_counter() - t0) / steps, hashlib.sha256(proof).hexdigest()
-        finally:
-            tr.close()
-    finally:
-        c.close()
-
-
-def probe_run_stages(pkg, members, stages, out, flush, is_rank0, ref_device=None, max_log=26):
-    """Runs every stage on `members` (the contexts this process drives: one with RCCL, all N of an in-process group — one host thread
-    each). Results go to out["stages"][name]; a failed stage ends the probe (the other members may be inside its collectives).
-    ref_device: the GPU this process times the one-GPU reference of every stage on (None: no reference)."""
-    import threading
-    for name, code, lmr, conv, warm, steps, overlap in stages:
-        row = {"log_max_rows": lmr, "conventions": list(conv), "overlap_mask": overlap}
-        out["stages"][name] = row
-        if ref_device is not None and not name.endswith("_exchange_overlap"):
-            try:
-                n1_sec, n1_sha = probe_n1_reference(pkg, ref_device, code, lmr, conv, max_log, max(1, min(steps, 3)))
-                row.update({"n1_ms_per_proof": round(n1_sec * 1e3, 3), "n1_proof_sha256": n1_sha})
-            except Exception as e:
-                row["n1_error"] = repr(e)
-            flush()
-        n = len(members)
-        gate = threading.Barrier(n)
-        res, errors = [None] * n, []
-
-        def run(k):
-            ctx, trace = members[k], None
-            try:
-                ctx.set_conventions(*conv)
-                if overlap is not None:                  # None: the library's default (exchange on the partner stream when the group spans GPUs)
-                    ctx.set_overlap(overlap)
-                trace = pkg.Trace(ctx, code, b"")
-                before = ctx.group_stats()
-                for _ in range(warm):
-                    trace.prove(lmr)
-                ctx.sync()
-                t_before = ctx.group_times()
-                gate.wait(timeout=600)
-                t0 = time.perf_counter()
-                for _ in range(steps):
-                    proof, phases = trace.prove(lmr)
-                ctx.sync()
-                dt_k = time.perf_counter() - t0
-                t_after = ctx.group_times()
-                res[k] = (dt_k, proof, phases, trace.cells, before, ctx.group_stats(), {kk: (t_after[kk] - t_before[kk]) / steps for kk in t_after})
-            except Exception as e:
-                errors.append(repr(e))
-                gate.abort()
-            finally:
-                if trace is not None:
-                    trace.close()
-
-        threads = [threading.Thread(target=run, args=(k,)) for k in range(n)]
-        [t.start() for t in threads]; [t.join() for t in threads]
-        if errors:
-            row["error"] = "; ".join(errors)
-            flush()
-            raise RuntimeError(row["error"])
-        dt = max(r[0] for r in res) / steps
-        _, proof, phases, cells, before, after, comm_ms = res[0]
-        row.update({"ms_per_proof": round(dt * 1e3, 3), "cells": cells, "cells_per_s": cells / dt, "steps": steps,
-                    "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(),
-                    "all_members_same_proof": all(r[1] == proof for r in res),
-                    "phase_ms_last_proof": {k: round(v * 1e3, 2) for k, v in phases.items()},
-                    "per_proof": {k: round((after[k] - before[k]) / (warm + steps), 1) for k in after},
-                    # where a proof over several GPUs spends its time: GPU-side milliseconds inside the collectives (HIP-event pairs on the rank's
-                    # stream: includes waiting for the slowest peer), rank 0 and the maximum over the ranks; the rest of ms_per_proof is compute
-                    "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()},
-                    "comm_ms_per_proof_max_rank": {k: round(max(r[6][k] for r in res), 3) for k in comm_ms},
-                    "comm_share_of_proof": round(sum(comm_ms.values()) / (dt * 1e3), 3)})
-        if "n1_ms_per_proof" in row:
-            row["speedup_vs_n1"] = round(row["n1_ms_per_proof"] / row["ms_per_proof"], 3)
-            row["identical_to_n1"] = row["n1_proof_sha256"] == row["proof_sha256"]
-        if is_rank0:
-            row["verified"] = bool(pkg.verify_brainfuck(proof, lmr, conv)[0])
-        if name.startswith("fib19"):
-            want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == lmr), None)
-            row["parity_checked"] = bool(want is not None and row["proof_sha256"] == want["sha256"])
-        flush()
-
-
-def shard_probe(args):
-    """Child-process mode (--shard-probe): ONE proof over all N GPUs, a few proofs per stage (probe_stages). Two transports:
-    default — this rank's child joins the other ranks' children in an RCCL shard group (the 128-byte unique id travels through a file);
-    --probe-local — rank 0's child alone drives all N GPUs from N host threads over the library's in-process transport (peer copies).
-    No torch, no torch.distributed: the parent keeps its process group for the contract's timing protocol. The result file is rewritten
-    after every stage, so a stage that hangs (the parent kills this child on its timeout) does not cost the earlier ones."""
-    rank, world, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
-    out = {"n_gpus": world, "rank": rank, "stages": {}}
-
-    def flush():
-        with open(args.probe_out + ".tmp", "w") as f:
-            json.dump(out, f)
-        os.replace(args.probe_out + ".tmp", args.probe_out)
-
-    try:
-        pkg = load_package()
-        stages = probe_stages(args)
-        max_log = max(s[2] for s in stages) + 2
-        if args.probe_local:
-            n_dev = pkg.device_count()
-            devices = [pick_device(r, n_dev, args.device) for r in range(world)]
-            out["devices"] = devices
-            members = [pkg.Context(d, max_log_domain=max_log) for d in devices]
-            group = pkg.LocalGroup(world) if world > 1 else None
-            if group is not None:
-                import threading
-                errs = []
-                def join(r):
-                    try:
-                        members[r].join_local_group(group, r)
-                    except Exception as e:
-                        errs.append(repr(e))
-                th = [threading.Thread(target=join, args=(r,)) for r in range(world)]
-                [t.start() for t in th]; [t.join() for t in th]
-                if errs:
-                    raise RuntimeError("; ".join(errs))
-        else:
-            members = [pkg.Context(pick_device(local_rank, pkg.device_count(), args.device), max_log_domain=max_log)]
-            if world > 1:                       # world == 1: the stages on a single GPU (how the probe itself is tested on a 1-GPU box)
-                idf = args.probe_id_file
-                if rank == 0:
-                    with open(idf + ".tmp", "wb") as f:
-                        f.write(pkg.rccl_unique_id())
-                    os.replace(idf + ".tmp", idf)
-                t0 = time.time()
-                while not os.path.exists(idf):
-                    if time.time() - t0 > 60:
-                        raise RuntimeError("unique id file did not appear")
-                    time.sleep(0.02)
-                members[0].join_rccl_group(open(idf, "rb").read(), rank, world)
-        flush()
-        ref_device = (devices[0] if args.probe_local else pick_device(local_rank, pkg.device_count(), args.device)) if world > 1 else None
-        probe_run_stages(pkg, members, stages, out, flush, rank == 0, ref_device=ref_device, max_log=max_log)
-        out["transport"] = members[0].group_info()[2]
-        for m in members:
-            if world > 1:
-                m.leave_group()
-            m.close()
-    except Exception as e:
-        out["error"] = repr(e)
-    flush()
-    return 0
-
-
-def run_shard_probe(args, rank, world):
-    """Parent side, BEFORE this process touches the GPU (a child must not be exec'd from a process that has initialised it).
-    (1) every rank starts its RCCL probe child, waits for it (bounded) and kills exactly that PID on timeout; (2) rank 0 alone starts the
-    in-process probe child (N host threads driving the N GPUs) while the other ranks wait for its completion marker.
-    Returns rank 0's RCCL result with the in-process result under "single_process" (or error records)."""
-    import subprocess
-    import tempfile
-    base = os.path.join(tempfile.gettempdir(), f"bfhip_probe_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}")
-    marker = f"{base}.localdone"
-
-    def run_child(extra, out_path):
-        try:
-            os.remove(out_path)
-        except OSError:
-            pass
-        cmd = [sys.executable, os.path.abspath(__file__), "--shard-probe", "--probe-out", out_path, "--probe-id-file", f"{base}.id", "--probe-steps", str(args.probe_steps),
-               "--log-max-rows", str(args.log_max_rows), "--conventions", args.conventions] + extra
-        if args.probe_fib19_only:
-            cmd.append("--probe-fib19-only")
-        if args.device is not None:
-            cmd += ["--device", str(args.device)]
-        child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        try:
-            child.wait(timeout=args.probe_timeout)
-        except subprocess.TimeoutExpired:
-            child.kill()
-            child.wait()
-            try:
-                partial = json.load(open(out_path))       # the stages that completed before the one that hung
-            except Exception:
-                partial = {"n_gpus": world}
-            partial["error"] = f"probe child did not finish within {args.probe_timeout} s (killed); stages listed without ms_per_proof did not complete"
-            return partial
-        try:
-            return json.load(open(out_path))
-        except Exception as e:
-            return {"n_gpus": world, "error": f"probe child left no result (exit code {child.returncode}): {e!r}"}
-
-    if rank == 0:
-        for path in (f"{base}.id", marker):
-            try:
-                os.remove(path)
-            except OSError:
-                pass
-    # round 5: the RCCL group's proofs are the headline of the main processes themselves; the per-rank RCCL children run on request only
-    result = run_child([], f"{base}_rank{rank}.json") if args.rccl_child_probe else {"n_gpus": world, "stages": {}}
-    if args.no_local_probe:
-        return result
-    if rank == 0:
-        try:
-            result["single_process"] = run_child(["--probe-local"], f"{base}_local.json")
-        finally:
-            open(marker, "w").close()
-    else:
-        t0 = time.time()
-        while not os.path.exists(marker) and time.time() - t0 < args.probe_timeout + 60:
-            time.sleep(0.2)
-    return result
-
-
-def gpu_local_cpus(device):
-    """The cores next to GPU `device` (sysfs local_cpulist of its PCI function), or None when that cannot be read."""
-    try:
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        buf = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
-            return None
-        text = open(f"/sys/bus/pci/devices/{buf.value.decode().lower()}/local_cpulist").read().strip()
-        cpus = set()
-        for part in text.split(","):
-            if "-" in part:
-                a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
-            elif part:
-                cpus.add(int(part))
-        return cpus or None
-    except Exception:
-        return None
-
-
-class pinned_host_thread:
-    """The proving thread on ONE core next to its GPU for the duration of a timed region (restored afterwards: the CPU baseline and child
-    processes use every core). A proof is ~10 Fiat-Shamir round trips with the GPU idle in each; a thread that the scheduler migrates while it
-    polls adds a 0.3-0.5 ms tail to 10-15 % of the 2^22-row proofs (measured: mean 9.24 -> 9.14 ms, p90 9.50 -> 9.20 ms under taskset) — what
-    any deployment does with numactl. Only a core of the GPU's own NUMA node is taken (a far core costs more than the jitter: measured); when
-    the node cannot be determined nothing is pinned. Opt-in (--pin): on other boxes of the pool the same pinning changed nothing or cost 1 %."""
-    cpu = None
-
-    def __init__(self, enabled, device=0, local_rank=0, world=1):
-        self.enabled, self.device, self.local_rank, self.world, self.old = enabled, device, local_rank, world, None
-
-    def __enter__(self):
-        if not self.enabled or not hasattr(os, "sched_setaffinity"):
-            return self
-        try:
-            old = os.sched_getaffinity(0)
-            near = gpu_local_cpus(self.device)
-            cand = sorted(old & near) if near else []
-            if not cand:
-                return self
-            # ranks that share a node take different cores; the first cores of a node are left to interrupt handling
-            cpu = cand[(2 + 2 * self.local_rank) % len(cand)]
-            os.sched_setaffinity(0, {cpu})
-            self.old = old
-            pinned_host_thread.cpu = cpu
-        except OSError:
-            self.old = None
-        return self
-
-    def __exit__(self, *exc):
-        if self.old is not None:
-            os.sched_setaffinity(0, self.old)
-        return False
-
-
-PIPELINED_WORK = [("fib19", None, None), ("2^22_rows", 22, 22), ("2^20_rows", 20, 20)]      # (name, sweep log or None = the bench workload, LOG_MAX_ROWS or None = --log-max-rows)
-
-
-def run_pipelined_one(pkg, device, code, lmr, k, rounds=6):
-    """k proofs in flight on one GPU: k FRESH contexts (stream, arena, staging ring each), one host thread each proving `rounds` proofs back to back.
-    Runs in a process of its own (one configuration per process: see run_pipelined)."""
-    import threading
-    ctxs = [pkg.Context(device, max_log_domain=lmr + 2) for _ in range(k)]
-    traces = [pkg.Trace(c, code, b"") for c in ctxs]
-    shas, errs = [None] * k, []
-    try:
-        def run(i, n, keep):
-            try:
-                for _ in range(n):
-                    proof, _ = traces[i].prove(lmr, want_json=keep)
-                if keep:
-                    shas[i] = hashlib.sha256(proof).hexdigest()
-            except Exception as e:
-                errs.append(repr(e))
-
-        def wave(n, keep):
-            th = [threading.Thread(target=run, args=(i, n, keep)) for i in range(k)]
-            [t.start() for t in th]; [t.join() for t in th]
-            for c in ctxs:
-                c.sync()
-        wave(3, False)                                   # warm-up (arena growth, first-proof setup, clocks)
-        # waves of `rounds` proofs per context until at least 0.5 s have been timed: a 2^20-row configuration is over in 20 ms otherwise, before the
-        # clocks have settled, and the one-in-flight reference would look slower than it is
-        waves, t0 = 0, time.perf_counter()
-        while waves == 0 or time.perf_counter() - t0 < 0.5:
-            wave(rounds, False); waves += 1
-        dt = time.perf_counter() - t0
-        wave(1, True)                                    # the bytes: one more proof per context with the JSON kept
-        if errs:
-            raise RuntimeError("; ".join(errs))
-        ms = dt / (waves * rounds * k) * 1e3
-        return {"ms_per_proof": round(ms, 3), "cells_per_s": traces[0].cells / (ms * 1e-3), "proofs_timed": waves * rounds * k, "proof_sha256": shas, "all_same_proof": len(set(shas)) == 1}
-    finally:
-        for t in traces:
-            t.close()
-        for c in ctxs:
-            c.close()
-
-
-def run_pipelined(args, rounds=6):
-    """{fib19, 2^22 rows, 2^20 rows} x {1, 2, 3 proofs in flight}, every configuration in a CHILD PROCESS of its own, started before this process
-    touches the GPU: what a deployment sees — k long-lived contexts and nothing else. (Round 5 found the gain to depend on what else the process had
-    created: HIP hands every stream a hardware queue at creation, and with four streams per context the main streams of two contexts shared one —
-    2-3 % instead of 12-17 % at 2^22 rows. Contexts now create their two partner streams on demand and the gain no longer depends on history,
-    profiles/r05_inflight_history.txt; the child processes stay: one configuration, one process, no leftovers.)"""
-    import subprocess
-    out = {"what": "k proofs in flight per GPU = k contexts + k host threads in a fresh process; ms_per_proof = wall time / proofs completed", "rounds_per_context": rounds}
-    for name, _, _ in PIPELINED_WORK:
-        row = {}
-        for k in (1, 2, 3):
-            cmd = [sys.executable, os.path.abspath(__file__), "--pipelined-child", f"{name}:{k}:{rounds}", "--log-max-rows", str(args.log_max_rows)] + (["--device", str(args.device)] if args.device is not None else [])
-            try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-                line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
-                row[f"in_flight_{k}"] = json.loads(line) if line else {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}
-            except Exception as e:
-                row[f"in_flight_{k}"] = {"error": repr(e)}
-        base = row["in_flight_1"]
-        for k in (2, 3):
-            if "ms_per_proof" in base and "ms_per_proof" in row[f"in_flight_{k}"]:
-                row[f"in_flight_{k}"]["gain_vs_1"] = round(base["ms_per_proof"] / row[f"in_flight_{k}"]["ms_per_proof"], 3)
-                row[f"in_flight_{k}"]["same_proof_as_1"] = row[f"in_flight_{k}"]["proof_sha256"][0] == base["proof_sha256"][0]
-        out[name] = row
-    return out
-
-
-def rank_environments(n, port, base_env=None):
-    """The environment of each of the n rank processes the self-launcher starts (what torch.distributed.run would have set)."""
-    base = dict(os.environ if base_env is None else base_env)
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return [dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                 BFHIP_BENCH_SELF_LAUNCHED="1") for r in range(n)]
-
-
-def launch_ranks(cmd, n, timeout, out=None, base_env=None, poll=0.1):
-    """`python3 bench.py --gpus N` without a launcher: starts the N ranks as fresh child processes of THIS process — which has not touched the
-    GPU and never will (a process that initialised the GPU must not be replaced or forked from) —, relays rank 0's one JSON line to `out`,
-    ends the stragglers (the exact PIDs started here) when a rank fails or the limit passes, and returns the exit code: 0 = every rank exited
-    0 and rank 0 printed its line; 1 = a rank failed or the line is missing; 124 = the limit passed."""
-    import socket
-    import subprocess
-    import tempfile
-    out = out or sys.stdout
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    procs, line_file = [], tempfile.NamedTemporaryFile(prefix="bfhip_bench_rank0_", suffix=".out", delete=False)
-    try:
-        for r, env in enumerate(rank_environments(n, port, base_env)):
-            # rank 0's stdout is the contract's line; whatever another rank prints goes to stderr
-            procs.append(subprocess.Popen(list(cmd), env=env, stdout=line_file if r == 0 else sys.stderr, stderr=None))
-        t_end, rc = time.time() + timeout, None
-        while rc is None:
-            codes = [p.poll() for p in procs]
-            if any(c not in (None, 0) for c in codes):
-                bad = next(r for r, c in enumerate(codes) if c not in (None, 0))
-                print(f"bench.py: rank {bad} exited with code {codes[bad]}: ending the other ranks", file=sys.stderr)
-                rc = 1
-            elif all(c == 0 for c in codes):
-                rc = 0
-            elif time.time() > t_end:
-                print(f"bench.py: the ranks did not finish within {timeout} s: ending them", file=sys.stderr)
-                rc = 124
-            else:
-                time.sleep(poll)
-        for p in procs:                      # stragglers: exactly the PIDs started above
-            if p.poll() is None:
-                p.terminate()
-        t_kill = time.time() + 5
-        for p in procs:
-            try:
-                p.wait(timeout=max(0.1, t_kill - time.time()))
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
-        line_file.flush()
-        lines = [l for l in open(line_file.name).read().splitlines() if l.strip()]
-        line = next((l for l in reversed(lines) if l.lstrip().startswith("{")), None)
-        if line is not None:
-            print(line, file=out, flush=True)
-        elif rc == 0:
-            print("bench.py: rank 0 exited 0 without printing its JSON line", file=sys.stderr)
-            rc = 1
-        return rc
-    finally:
-        line_file.close()
-        try:
-            os.remove(line_file.name)
-        except OSError:
-            pass
-
-
-def main():
+sys.path.insert(0, ROOT)
+from tools.benchlib import group as group_mod                                                                                    # noqa: E402
+from tools.benchlib.cpu import cpu_baseline, cpu_baseline_block, host_cpu_budget, simd_bound, simdbackend_work_counts             # noqa: E402,F401
+from tools.benchlib.launcher import launch_ranks, pinned_host_thread, rank_environments                                         # noqa: E402,F401
+from tools.benchlib.probes import batch_summary, pipelined_child_main, run_pipelined, run_poseidon_point, run_sweep              # noqa: E402
+from tools.benchlib.roofline import add_sustained_clock, dominant_roofline, fft_report, profile_report, roofline_from_committed_rocprof   # noqa: E402,F401
+from tools.benchlib.shard import run_shard_probe, shard_probe                                                                    # noqa: E402
+from tools.benchlib.workloads import (FIB19, HBM_PEAK_GBS, VALU_OPS_PER_COMPRESSION, VALU_PEAK_TOPS, committed_digests, kernel_sources_sha256,   # noqa: E402,F401
+                                      load_package, pick_device, sweep_program, want_digest)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks (one process per GPU). Without a launcher (WORLD_SIZE unset) and N > 1 this process starts the N ranks itself; "
                     "under a launcher it must equal WORLD_SIZE. Default: WORLD_SIZE, or 1")
@@ -814,26 +55,25 @@ def main():
     ap.add_argument("--pin", action="store_true", help="pin the proving host thread to one core of the GPU's NUMA node during the timed regions (default off: the gain "
                     "is box dependent, profiles/r03_bench_host_pinning_ab.txt)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
-                    help="full: time the CPU port on the bench workload itself live on this box (~35 s with 64 threads, ~20 GB of host memory); sample: committed "
+                    help="full: time the CPU port on the bench workload itself live on this box (~20 s, ~20 GB of host memory); sample: committed "
                          "full-size measurement + a bounded live sample; auto (default): full when the host has >= 32 cores and >= 48 GB of free memory")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--kernel-events", default="dominant", choices=["dominant", "all"], help="HIP-event timing of the dominant kernel only (default, ~0.5%% overhead) or of every kernel (~10%%) inside the timed region")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the 2^20..2^26 synthetic sweep (N=1 only; ~15 s)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the 0.6 s sustained-clock probe behind the timed region (roofline.sustained_clock_ghz)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 2^20..2^26 synthetic sweep and the proofs-in-flight children (N=1 only; ~30 s)")
     ap.add_argument("--sweep-steps", type=int, default=3)
     ap.add_argument("--no-poseidon", action="store_true", help="skip the Poseidon252 2^26-row point (BASELINE config 5 on one GPU; ~15 s)")
     ap.add_argument("--poseidon-log", type=int, default=26)
     ap.add_argument("--sweep-logs", default="20,21,22,23,24,25,26")
     ap.add_argument("--conventions", default="0,0,0,0", help="merkle_node_hash,mix_u64,logup_mask_order,merkle_channel (include/bfhip.h bfhip_conventions); default = stwo defaults, Blake2s channel")
     ap.add_argument("--reuse-preprocessed", action="store_true", help="NOT the headline: keep the program-independent preprocessed tree across proofs (a deployment option; the reference recommits it per proof)")
-    ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + HIP stream each); >1 reports pipelined throughput, no roofline")
+    ap.add_argument("--inflight", type=int, default=1, help="proofs in flight per GPU (one host thread + context each); >1 reports pipelined throughput, no roofline")
     ap.add_argument("--shard", action="store_true", help="(default for N > 1 since round 5; kept for old command lines) the N ranks prove ONE trace together")
     ap.add_argument("--replicas", action="store_true", help="N > 1: headline = N independent proofs (weak scaling) instead of ONE proof over the shard group (strong scaling, default)")
-    ap.add_argument("--no-extra-stages", action="store_true", help="N > 1: only the headline workload over the group, not the 2^24-row synthetic trace (configs 3/4) and the 2^26-row "
-                    "Poseidon252 trace (config 5)")
-    ap.add_argument("--group-timeout", type=int, default=900, help="N > 1: seconds the shard group's part (join, timed proofs, extra stages) may take; after that rank 0 prints the replicas "
-                    "line measured before the group formed and every rank leaves (a collective that never returns cannot be interrupted)")
-    ap.add_argument("--rccl-child-probe", action="store_true", help="N > 1: also run the group stages in child processes (one per rank, RCCL) before the ranks touch their GPUs — "
-                    "the pre-round-5 way, kept for debugging a transport that takes the main process down")
+    ap.add_argument("--no-extra-stages", action="store_true", help="N > 1: only the headline workload over the group, not the 2^24-row synthetic trace (configs 3/4) and the 2^26-row Poseidon252 trace (config 5)")
+    ap.add_argument("--group-timeout", type=int, default=900, help="N > 1: seconds the shard group's headline part (join, timed proofs) and, separately, its extra stages may take; after that rank 0 prints "
+                    "what was measured before (the replicas line / the strong-scaling line without the extra stages) and every rank leaves with exit code 3 (a collective that never returns cannot be interrupted)")
+    ap.add_argument("--rccl-child-probe", action="store_true", help="N > 1: also run the group stages in child processes (one per rank, RCCL) before the ranks touch their GPUs (debugging a transport that takes the main process down)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test mode on boxes with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="test mode: every rank uses this device instead of LOCAL_RANK")
     ap.add_argument("--no-shard-probe", action="store_true", help="N > 1: skip the child-process probes altogether (same as --no-local-probe without --rccl-child-probe)")
@@ -841,29 +81,23 @@ def main():
     ap.add_argument("--probe-timeout", type=int, default=240)
     ap.add_argument("--probe-fib19-only", action="store_true", help="shard probe: only the bench workload, not the 2^24-row and 2^26-row Poseidon252 traces (BASELINE configs 3-5)")
     ap.add_argument("--no-local-probe", action="store_true", help="shard probe: skip the in-process variant (rank 0's child driving all N GPUs from N host threads)")
-    ap.add_argument("--pipelined-child", default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--probe-local", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--shard-probe", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--probe-out", help=argparse.SUPPRESS)
-    ap.add_argument("--probe-id-file", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    for hidden in ("--pipelined-child", "--probe-out", "--probe-id-file"):
+        ap.add_argument(hidden, default=None, help=argparse.SUPPRESS)
+    for hidden in ("--probe-local", "--shard-probe"):
+        ap.add_argument(hidden, action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
     if args.shard_probe:
         return shard_probe(args)
     if args.pipelined_child:
-        # child-process mode: ONE proofs-in-flight configuration "name:k:rounds" in a process of its own (run_pipelined)
-        name, k, rounds = args.pipelined_child.split(":")
-        _, sweep_log, lmr = next(w for w in PIPELINED_WORK if w[0] == name)
-        pkg = load_package()
-        code, lmr = (FIB19, args.log_max_rows) if sweep_log is None else (sweep_program(sweep_log), lmr)
-        print(json.dumps(run_pipelined_one(pkg, pick_device(0, pkg.device_count(), args.device), code, lmr, int(k), int(rounds))), flush=True)
-        return 0
-
+        return pipelined_child_main(args)
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
         # no launcher started the ranks: do it here, before anything in this process touches the GPU (children are fresh processes)
         return launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus, args.launch_timeout)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus is not None and args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: the two must agree "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}, or plain python3 bench.py --gpus {args.gpus})")
@@ -875,25 +109,22 @@ def main():
         faulthandler.register(signal.SIGTERM, all_threads=True, chain=True)
         os.environ.setdefault("BFHIP_COMM_TIMEOUT_S", "120")     # a collective that never completes ends the stage with an error, not the run with a hang
 
-    # N > 1, replicas mode: besides the contract's weak-scaling number, measure ONE proof over all N GPUs (shard group, strong scaling) in
-    # child processes first — bounded, killed on timeout, never allowed to cost the main line.
+    # ---- child processes that must start BEFORE this process touches the GPU ---------------------------------------------------------------------------
+    # N > 1: ONE process driving all N GPUs over the in-process transport (a second transport on the same hardware); bounded, killed on timeout.
     shard_probe_result = None
     if world > 1 and not args.replicas and not args.no_shard_probe and (args.rccl_child_probe or not args.no_local_probe) and world & (world - 1) == 0:
         try:
             shard_probe_result = run_shard_probe(args, rank, world)
         except Exception as e:
             shard_probe_result = {"n_gpus": world, "error": repr(e)}
-
-    # ---- N = 1: proofs in flight (fresh contexts, one host thread + stream each): the single-workgroup latency chains and host points of one
-    # proof are filled by another proof's kernels. {fib19, 2^22 rows (the metric's size), 2^20 rows} x {1, 2, 3 in flight}, SHA-256 per proof.
-    # Reported beside `value`, never as it: one call = one proof (mod.rs:471-735); batching is the caller's.
-    # In child processes started BEFORE this one touches the GPU (run_pipelined says why).
-    pipelined_early = None
+    # N = 1: proofs in flight through the library's pool, {fib19, 2^22 rows (the metric's size), 2^20 rows} x {1, 2, 3 in flight}, one configuration per
+    # child. Reported beside `value`, never as it: value is one proof at a time (one prove_brainfuck call = one proof, mod.rs:471-735).
+    pipelined = None
     if world == 1 and args.inflight == 1 and not args.no_sweep:
         try:
-            pipelined_early = run_pipelined(args)
+            pipelined = run_pipelined(args)
         except Exception as e:
-            pipelined_early = {"error": repr(e)}
+            pipelined = {"error": repr(e)}
 
     import torch
     dist = None
@@ -906,6 +137,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    R = group_mod.Ranks(args, rank, local_rank, world, torch, dist)
 
     pkg = load_package()
     if pkg.device_count() < 1:
@@ -933,48 +165,10 @@ def main():
         def run(i, tr):
             res[i] = tr.prove(args.log_max_rows)
         th = [threading.Thread(target=run, args=(i + 1, tr)) for i, (_, tr) in enumerate(extra)]
-        for t in th:
-            t.start()
+        [t.start() for t in th]
         run(0, trace)
-        for t in th:
-            t.join()
+        [t.join() for t in th]
         return res[0]
-
-    spec = importlib.util.spec_from_file_location("stwo_brainfuck_amd_replicas", os.path.join(ROOT, "stwo-brainfuck_amd", "replicas.py"))
-    replicas = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(replicas)
-    cuda_t = (lambda v: torch.tensor([v], dtype=torch.float64, device="cuda")) if (dist is not None and args.dist_backend == "nccl") else None
-
-    t_start = time.time()
-
-    def note(msg):
-        """N > 1: one stderr line per stage and rank — where a multi-GPU run is when something hangs (the JSON line stays the only stdout)."""
-        if world > 1:
-            print(f"bench.py[rank {rank}/{world} +{time.time() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
-
-    def over_ranks(value, op):
-        """max / min / sum of a number over the ranks (the timing protocol's channel: torch.distributed)."""
-        if dist is None:
-            return value
-        t = torch.tensor([float(value)], dtype=torch.float64) if cuda_t is None else cuda_t(float(value))
-        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
-        return float(t.item())
-
-    def agree(ok):
-        """True only if the step succeeded on EVERY rank (the ranks must take the same path afterwards)."""
-        return over_ranks(1.0 if ok else 0.0, "min") > 0.5
-
-    def join_group(c):
-        # control plane only: rank 0's RCCL unique id reaches the others through torch.distributed; every data-path exchange of the proof
-        # is issued by libbfhip itself on the context's stream (RCCL over xGMI, device buffers on both ends)
-        dev = torch.device("cuda", device) if args.dist_backend == "nccl" else None
-        c.join_rccl_group(replicas.share_unique_id(dist, pkg.rccl_unique_id, dev), rank, world)
-
-    # N > 1: ONE proof over all ranks is the headline (strong scaling); --replicas: N independent proofs (weak scaling)
-    sharded = dist is not None and world > 1 and not args.replicas
-    if sharded and args.inflight > 1:
-        raise SystemExit("a shard group proves one trace at a time: --inflight needs --replicas (or one GPU)")
-    shard_error, n1 = None, None
 
     def sync():
         ctx.sync()
@@ -982,247 +176,41 @@ def main():
             c2.sync()
         torch.cuda.synchronize()
 
-    comm_before = {}
-
     def start_events():
-        if sharded:
-            ctx.sync()                                   # group_times() wants a drained stream
-            comm_before.update(ctx.group_times())
         if not args.no_kernel_events:
             lib.bfhip_profile_enable(ctx._h, 1 if args.kernel_events == "all" else 2)
             lib.bfhip_profile_reset(ctx._h)
 
+    spec = importlib.util.spec_from_file_location("stwo_brainfuck_amd_replicas", os.path.join(ROOT, "stwo-brainfuck_amd", "replicas.py"))
+    replicas = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(replicas)
     pin = lambda: pinned_host_thread(args.pin and args.inflight == 1, device, local_rank, world)      # noqa: E731
-    group = None
-    replica_line, watchdog = None, None
-    if sharded:
-        # ---- first the N independent proofs, one per GPU, under the contract's protocol (W warm-up, barrier, K steps, barrier, MAX over ranks): this is
-        # (a) the `replicas` field, (b) the one-GPU time speedup_vs_n1 divides by (every rank alone on its own GPU, the slowest rank's time), and
-        # (c) the line this run prints if the group below never comes back — a multi-GPU run always yields a line.
-        note(f"replicas: {args.warmup} + {args.steps} proofs per GPU")
-        with pin():
-            dt_r, (proof_r, _) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t)
-        cells_r = replicas.aggregate_units(trace.cells, dist=dist, backend_tensor=cuda_t)
-        replica_line = {"what": "N independent proofs, one per GPU, no data-path collective (weak scaling; the headline before round 5, and with --replicas)", "value": cells_r * args.steps / dt_r,
-                        "unit": "trace cells/s", "ms_per_step": dt_r / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                        "proof_sha256": hashlib.sha256(proof_r).hexdigest()}
-        n1 = {"ms_per_proof": replica_line["ms_per_step"], "proof_sha256": replica_line["proof_sha256"], "steps": args.steps,
-              "note": "every rank alone on its own GPU at the same time (the replicas run of this line); the slowest rank's time"}
 
-        def group_never_came_back():
-            # the group's part has not finished within --group-timeout: a collective that cannot be interrupted from here (a hung bootstrap, a wedged
-            # queue). Rank 0 prints the replicas line — measured above under the contract's protocol — and every rank leaves.
-            if rank == 0:
-                want_r = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == args.log_max_rows), None)
-                line = {"metric": "trace cells committed+proved/sec", "value": replica_line["value"], "unit": "trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                        "ms_per_step": replica_line["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (M31 / QM31 modular arithmetic)",
-                        "data": "fib19.bf execution trace (199246 VM steps), synthetic in the sense of the contract: a bundled program, no external data",
-                        "parity_checked": bool(want_r is not None and want_r["sha256"] == replica_line["proof_sha256"]),
-                        "config": {"workload": "fib19.bf (BASELINE config 2; 2^24 domain rows, Blake2s Merkle), 1 proof per step and GPU", "log_max_rows": args.log_max_rows,
-                                   "cells_per_proof": trace.cells, "parallelism": "replicas"},
-                        "roofline": None, "replicas": replica_line,
-                        "shard_group_error": f"the shard group (ONE proof over the {world} GPUs) did not finish within {args.group_timeout} s and could not be interrupted — value / ms_per_step are the "
-                                             "REPLICAS (weak scaling), measured before the group formed"}
-                print(json.dumps(line), flush=True)
-            print(f"bench.py[rank {rank}/{world}] the shard group did not come back within {args.group_timeout} s: leaving", file=sys.stderr, flush=True)
-            os._exit(0)      # the line above says what happened; a non-zero code would only make a launcher discard it
+    # ---- the line: built from `S` (everything measured so far), so that the extra-stages watchdog of an N > 1 run can still print what was measured ---------
+    S = {"sweep": None, "poseidon": None, "fft": None, "roofline": None, "cpu_baseline": None}
 
-        import threading
-        watchdog = threading.Timer(args.group_timeout, group_never_came_back)
-        watchdog.daemon = True
-        watchdog.start()
-        note(f"one-GPU reference {n1['ms_per_proof']:.2f} ms; joining the shard group")
-        try:
-            join_group(ctx)
-            ok = True
-            note("joined: " + ctx.group_info()[2])
-        except Exception as e:
-            ok, shard_error = False, f"joining the shard group failed on rank {rank}: {e!r}"
-        if not agree(ok):
-            shard_error = shard_error or "joining the shard group failed on another rank"
-            try:
-                ctx.leave_group()
-            except Exception:
-                pass
-            sharded = False
-    if sharded:
-        note(f"timed region: {args.warmup} + {args.steps} proofs over the group")
-        try:
-            with pin():
-                dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t, on_timed_start=start_events)
-            comm_after = ctx.group_times()
-            comm_ms = {k: (comm_after[k] - comm_before.get(k, 0.0)) / args.steps for k in comm_after}
-            group = {"transport": ctx.group_info()[2], "per_proof_rank0": {k: round(v / (args.warmup + args.steps), 1) for k, v in ctx.group_stats().items()},
-                     "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()}}
-            ok = True
-        except Exception as e:
-            ok, shard_error = False, f"the shard group's proof failed on rank {rank}: {e!r}"
-        note("group proofs done" if ok else f"group proofs FAILED: {shard_error}")
-        if not agree(ok):
-            shard_error = shard_error or "the shard group's proof failed on another rank"
-            sharded = False
-            lib.bfhip_profile_enable(ctx._h, 0)
-        else:
-            # only now, with every rank known to be here: collectives of the timing channel are never issued from inside a try block a peer may have left
-            group["comm_ms_per_proof_max_rank"] = round(over_ranks(sum(comm_ms.values()), "max"), 3)
-        try:
-            ctx.leave_group()
-        except Exception:
-            pass
-    group_rep = None
-    if sharded and not args.no_kernel_events:
-        group_rep = profile_report(lib, ctx)             # the dominant kernel of the TIMED group proofs (this rank's share)
-        lib.bfhip_profile_enable(ctx._h, 0)
-
-    # ---- N > 1: BASELINE configs 3/4 literal (synthetic 2^24-row trace) and 5 (2^26 rows, Poseidon252) over a second group, each with its one-GPU time
-    extra_stages = {}
-    if sharded and not args.no_extra_stages:
-        note("extra stages: 2^24-row trace (configs 3/4), 2^26-row Poseidon252 trace (config 5)")
-        big = None
-        try:
-            stages = [("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, None), ("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, None)]
-            big = pkg.Context(device, max_log_domain=28)
-            join_group(big)
-            holder = {"stages": extra_stages}
-            probe_run_stages(pkg, [big], stages, holder, lambda: None, rank == 0, ref_device=device, max_log=28)
-            ok = True
-        except Exception as e:
-            ok = False
-            extra_stages["error"] = f"rank {rank}: {e!r}"
-        if not agree(ok):
-            extra_stages.setdefault("error", "a stage failed on another rank")
-        if big is not None:
-            try:
-                big.leave_group()
-            except Exception:
-                pass
-            big.close()
-
-    if watchdog is not None:
-        watchdog.cancel()
-    # ---- replicas as the headline: N = 1, --replicas, or the group failed (its own replicas run above then stands) -----------------------------------
-    if not sharded:
-        note("replicas (headline)")
-        with pin():
-            dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=cuda_t, on_timed_start=start_events)
-        total_cells = replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=cuda_t)
-    else:
-        total_cells = trace.cells                         # all ranks proved the same one
-
-    # ---- parity: the proof timed last against the committed digest of the CPU oracle's proof of this workload (same conventions) ------
-    digest = hashlib.sha256(proof).hexdigest()
-    want = next((d for d in committed_digests().values() if tuple(d.get("conventions", ())) == conv and d.get("log_max_rows") == args.log_max_rows), None)
-    parity_checked = bool(want is not None and want["sha256"] == digest and want["proof_bytes"] == len(proof))
-    verified, why = pkg.verify_brainfuck(proof, args.log_max_rows)
-
-    roofline, fft = None, None
-    if not args.no_kernel_events:
-        rep = group_rep if group_rep is not None else profile_report(lib, ctx)
-        lib.bfhip_profile_enable(ctx._h, 0)
-        name, d = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
-        avg_ms = d["total_ms"] / d["calls"]
-        gbs = d["bytes"] / d["calls"] / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        import glob
-        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # from the separate rocprofv3 --pmc passes of the latest round
-        if pmc_files:
-            # The counter passes are a separate command (rocprofv3 --pmc serialises the dispatches: it cannot run inside a timed region), so the
-            # figure is read from the latest committed file — and only trusted while the kernel it was taken on is the kernel that ran here:
-            # tools/pmc_traffic.py records the SHA-256 of the kernel sources; a mismatch (or a file without the record) reports null.
-            pmc = json.load(open(pmc_files[-1]))
-            want_src = pmc.get("_kernel_sources_sha256")
-            have_src = kernel_sources_sha256()
-            if want_src == have_src:
-                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(pmc_files[-1], ROOT) + " (separate rocprofv3 --pmc passes of the same command on the same kernel sources; not collected in this run)"
-            else:
-                traffic_src = os.path.relpath(pmc_files[-1], ROOT) + " is STALE: taken on other kernel sources (csrc/merkle.hip, csrc/kernels.h changed since) — traffic not reported; rerun tools/profile_round.sh pmc"
-        hbm = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-               "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"])}
-        common = {"kernel": name, "traffic": traffic, "traffic_source": traffic_src, "launches": d["calls"], "avg_launch_us": round(avg_ms * 1e3, 2),
-                  "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
-        if name.startswith("k_merkle_layer") and d.get("units", 0) > 0:
-            # The Merkle kernel is integer-VALU bound: ~977 lane-ops per Blake2s compression, one compression per
-            # 64 message bytes. Compressions are counted from the launch shapes of this very run (prof.hip `units`), not a constant.
-            comp_per_step = d["units"] / args.steps
-            tops = d["units"] * VALU_OPS_PER_COMPRESSION / (d["total_ms"] * 1e-3) / 1e12
-            roofline = {**common, "bound": "valu", "achieved": round(tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "Tops/s (int32 VALU lane-ops)",
-                        "frac": round(tops / VALU_PEAK_TOPS, 4), "compressions_per_proof": round(comp_per_step),
-                        "G_compressions_per_s": round(d["units"] / (d["total_ms"] * 1e-3) / 1e9, 2), "valu_ops_per_compression": VALU_OPS_PER_COMPRESSION,
-                        "hbm": hbm}
-        else:
-            roofline = {**common, **hbm}
-        roofline["kernel_sources_sha256"] = kernel_sources_sha256()
-        # the same fraction from the committed rocprofv3 --kernel-trace --stats summary of this command (tools/profile_round.sh roofline: 20 steps on ONE
-        # stream, BFHIP_SINGLE_STREAM=1) — trusted only while that run was taken on the kernel sources that ran here
-        roofline.update(roofline_from_committed_rocprof(roofline.get("compressions_per_proof"), roofline["launches"] / args.steps))
-        if sharded:
-            roofline["scope"] = f"rank 0's share of the group's proofs (1 of {world} ranks): launches, compressions and kernel times are this rank's"
-        # ---- the circle-FFT kernels (north-star: >= 60 % HBM on the FFT kernel): one extra UNTIMED proof with every kernel bracketed ----
-        if world == 1:
-            lib.bfhip_profile_enable(ctx._h, 1)
-            lib.bfhip_profile_reset(ctx._h)
-            trace.prove(args.log_max_rows)
-            full = profile_report(lib, ctx)
-            lib.bfhip_profile_enable(ctx._h, 0)
-            fk = {k: v for k, v in full.items() if k.startswith("k_fft")}
-            if fk:
-                tot_ms = sum(v["total_ms"] for v in fk.values())
-                fft = {"kernels": {k: {"ms_per_proof": round(v["total_ms"], 3), "launches": v["calls"], "moved_GBps": round(v["bytes"] / v["total_ms"] / 1e6, 1),
-                                       "moved_frac_of_hbm_peak": round(v["bytes"] / v["total_ms"] / 1e6 / HBM_PEAK_GBS, 4)} for k, v in sorted(fk.items())},
-                       "ms_per_proof": round(tot_ms, 3),
-                       "moved_GBps": round(sum(v["bytes"] for v in fk.values()) / tot_ms / 1e6, 1),
-                       "algorithmic_GBps": round(sum(v["units"] for v in fk.values()) / tot_ms / 1e6, 1),
-                       "algorithmic_frac_of_hbm_peak": round(sum(v["units"] for v in fk.values()) / tot_ms / 1e6 / HBM_PEAK_GBS, 4),
-                       "note": "in-proof mix of column sizes (most launches are small); algorithmic bytes = 8N per interpolated, 12N per extended column (SURVEY.md section 8(d)); "
-                               "the 128 x 2^24 kernel run is tools/fft_roofline.py -> profiles/"}
-                roofline["all_kernels_ms_per_proof_instrumented"] = {k: round(v["total_ms"], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1]["total_ms"])}
-                # every Blake2s compression of the proof's trees, whichever kernel ran it (fixed by the protocol): k_merkle_layer + the
-                # multi-level kernels of the small end (k_merkle_subtree, k_merkle_top, k_fri_layer, k_fri_tail)
-                roofline["compressions_per_proof_all_merkle_kernels"] = round(sum(v.get("units", 0) for k, v in full.items() if k in ("k_merkle_layer", "k_merkle_subtree", "k_merkle_top", "k_fri_tail", "k_fri_layer")))
-
-    # ---- N = 1: proofs in flight: measured in a CHILD process started before this one touched the GPU (pipelined_early below) --------------------
-    pipelined = pipelined_early
-
-    sweep = None
-    if world == 1 and not args.no_sweep and rank == 0:
-        trace_cells = trace.cells
-        try:
-            with pin():
-                sweep = run_sweep(pkg, device, args.sweep_steps, [int(v) for v in args.sweep_logs.split(",")])
-        except Exception as e:      # the sweep must never cost the headline line
-            sweep = {"error": repr(e)}
-    poseidon = None
-    if world == 1 and not args.no_sweep and not args.no_poseidon and rank == 0:
-        try:
-            with pin():
-                poseidon = run_poseidon_point(pkg, device, args.poseidon_log)
-        except Exception as e:
-            poseidon = {"error": repr(e)}
-
-    cells = trace.cells
-    if rank == 0:
-        headline22 = next((p for p in sweep if p["log_domain_rows"] == 22), None) if isinstance(sweep, list) else None
+    def build_line(S, g, extras_error=None):
+        sharded, dt, proof, phases = S["sharded"], S["dt"], S["proof"], S["phases"]
+        digest = hashlib.sha256(proof).hexdigest()
+        want = want_digest(conv, args.log_max_rows)
+        parity_checked = bool(want is not None and want["sha256"] == digest and want["proof_bytes"] == len(proof))
+        verified, _ = pkg.verify_brainfuck(proof, args.log_max_rows)
+        sweep = S["sweep"]
+        p22 = next((p for p in sweep if p["log_domain_rows"] == 22), None) if isinstance(sweep, list) else None
+        p22_name = "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')"
+        ms_step = dt / args.steps * 1e3
+        metric_point = ({"workload": p22_name, "rows": "2^22", "value": p22["cells_per_s"], "cells_per_s": p22["cells_per_s"], "unit": "trace cells/s", "ms_per_proof": p22["ms_per_proof"],
+                         "cells": p22["cells"], "proof_sha256": p22["proof_sha256"], "sha256": p22["proof_sha256"], "verified": p22["verified"],
+                         "pipelined": ({k: {kk: vv for kk, vv in v.items() if kk not in ("proof_sha256", "how")} for k, v in pipelined["2^22_rows"].items() if k.startswith("in_flight_")}
+                                       if isinstance(pipelined, dict) and "2^22_rows" in pipelined else None)} if p22 else None)
         out = {
-            "metric": "trace cells committed+proved/sec",
-            "value": total_cells * args.steps / dt,
-            "unit": "trace cells/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            # BASELINE.json's metric is quoted "at 2^22 rows": that point of the sweep, promoted (value above is the larger fib19 workload)
-            "metric_point": ({"workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')",
-                              "value": headline22["cells_per_s"], "unit": "trace cells/s", "ms_per_proof": headline22["ms_per_proof"], "cells": headline22["cells"],
-                              "proof_sha256": headline22["proof_sha256"], "verified": headline22["verified"],
-                              "pipelined": ({k: {kk: vv for kk, vv in v.items() if kk != "proof_sha256"} for k, v in pipelined["2^22_rows"].items() if k.startswith("in_flight_")}
-                                            if isinstance(pipelined, dict) and "2^22_rows" in pipelined else None)} if headline22 else None),
-            "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
-            "speedup_vs_n1": (round(n1["ms_per_proof"] / (dt / args.steps * 1e3), 3) if (sharded and n1) else None),
-            "comm_share_of_proof": (round(sum(group["comm_ms_per_proof_rank0"].values()) / (dt / args.steps * 1e3), 3) if (sharded and group) else None),
-            "vs_baseline": None,
-            "dtype": "u32 (M31 / QM31 modular arithmetic)",
+            "metric": "trace cells committed+proved/sec", "value": S["total_cells"] * args.steps / dt, "unit": "trace cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "metric_point": metric_point,      # BASELINE.json's metric is quoted "at 2^22 rows" (value above is the larger fib19 workload); also inside `config`, which the driver keeps whole
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak",
+            "speedup_vs_n1": (round(g["n1"]["ms_per_proof"] / ms_step, 3) if (sharded and g and g.get("n1")) else None),
+            "comm_share_of_proof": (round(sum(g["group"]["comm_ms_per_proof_rank0"].values()) / ms_step, 3) if (sharded and g and g.get("group")) else None),
+            "vs_baseline": None, "dtype": "u32 (M31 / QM31 modular arithmetic)",
             "data": "fib19.bf execution trace (199246 VM steps), synthetic in the sense of the contract: a bundled program, no external data",
             "parity_checked": parity_checked,
             "parity": {"proof_sha256": digest, "proof_bytes": len(proof), "expected_sha256": want["sha256"] if want else None,
@@ -1231,69 +219,107 @@ def main():
             "config": {"workload": ("fib19.bf (BASELINE config 2; largest component 2^20 table rows = 2^24 domain rows, Blake2s Merkle), 1 proof per step"
                                     + (f" = ONE proof over the {world}-GPU shard group (BASELINE config 4's size: a 2^24-domain-row trace, column-sharded transforms, row-sharded "
                                        "Merkle / constraints / quotients / folds, RCCL); the synthetic 2^24-row trace of configs 3/4 and config 5 ride in strong_scaling" if sharded else "")
-                                    + "; the metric's own point ('at 2^22 rows': synthetic nested-counter trace, 2^22 domain rows, LOG_MAX_ROWS 22) is metric_point"),
-                       "log_max_rows": args.log_max_rows, "cells_per_proof": cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
-                       "component_log_sizes": trace.log_sizes, "parallelism": ("shard group: one proof over all ranks (column-sharded transforms, row-sharded Merkle/constraints/quotients/folds, RCCL)" if sharded else "replicas") if world > 1 else "single",
-                       "ranks_started_by": ("bench.py itself (no launcher)" if os.environ.get("BFHIP_BENCH_SELF_LAUNCHED") else "the launcher") if world > 1 else None, "proofs_in_flight_per_gpu": args.inflight, "host_thread_pinned_to_cpu": pinned_host_thread.cpu, "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
+                                    + "; the metric's own point ('at 2^22 rows': synthetic nested-counter trace, 2^22 domain rows, LOG_MAX_ROWS 22) is config.metric_point"),
+                       "log_max_rows": args.log_max_rows, "cells_per_proof": trace.cells, "main_cells": trace.main_cells, "interaction_cells": trace.interaction_cells,
+                       "component_log_sizes": trace.log_sizes,
+                       "parallelism": ("shard group: one proof over all ranks (column-sharded transforms, row-sharded Merkle/constraints/quotients/folds, RCCL)" if sharded else "replicas") if world > 1 else "single",
+                       "ranks_started_by": ("bench.py itself (no launcher)" if os.environ.get("BFHIP_BENCH_SELF_LAUNCHED") else "the launcher") if world > 1 else None,
+                       "proofs_in_flight_per_gpu": args.inflight, "host_thread_pinned_to_cpu": pinned_host_thread.cpu,
+                       "preprocessed_tree": "reused across proofs" if args.reuse_preprocessed else "recommitted every proof (as the reference)",
                        "proof_bytes": len(proof), "phase_ms_last_step": {k: round(v * 1e3, 2) for k, v in phases.items()},
-                       "headline_2^22": ({"cells_per_s": headline22["cells_per_s"], "ms_per_proof": headline22["ms_per_proof"], "cells": headline22["cells"],
-                                          "workload": "synthetic nested-counter trace, Memory component 2^22 domain rows, LOG_MAX_ROWS 22 (BASELINE metric 'at 2^22 rows')",
-                                          **{k2: headline22[k2] for k2 in ("roofline", "gpu_busy_frac_estimate", "sum_of_kernel_ms", "kernels_ms_per_proof_instrumented") if k2 in headline22}}
-                                         if headline22 else None)},
-            "roofline": roofline,
-            "fft": fft,
-            "pipelined": pipelined,
-            "sweep": sweep,
-            "poseidon252": poseidon,
+                       # ---- the metric's own numbers, inside the object the driver's record keeps whole ----
+                       "metric_point": ({k: metric_point[k] for k in ("rows", "ms_per_proof", "cells_per_s", "sha256", "verified")} if metric_point else None),
+                       "batch": batch_summary(pipelined),
+                       "sweep_ms": ({f"2^{p['log_domain_rows']}": p["ms_per_proof"] for p in sweep} if isinstance(sweep, list) else None),
+                       "headline_2^22": ({"cells_per_s": p22["cells_per_s"], "ms_per_proof": p22["ms_per_proof"], "cells": p22["cells"], "workload": p22_name,
+                                          **{k2: p22[k2] for k2 in ("roofline", "gpu_busy_frac_estimate", "sum_of_kernel_ms", "kernels_ms_per_proof_instrumented") if k2 in p22}} if p22 else None)},
+            "roofline": S["roofline"], "fft": S["fft"], "pipelined": pipelined, "sweep": sweep, "poseidon252": S["poseidon"],
         }
-        if world > 1:
-            if shard_error:
-                out["shard_group_error"] = shard_error + " — value / ms_per_step are the REPLICAS (weak scaling) instead"
+        if world > 1 and g:
+            if g.get("shard_error"):
+                out["shard_group_error"] = g["shard_error"] + " — value / ms_per_step are the REPLICAS (weak scaling) instead"
             if sharded:
-                head = {"ms_per_proof": round(dt / args.steps * 1e3, 3), "n1_ms_per_proof": round(n1["ms_per_proof"], 3), "speedup_vs_n1": out["speedup_vs_n1"],
-                        "comm_share_of_proof": out["comm_share_of_proof"], "identical_to_n1": n1["proof_sha256"] == digest, "cells_per_s": out["value"], "proof_sha256": digest,
-                        "parity_checked": parity_checked, **group}
+                head = {"ms_per_proof": round(ms_step, 3), "n1_ms_per_proof": round(g["n1"]["ms_per_proof"], 3), "speedup_vs_n1": out["speedup_vs_n1"], "n1_what": g["n1"]["note"],
+                        "comm_share_of_proof": out["comm_share_of_proof"], "identical_to_n1": g["n1"]["proof_sha256"] == digest, "cells_per_s": out["value"], "proof_sha256": digest,
+                        "parity_checked": parity_checked, **g["group"]}
                 rows = {"fib19": head}
-                for nm, st in extra_stages.items():
+                for nm, st in g["extra_stages"].items():
                     rows[nm] = ({k: st[k] for k in ("ms_per_proof", "n1_ms_per_proof", "speedup_vs_n1", "comm_share_of_proof", "identical_to_n1", "cells_per_s", "proof_sha256",
                                                    "verified", "comm_ms_per_proof_rank0", "error", "n1_error") if k in st} if isinstance(st, dict) else {"error": st})
-                out["strong_scaling"] = {"n_gpus": world, "what": "ONE proof over all N GPUs (shard group, RCCL, one process per GPU); n1 = the same proof on one GPU alone, timed in this run",
-                                         "transport": group["transport"], "workloads": rows}
-                out["replicas"] = replica_line
+                if extras_error:
+                    rows["extra_stages_error"] = extras_error
+                out["strong_scaling"] = {"n_gpus": world, "what": "ONE proof over all N GPUs (shard group, RCCL, one process per GPU); n1 = the same proof by rank 0 alone on its GPU, the other ranks idle, timed in this run",
+                                         "transport": g["group"]["transport"], "workloads": rows}
+                out["replicas"] = g["replica_line"]
             if shard_probe_result is not None:
                 # the same stages by ONE process driving all N GPUs over the in-process transport (peer copies), and on request the RCCL child probes
                 out["shard_group_single_process"] = shard_probe_result.get("single_process")
                 if args.rccl_child_probe:
                     out["shard_group_child_probe"] = {k: v for k, v in shard_probe_result.items() if k != "single_process"}
-        if world == 1 and not args.no_cpu_baseline:
-            full = args.cpu_baseline == "full"
-            if args.cpu_baseline == "auto":
-                avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-                try:
-                    free_gb = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) / 1e6
-                except Exception:
-                    free_gb = 0.0
-                full = avail >= 32 and free_gb >= 48
-            out["cpu_baseline"] = cpu_baseline(cells, full=full)
-            cb = out["cpu_baseline"]
-            if full and "proof_sha256" in cb:
-                cb["proof_identical_to_gpu"] = cb["proof_sha256"] == digest
-            # the north-star's ">= 10x the reference's parallel CPU prover on fib19-scale traces at 1 GPU", answered against THIS number in words
-            if full and cb.get("kind") == "port-simd":
-                r = out["value"] / cb["value"]
-                cb["north_star_10x"] = (f"{'met' if r >= 10 else 'NOT met'} against the stand-in: one GPU proves {r:.0f}x the cells/s of the AVX-512 port on {cb['cores_effective']} effective cores "
-                                        f"({cb['threads']} threads) of this box. The stand-in is not the reference: SimdBackend also vectorises constraint evaluation, logUp and the FRI folds, "
-                                        "which the port leaves scalar, and rayon may schedule better than OpenMP loops — see simd_bound for the floor of what any SimdBackend-shaped prover needs")
-            else:
-                cb["north_star_10x"] = "not determined in this run: the stand-in was not timed on the bench workload (small host, or no AVX-512)"
+        if S["cpu_baseline"] is not None:
+            out["cpu_baseline"] = S["cpu_baseline"]
+        return out
+
+    def roofline_of(rep, sharded_world):
+        return None if rep is None else dominant_roofline(rep, args.steps, sharded_world)
+
+    # ---- the timed region -------------------------------------------------------------------------------------------------------------------------------------
+    g = None
+    sharded = dist is not None and world > 1 and not args.replicas      # N > 1: ONE proof over all ranks is the headline (strong scaling)
+    if sharded and args.inflight > 1:
+        raise SystemExit("a shard group proves one trace at a time: --inflight needs --replicas (or one GPU)")
+    if sharded:
+        def emit_partial(gp, extras_error):
+            # second watchdog of an N > 1 run: the extra stages never came back, the headline group's numbers stand
+            S.update(sharded=True, dt=gp["dt"], proof=gp["proof"], phases=gp["phases"], total_cells=trace.cells, roofline=roofline_of(gp.get("group_rep"), world))
+            print(json.dumps(build_line(S, gp, extras_error)), flush=True)
+        g = group_mod.run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_events, pin, profile_report, emit_partial)
+        sharded = g["sharded"]
+    if sharded:
+        dt, proof, phases, total_cells = g["dt"], g["proof"], g["phases"], trace.cells      # all ranks proved the same one
+    else:
+        # replicas as the headline: N = 1, --replicas, or the group failed (the contract: W untimed, barrier + sync, K timed, barrier + sync, MAX over ranks)
+        R.note("replicas (headline)")
+        with pin():
+            dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=R.cuda_t, on_timed_start=start_events)
+        total_cells = replicas.aggregate_units(trace.cells * args.inflight, dist=dist, backend_tensor=R.cuda_t)
+    S.update(sharded=sharded, dt=dt, proof=proof, phases=phases, total_cells=total_cells)
+
+    # ---- roofline of the dominant kernel over the TIMED region; the sustained clock right behind it; the FFT kernels from one extra untimed proof -------------
+    if not args.no_kernel_events:
+        rep = g["group_rep"] if (sharded and g.get("group_rep") is not None) else profile_report(lib, ctx)
+        lib.bfhip_profile_enable(ctx._h, 0)
+        S["roofline"] = roofline_of(rep, world if sharded else 0)
+        if not args.no_clock_probe:
+            add_sustained_clock(S["roofline"], ctx)
+        if world == 1:
+            lib.bfhip_profile_enable(ctx._h, 1)
+            lib.bfhip_profile_reset(ctx._h)
+            trace.prove(args.log_max_rows)
+            full = profile_report(lib, ctx)
+            lib.bfhip_profile_enable(ctx._h, 0)
+            S["fft"] = fft_report(full)
+            if S["fft"]:
+                S["roofline"]["all_kernels_ms_per_proof_instrumented"] = {k: round(v["total_ms"], 3) for k, v in sorted(full.items(), key=lambda kv: -kv[1]["total_ms"])}
+                # every Blake2s compression of the proof's trees, whichever kernel ran it (fixed by the protocol)
+                S["roofline"]["compressions_per_proof_all_merkle_kernels"] = round(sum(v.get("units", 0) for k, v in full.items() if k in ("k_merkle_layer", "k_merkle_subtree", "k_merkle_top", "k_fri_tail", "k_fri_layer")))
+
+    if world == 1 and not args.no_sweep and rank == 0:
+        try:
+            with pin():
+                S["sweep"] = run_sweep(pkg, device, args.sweep_steps, [int(v) for v in args.sweep_logs.split(",")])
+        except Exception as e:      # the sweep must never cost the headline line
+            S["sweep"] = {"error": repr(e)}
+        if not args.no_poseidon:
             try:
-                sb = simd_bound(dt / args.steps, trace.log_sizes, args.log_max_rows)
-                if "seconds_lower_bound" in sb:
-                    sb["cells_per_s_upper_bound"] = cells / sb["seconds_lower_bound"]["total"]
-                out["cpu_baseline"]["simd_bound"] = sb
+                with pin():
+                    S["poseidon"] = run_poseidon_point(pkg, device, args.poseidon_log)
             except Exception as e:
-                out["cpu_baseline"]["simd_bound"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+                S["poseidon"] = {"error": repr(e)}
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            S["cpu_baseline"] = cpu_baseline_block(args.cpu_baseline, trace.cells, total_cells * args.steps / dt, hashlib.sha256(proof).hexdigest(), dt / args.steps, trace.log_sizes, args.log_max_rows)
+        print(json.dumps(build_line(S, g)), flush=True)
     if args.reuse_preprocessed:
         lib.bfhip_ctx_reuse_preprocessed(ctx._h, 0)
     for c2, t2 in extra:

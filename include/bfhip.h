@@ -95,7 +95,7 @@ int32_t bfhip_ctx_memory(bfhip_ctx* ctx, uint64_t out[4]);
  * hardware queue while the host thread sleeps. Where they are on (policy 0, or forced with BFHIP_MAILBOX=1), a host thread that is stalled for
  * longer than BFHIP_MAILBOX_TIMEOUT_MS (default 10 000 ms: SIGSTOP, a debugger, heavy oversubscription) makes that proof FAIL with a
  * "mailbox kernel gave up waiting for the host" error instead of merely being slow; the context stays usable and the next proof starts
- * clean. At most one proof of a process runs in the mailbox order at a time (two could block each other through a shared hardware queue): with several
+ * clean. At most one proof per GPU of a process runs in the mailbox order at a time (two could block each other through a shared hardware queue): with several
  * proofs in flight the others keep the plain order. BFHIP_MAILBOX=0 switches them off altogether. All members of a group must use the same overlap mask (bfhip_ctx_set_overlap). */
 int32_t bfhip_ctx_set_sync_policy(bfhip_ctx* ctx, int32_t blocking);
 /* Mailbox settings of a live context (what BFHIP_MAILBOX / BFHIP_MAILBOX_TIMEOUT_MS set at creation):
@@ -216,6 +216,11 @@ int32_t bfhip_accumulate_quotients(bfhip_ctx* ctx, uint32_t log_size, const uint
 int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* input_h, size_t n_input, uint32_t log_max_rows,
                               char** proof_json, size_t* proof_len, char** transcript, double* phase_seconds);
 void bfhip_free_host(void* p);
+/* What the last COMPLETED proof of this context actually did (0 before the first): bit 0 = it ran in the mailbox order (forcing mode 1 does not
+ * guarantee it: one proof per GPU holds that order at a time, see bfhip_ctx_set_sync_policy), bit 1 = it took the context's kept preprocessed tree
+ * (bfhip_ctx_reuse_preprocessed), bit 2 = it took a pool's shared preprocessed tree (bfhip_pool_set_preprocessed). Tests and tools read it so that
+ * a setting that silently did not apply is visible. */
+int32_t bfhip_ctx_last_proof_flags(bfhip_ctx* ctx, uint32_t* flags);
 /* ---- one proof over several GPUs (shard group) ------------------------------------------------------------------------------------------
  * north_star: "trace columns shard naturally across the 8 GPUs of one node, with the Merkle root and FRI fold reduced via RCCL over xGMI"
  * (SURVEY.md section 8(e)). The ranks of a group prove ONE trace together and all return the byte-identical proof of the single-GPU path:
@@ -344,6 +349,13 @@ int32_t bfhip_host_table(const uint32_t* trace7, size_t n_trace, const uint32_t*
 int32_t bfhip_profile_enable(bfhip_ctx* ctx, int32_t mode);
 int32_t bfhip_profile_reset(bfhip_ctx* ctx);
 int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json);
+/* Diagnostic: the shader clock this device sustains under the dominant kernel's instruction mix — a register-only loop of the Blake2s compression
+ * (no memory traffic) launched back to back for `seconds` (>= 0.5 for a settled clock), every workgroup stamping the shader-cycle counter against
+ * the constant 100 MHz counter around its loop. out = {median GHz over the workgroups of the last launch, min, max, 10^9 compressions/s of the last
+ * launches, launches issued, ms per launch}. bench.py prices the Merkle kernel's VALU fraction against the nominal 2.4 GHz AND against this clock:
+ * devices of one model differ by up to 12 % on compute-bound loops, and a line that only knows the nominal clock cannot tell a slow device from a
+ * slow kernel. Never part of a proof. */
+int32_t bfhip_clock_probe(bfhip_ctx* ctx, double seconds, double out[6]);
 
 #ifdef __cplusplus
 }

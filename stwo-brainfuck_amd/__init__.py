@@ -147,6 +147,19 @@ class Context:
         the (test) delay — a positive delay needs the test-hooks build of the library."""
         _check(lib().bfhip_ctx_set_mailbox(self._h, int(mode), int(timeout_ms), int(test_delay_ms)))
 
+    def last_proof_flags(self):
+        """bfhip_ctx_last_proof_flags: {mailbox_order, kept_preprocessed, shared_preprocessed} of the last completed proof."""
+        f = ctypes.c_uint32()
+        _check(lib().bfhip_ctx_last_proof_flags(self._h, ctypes.byref(f)))
+        return {"mailbox_order": bool(f.value & 1), "kept_preprocessed": bool(f.value & 2), "shared_preprocessed": bool(f.value & 4)}
+
+    def clock_probe(self, seconds=0.6):
+        """bfhip_clock_probe: {ghz (median over workgroups), ghz_min, ghz_max, G_compressions_per_s, launches, ms_per_launch} of a register-only
+        Blake2s loop run back to back for `seconds` — the clock this device sustains under the dominant kernel's instruction mix."""
+        out = (ctypes.c_double * 6)()
+        _check(lib().bfhip_clock_probe(self._h, ctypes.c_double(seconds), out))
+        return dict(zip(("ghz", "ghz_min", "ghz_max", "G_compressions_per_s", "launches", "ms_per_launch"), [float(v) for v in out]))
+
     def memory(self):
         """bfhip_ctx_memory: {arena_reserved, arena_peak, twiddles, arena_in_use} in bytes."""
         out = (ctypes.c_uint64 * 4)()

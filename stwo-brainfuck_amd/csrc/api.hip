@@ -6,6 +6,8 @@
 #include "host/quotients.h"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
+#include <chrono>
 
 using namespace bf;
 
@@ -130,6 +132,52 @@ int32_t bfhip_device_memory(int32_t device_id, uint64_t* free_bytes, uint64_t* t
     BF_HIP(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
+    return 0;
+    API_CATCH
+}
+
+// Diagnostic: the shader clock the device sustains under the dominant kernel's instruction mix (merkle.hip: k_clock_probe).
+int32_t bfhip_clock_probe(bfhip_ctx* ctx, double seconds, double out[6]) {
+    API_CTX(ctx)
+    if (!out) throw HipError("null argument");
+    if (!(seconds > 0.0) || seconds > 30.0) throw HipError("bfhip_clock_probe: seconds must be in (0, 30]");
+    Ctx& c = ctx->c;
+    c.sync();
+    const u32 blocks = 256 * 8, iters = 2048;          // 8 workgroups of 4 waves per CU; ~2.5 ms per launch
+    uint4* d_stamps = nullptr; u32* d_sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<uint4> st(blocks);
+    u64 launches = 0; float ms = 0.f;
+    try {
+        BF_HIP(hipMalloc((void**)&d_stamps, blocks * sizeof(uint4)));
+        BF_HIP(hipMalloc((void**)&d_sink, (size_t)blocks * 256 * sizeof(u32)));
+        BF_HIP(hipEventCreate(&e0)); BF_HIP(hipEventCreate(&e1));
+        const auto t0 = std::chrono::steady_clock::now();
+        // back-to-back launches (a few in the queue at any time) until `seconds` have passed; the LAST launch's stamps are read
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            for (int k = 0; k < 8; k++) { clock_probe_launch(c.stream, d_stamps, d_sink, blocks, iters); launches++; }
+            BF_HIP(hipGetLastError());
+            c.sync();
+        }
+        BF_HIP(hipEventRecord(e0, c.stream));
+        for (int k = 0; k < 8; k++) clock_probe_launch(c.stream, d_stamps, d_sink, blocks, iters);
+        BF_HIP(hipEventRecord(e1, c.stream));
+        BF_HIP(hipMemcpyAsync(st.data(), d_stamps, blocks * sizeof(uint4), hipMemcpyDeviceToHost, c.stream));
+        c.sync();
+        BF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    } catch (...) { (void)hipFree(d_stamps); (void)hipFree(d_sink); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); throw; }
+    (void)hipFree(d_stamps); (void)hipFree(d_sink); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::vector<double> ghz;
+    for (auto& s4 : st) {
+        const double cyc = (double)(((u64)s4.y << 32) | s4.x), ticks = (double)(((u64)s4.w << 32) | s4.z);
+        if (ticks > 0) ghz.push_back(cyc / ticks * 0.1);       // cycles per 10 ns tick -> GHz
+    }
+    if (ghz.empty()) throw HipError("bfhip_clock_probe: no stamps");
+    std::sort(ghz.begin(), ghz.end());
+    out[0] = ghz[ghz.size() / 2]; out[1] = ghz.front(); out[2] = ghz.back();
+    out[3] = ms > 0 ? 8.0 * blocks * 256.0 * iters / (ms * 1e-3) / 1e9 : 0.0;      // G compressions/s of the last 8 launches
+    out[4] = (double)(launches + 8);
+    out[5] = ms > 0 ? ms / 8.0 : 0.0;                                                 // ms per launch
     return 0;
     API_CATCH
 }

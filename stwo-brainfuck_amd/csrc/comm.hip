@@ -159,12 +159,16 @@ struct LocalComm : Comm {
             if (g->taken[r]) throw HipError("shard group: this rank of the group is already taken by another context");
             g->taken[r] = true;
         }
-        BF_HIP(hipGetDevice(&g->slots[r].device));        // the C-ABI entry has bound this thread to the context's GPU
+        int dev = -1;
+        BF_HIP(hipGetDevice(&dev));                       // the C-ABI entry has bound this thread to the context's GPU
         {
-            // a member on another GPU than one already there makes the group multi-device at once, for every member (before any collective)
+            // Whether the group spans several GPUs is decided at a RENDEZVOUS, where every member is present and takes the same decision
+            // (check_peers, behind the first barrier) — not here: a member that joined early and started its first proof would read "one
+            // device" while a later joiner on another GPU read "several", and the two would issue different collective sequences for the
+            // first tree (one exchange against first_wave + second_wave: 'unmatched send/receive'). Until that rendezvous every
+            // member answers spans_devices() == false. The slot is written under the lock the peers read it under.
             std::lock_guard<std::mutex> lk(g->mu);
-            for (u32 p = 0; p < count; p++)
-                if (p != r && g->taken[p] && g->slots[p].device >= 0 && g->slots[p].device != g->slots[r].device) g->spans.store(1, std::memory_order_release);
+            g->slots[r].device = dev;
             g->epoch.fetch_add(1, std::memory_order_release);
         }
         BF_HIP(hipEventCreateWithFlags(&g->slots[r].ready, hipEventDisableTiming));
@@ -177,8 +181,8 @@ struct LocalComm : Comm {
         (void)hipFree(scratch);
     }
     void abort() override { g->fail(); }
-    // the group's answer where it is known (the same for every member), this member's own view before its first collective
-    bool spans_devices() const override { const int v = g->spans.load(std::memory_order_acquire); return v < 0 ? multi_device : v != 0; }
+    // the group's answer once a rendezvous has decided it (the same for every member); false before the first collective
+    bool spans_devices() const override { return g->spans.load(std::memory_order_acquire) > 0; }
     const char* transport() const override {
         return multi_device ? "local (N contexts of one process on one GPU each, peer copies ordered by HIP events)"
                             : "local (N contexts of one process, device-to-device copies ordered by HIP events)";
@@ -188,6 +192,7 @@ struct LocalComm : Comm {
         const u32 e = g->epoch.load(std::memory_order_acquire);
         if (checked_epoch == e) return;
         checked_epoch = e;
+        std::lock_guard<std::mutex> lk(g->mu);             // the slots' devices are written under this lock (constructor)
         const int mine = g->slots[rank].device;
         for (u32 p = 0; p < count; p++) {
             const int d = g->slots[p].device;

@@ -14,7 +14,9 @@
 namespace bf {
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
-#define BF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) throw bf::HipError(std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+// A failed runtime call also leaves its code in the thread's "last error"; it is cleared here, or the next BF_HIP(hipGetLastError()) behind a perfectly
+// good launch would report it (r06: an out-of-memory context creation made the NEXT creation on that thread fail with "out of memory").
+#define BF_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { (void)hipGetLastError(); throw bf::HipError(std::string(#expr) + ": " + hipGetErrorString(e__)); } } while (0)
 
 // Bump allocator over large HBM chunks: the prover allocates hundreds of columns per proof and frees them all at once.
 struct Arena {
@@ -106,6 +108,7 @@ struct Ctx {
     template <class T> T* small_alias(T* host_ptr) const { return reinterpret_cast<T*>(d_small_alias + (reinterpret_cast<char*>(host_ptr) - h_small)); }
     char* h_stage = nullptr; char* d_stage = nullptr; size_t stage_bytes = 8 << 20, stage_used = 0;
     // ---- mailboxes and stamps (mailbox.hip, r04): the launches behind a Fiat-Shamir point are enqueued before the host knows the challenge ----
+    u32 last_proof_flags = 0;         // bfhip_ctx_last_proof_flags: what the last completed proof of this context did
     u32 proof_seq = 0;                // flags and stamps of a proof carry its number (never 0), so a slot needs no reset between proofs
     // Measured over three boxes the order gains 1-3 % on 2^20-row proofs and nothing (fib19: +0.1..+0.5 %) on large ones, where the saved
     // idle time is below the noise of a VALU-limited proof (finding iii). So by default it is used for proofs with

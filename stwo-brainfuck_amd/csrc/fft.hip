@@ -588,7 +588,7 @@ enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_S
 
 void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, const u32* tw, const u32* itw, u32 tw_root_log) {
     plan.inverse = inverse; plan.groups.clear(); plan.launches.clear(); plan.d_groups = nullptr;
-    struct Item { int pi, kind; PassArgs a; double bytes, alg; };
+    struct Item { int pi, kind; PassArgs a; double bytes, alg; double bfly() const { return 0.5 * a.ncols * (double)(1u << a.log) * a.k; } };      // butterflies of the pass
     std::vector<Item> items;
     int max_np = 0;
     for (size_t ji = 0; ji < njobs; ji++) {
@@ -698,7 +698,7 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
                 const u32 gy = kind == K_TINY ? 1u : a.block0;
                 a.block0 = blocks; blocks += a.grid_x * gy;
                 plan.groups.push_back(a);
-                L.bytes += it.bytes; L.alg += it.alg;
+                L.bytes += it.bytes; L.alg += it.alg; L.bfly += it.bfly();
             }
             L.ngroups = (u32)plan.groups.size() - L.first_group; L.total_blocks = blocks;
             if (L.ngroups) plan.launches.push_back(L);
@@ -714,38 +714,38 @@ void fft_run(hipStream_t stream, const FftPlan& plan) {
         const dim3 grid(L.total_blocks);
         switch (L.kind) {
             case K_TILE12: {
-                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L.bytes, L.alg, false, L.bfly);
                 static const u32 generic = [] { const char* v = getenv("BFHIP_FFT_TILE12_GENERIC"); return (v && v[0] == '1') ? 1u : 0u; }();
                 if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
                 else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
                 break; }
             case K_STRIDED5: {
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_strided7<false, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED6: {
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_strided7<false, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K8: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K9: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K10: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
                 break; }
             case K_PASS: {
-                ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L.bytes, L.alg);
+                ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
                 break; }

@@ -17,7 +17,7 @@ int prof_mode(hipStream_t s);
 void prof_enable(hipStream_t s, int mode);
 void prof_run_begin(hipStream_t s, const char* name);   // mode 2: one event pair for a run of back-to-back launches of one kernel
 void prof_run_end(hipStream_t s);
-void prof_begin(hipStream_t s, const char* name, double bytes, double units);
+void prof_begin(hipStream_t s, const char* name, double bytes, double units, double aux = 0.0);
 void prof_end(hipStream_t s);
 void prof_reset(hipStream_t s);
 std::string prof_report_json(const hipStream_t* streams, int n);
@@ -26,10 +26,11 @@ void prof_forget(hipStream_t s);
 // dominant: the kernel that mode 2 (lowest overhead) instruments — the Merkle layer kernel.
 struct ProfScope {
     hipStream_t s; bool on;
-    ProfScope(hipStream_t s_, const char* name, double bytes, double units = 0.0, bool dominant = false) : s(s_) {
+    // aux: a second work count of the launch (circle-FFT kernels: butterflies, so that a VALU-bound pass can be priced against the VALU peak)
+    ProfScope(hipStream_t s_, const char* name, double bytes, double units = 0.0, bool dominant = false, double aux = 0.0) : s(s_) {
         int m = prof_mode(s);
         on = m == 1 || (m == 2 && dominant);
-        if (on) prof_begin(s, name, bytes, units);
+        if (on) prof_begin(s, name, bytes, units, aux);
     }
     ~ProfScope() { if (on) prof_end(s); }
 };
@@ -91,7 +92,7 @@ struct PassArgs {
     const u32* tw;            // twiddle (forward) or inverse-twiddle (inverse) layered buffer
     u32 block0, grid_x;       // first workgroup of this group within its launch; tiles per column block
 };
-struct FftLaunch { int kind; u32 first_group, ngroups, total_blocks; double bytes, alg; };
+struct FftLaunch { int kind; u32 first_group, ngroups, total_blocks; double bytes, alg, bfly; };
 // fft_plan: host-side layout of every pass of every job; the caller copies plan.groups to device memory the stream can read (the
 // staging ring: one copy together with the pointer arrays) and sets d_groups; fft_run issues the launches.
 struct FftPlan { bool inverse = false; std::vector<PassArgs> groups; std::vector<FftLaunch> launches; const PassArgs* d_groups = nullptr; };
@@ -148,6 +149,8 @@ struct FriLayerArgs {
 };
 void fri_layer(hipStream_t stream, const FriLayerArgs& a);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
+// diagnostic (bfhip_clock_probe): register-only Blake2s loop, per-workgroup {d s_memtime, d s_memrealtime} stamps
+void clock_probe_launch(hipStream_t stream, uint4* d_stamps, u32* d_sink, u32 blocks, u32 iters);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy);

@@ -754,4 +754,30 @@ void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32
     hipLaunchKernelGGL(k_grind, dim3(span / 256), dim3(256), 0, stream, d_digest, base, pow_bits, d_best, mix_u64_conv);
 }
 
+// Diagnostic only (bfhip_clock_probe; never part of a proof): the shader clock this device SUSTAINS under the proof's dominant load. A
+// register-only loop of the same compression the Merkle kernels run, one chain per lane like k_merkle_layer; lane 0 of every workgroup stamps
+// the shader-cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around its loop: clock = d(memtime) / d(memrealtime) x
+// 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" item 6). The stamps go to a buffer nothing else reads. Devices of one model differ by up to
+// 12 % on such loops (same section, item 5): a bench line's VALU fraction against the nominal 2.4 GHz cannot tell a slow device from a slow
+// kernel — this number can.
+__global__ void __launch_bounds__(256) k_clock_probe(uint4* __restrict__ stamps, u32* __restrict__ sink, u32 iters) {
+    u32 h[8], m[16];
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = tid * 0x9E3779B9u + i;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = (tid ^ 0x5BD1E995u) * (2u * i + 1u);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (u32 it = 0; it < iters; it++) { blake2s_compress(h, m, it, 0); m[it & 15] ^= h[0]; }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc ^= h[i];
+    sink[tid] = acc;
+    if (threadIdx.x == 0) stamps[blockIdx.x] = uint4{(u32)(c1 - c0), (u32)((c1 - c0) >> 32), (u32)(r1 - r0), (u32)((r1 - r0) >> 32)};
+}
+void clock_probe_launch(hipStream_t stream, uint4* d_stamps, u32* d_sink, u32 blocks, u32 iters) {
+    hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, stream, d_stamps, d_sink, iters);
+}
+
 }  // namespace bf

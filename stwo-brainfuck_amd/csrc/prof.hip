@@ -14,8 +14,8 @@
 
 namespace bf {
 
-struct ProfRec { const char* name; double bytes, units; hipEvent_t e0, e1; u64 calls; };
-struct ProfAgg { u64 calls = 0; double ms = 0, bytes = 0, units = 0; };
+struct ProfRec { const char* name; double bytes, units; hipEvent_t e0, e1; u64 calls; double aux; };
+struct ProfAgg { u64 calls = 0; double ms = 0, bytes = 0, units = 0, aux = 0; };
 struct ProfState {
     int mode = 0;          // 0 off, 1 every instrumented kernel, 2 only the Merkle layer kernel, one event pair per run of back-to-back launches
     bool run = false;      // mode 2: inside a run (prof_run_begin .. prof_run_end) launches only add their counts to the run's record
@@ -48,11 +48,11 @@ void prof_enable(hipStream_t s, int mode) {
     st.mode = mode;
 }
 
-void prof_begin(hipStream_t s, const char* name, double bytes, double units) {
+void prof_begin(hipStream_t s, const char* name, double bytes, double units, double aux) {
     ProfState* st = state_of(s);
     if (!st) return;
-    if (st->run) { st->recs.back().bytes += bytes; st->recs.back().units += units; st->recs.back().calls++; return; }
-    ProfRec r{name, bytes, units, st->get_event(), st->get_event(), 1};
+    if (st->run) { st->recs.back().bytes += bytes; st->recs.back().units += units; st->recs.back().aux += aux; st->recs.back().calls++; return; }
+    ProfRec r{name, bytes, units, st->get_event(), st->get_event(), 1, aux};
     (void)hipEventRecord(r.e0, s);
     st->recs.push_back(r);
 }
@@ -63,7 +63,7 @@ void prof_end(hipStream_t s) { ProfState* st = state_of(s); if (st && !st->run) 
 void prof_run_begin(hipStream_t s, const char* name) {
     ProfState* st = state_of(s);
     if (!st || st->mode != 2 || st->run) return;
-    ProfRec r{name, 0.0, 0.0, st->get_event(), st->get_event(), 0};
+    ProfRec r{name, 0.0, 0.0, st->get_event(), st->get_event(), 0, 0.0};
     (void)hipEventRecord(r.e0, s);
     st->recs.push_back(r);
     st->run = true;
@@ -79,7 +79,7 @@ void prof_run_end(hipStream_t s) {
 static void collect(ProfState& st) {
     for (auto& r : st.recs) {
         float ms = 0;
-        if (r.calls && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = st.agg[r.name]; a.calls += r.calls; a.ms += ms; a.bytes += r.bytes; a.units += r.units; }
+        if (r.calls && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = st.agg[r.name]; a.calls += r.calls; a.ms += ms; a.bytes += r.bytes; a.units += r.units; a.aux += r.aux; }
         st.pool.push_back(r.e0); st.pool.push_back(r.e1);
     }
     st.recs.clear();
@@ -99,15 +99,15 @@ std::string prof_report_json(const hipStream_t* streams, int n) {
             auto it = g_states.find(streams[i]);
             if (it == g_states.end()) continue;
             collect(it->second);
-            for (auto& kv : it->second.agg) { auto& a = sum[kv.first]; a.calls += kv.second.calls; a.ms += kv.second.ms; a.bytes += kv.second.bytes; a.units += kv.second.units; }
+            for (auto& kv : it->second.agg) { auto& a = sum[kv.first]; a.calls += kv.second.calls; a.ms += kv.second.ms; a.bytes += kv.second.bytes; a.units += kv.second.units; a.aux += kv.second.aux; }
         }
     }
     std::string s = "{";
     bool first = true;
     for (auto& kv : sum) {
         char buf[320];
-        snprintf(buf, sizeof buf, "%s\"%s\":{\"calls\":%llu,\"total_ms\":%.6f,\"bytes\":%.0f,\"units\":%.0f}", first ? "" : ",", kv.first.c_str(), (unsigned long long)kv.second.calls,
-                 kv.second.ms, kv.second.bytes, kv.second.units);
+        snprintf(buf, sizeof buf, "%s\"%s\":{\"calls\":%llu,\"total_ms\":%.6f,\"bytes\":%.0f,\"units\":%.0f,\"aux\":%.0f}", first ? "" : ",", kv.first.c_str(), (unsigned long long)kv.second.calls,
+                 kv.second.ms, kv.second.bytes, kv.second.units, kv.second.aux);
         s += buf; first = false;
     }
     return s + "}";

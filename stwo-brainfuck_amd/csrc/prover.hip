@@ -769,14 +769,22 @@ struct HipProver {
         // queue while B's sit behind A's — each host thread waits for a stamp that cannot be written until the other posts: both give up after
         // BFHIP_MAILBOX_TIMEOUT_MS (seen with three 2^20-row proofs in flight, profiles/r05_bench.json of the first pass). A proof that does not
         // get the token keeps the order wait -> draw -> copy -> launch: behind one spinning kernel it is merely later, never stuck.
+        // The token is per GPU (hardware queues are per device), and a proof that unwinds on an error keeps it until its streams have drained:
+        // its mailbox kernels may still be spinning (the Mailbox destructors, which run first, post them) and must not meet another proof's.
         struct MailboxToken {
-            bool held = false;
-            static std::atomic<int>& flag() { static std::atomic<int> f{0}; return f; }
-            bool acquire() { int z = 0; held = flag().compare_exchange_strong(z, 1); return held; }
-            ~MailboxToken() { if (held) flag().store(0); }
-        } mailbox_token;
+            Ctx& c; bool held = false; int entered = std::uncaught_exceptions();
+            explicit MailboxToken(Ctx& c_) : c(c_) {}
+            static std::atomic<int>& flag(int device) { static std::atomic<int> f[64]; return f[device & 63]; }
+            bool acquire() { int z = 0; held = flag(c.device).compare_exchange_strong(z, 1); return held; }
+            ~MailboxToken() {
+                if (!held) return;
+                if (std::uncaught_exceptions() > entered) for (hipStream_t st : {c.stream, c.id_main, c.stream2}) if (st) (void)hipStreamSynchronize(st);
+                flag(c.device).store(0);
+            }
+        } mailbox_token(c);
         if (c.use_mailbox && !sharded() && !(c.overlap & 2u) && !mailbox_token.acquire()) c.use_mailbox = false;
         const bool mb = c.use_mailbox && !sharded() && !(c.overlap & 2u);
+        c.last_proof_flags = 0;       // completed below: what this proof actually did (bfhip_ctx_last_proof_flags)
         if (++c.proof_seq == 0) c.proof_seq = 1;
         c.reap_some();
         if (mb && c.stage_used > c.stage_bytes / 4) {
@@ -1197,6 +1205,7 @@ struct HipProver {
             tm.fri = (now() - t0) - tm.quotients;
         }
 
+        c.last_proof_flags = (mb ? 1u : 0u) | (reuse && !shared ? 2u : 0u) | (shared ? 4u : 0u);
         tm.total = now() - t_start;
         mark("done");
         print_marks();
@@ -2098,6 +2107,11 @@ extern "C" int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const
     catch (...) { release_group_after_failure(ctx); in.release(); bfhip_set_error("unknown error"); return -1; }
 }
 extern "C" void bfhip_free_host(void* p) { free(p); }
+extern "C" int32_t bfhip_ctx_last_proof_flags(bfhip_ctx* ctx, uint32_t* flags) {
+    if (!ctx || !flags) { bfhip_set_error("null argument"); return -1; }
+    *flags = ctx->c.last_proof_flags;
+    return 0;
+}
 extern "C" int32_t bfhip_ctx_reuse_preprocessed(bfhip_ctx* ctx, int32_t on) {
     if (on) { preprocessed_cache_of(&ctx->c).enabled = true; return 0; }
     std::lock_guard<std::mutex> g(g_cache_mutex);

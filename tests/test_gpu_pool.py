@@ -58,6 +58,9 @@ def test_every_proof_of_a_mixed_batch_matches_the_oracle(pkg, oracle, conv, want
             for slot, i in enumerate(order):
                 assert proofs[slot] == want[i], f"batch {rnd}, proof {slot} (program {i}) differs from the oracle (k={k}, preprocessed mode {mode})"
             assert info["batch_seconds"] > 0 and all(s > 0 for s in info["seconds"])
+            # the setting applied: every worker that proved something took (or did not take) the batch's shared tree
+            used = [pool.ctx(i).last_proof_flags() for i in range(k)]
+            assert any(u["shared_preprocessed"] for u in used) == (mode != 0) and not any(u["kept_preprocessed"] for u in used), (mode, used)
         assert pkg.verify_brainfuck(proofs[0], LMR) == (True, "")
         # an empty batch is a no-op
         assert pool.prove_batch([], log_max_rows=LMR)[0] == []

@@ -451,6 +451,53 @@ def test_bench_line_contract(tmp_path):
     assert "2^22 rows" in d["config"]["workload"] and "fib19" in d["config"]["workload"]
 
 
+def test_bench_line_is_self_explaining(tmp_path):
+    """the line must say whether the box was slow (roofline.sustained_clock_ghz from the library's in-run clock probe, the VALU
+    fraction at THAT clock beside the one at the nominal 2.4 GHz), carry the metric's own numbers inside `config` (the object the driver's record keeps
+    whole): the 2^22-row point, the same size through the library's pool from one caller thread with and without the shared preprocessed tree, the
+    sweep's ms per proof — and report the FFT kernels against their VALU bound as well as against HBM."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sweep-logs", "20,22", "--sweep-steps", "2", "--no-poseidon"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rf = d["roofline"]
+    assert 1.5 < rf["sustained_clock_ghz"] <= 2.45, rf.get("clock_probe")
+    assert abs(rf["frac_at_sustained_clock"] - rf["frac"] * 2.4 / rf["sustained_clock_ghz"]) < 2e-3 and 0.6 < rf["frac_at_sustained_clock"] < 1.02
+    cp = rf["clock_probe"]
+    assert cp["ghz_min"] <= rf["sustained_clock_ghz"] <= cp["ghz_max"] and 0.9 < cp["probe_frac_at_its_clock"] < 1.02, cp      # the register-only loop issues at its clock's peak
+    cfg = d["config"]
+    mp = cfg["metric_point"]
+    assert set(mp) == {"rows", "ms_per_proof", "cells_per_s", "sha256", "verified"} and mp["rows"] == "2^22" and mp["verified"] is True and len(mp["sha256"]) == 64
+    assert abs(mp["cells_per_s"] - d["metric_point"]["cells"] / (mp["ms_per_proof"] * 1e-3)) / mp["cells_per_s"] < 1e-3
+    assert set(cfg["sweep_ms"]) == {"2^20", "2^22"} and cfg["sweep_ms"]["2^22"] == mp["ms_per_proof"]
+    b = cfg["batch"]
+    for k in ("in_flight_2", "in_flight_3"):
+        sh, rc = b[k]["shared_preprocessed"], b[k]["recommitted_preprocessed"]
+        assert sh["same_proof_as_1"] is True and sh["ms_per_proof"] > 0 and rc["ms_per_proof"] > 0 and sh["gain_vs_1"] > 1.0, b
+        assert sh["ms_per_proof"] <= rc["ms_per_proof"] * 1.03, b            # sharing the preprocessed commitment never costs
+    assert b["ms_per_proof"] == min(b["in_flight_2"]["shared_preprocessed"]["ms_per_proof"], b["in_flight_3"]["shared_preprocessed"]["ms_per_proof"])
+    assert "one caller thread" in b["what"].lower() or "ONE caller thread" in b["what"]
+    for name, k in d["fft"]["kernels"].items():
+        assert 0.0 < k["valu_frac"] < 1.0 and k["butterflies"] > 0 and 0.0 < k["moved_frac_of_hbm_peak"] < 1.0, (name, k)
+    assert 0.0 < d["fft"]["valu_frac"] < 1.0
+
+
+def test_clock_probe_reads_a_plausible_sustained_clock(pkg):
+    """bfhip_clock_probe: d(s_memtime) / d(s_memrealtime) x 100 MHz around a register-only Blake2s loop. The clock lies between the part's floor under load
+    and its 2.4 GHz maximum, and at that clock the loop issues at the integer-VALU peak (977 lane-ops per compression, 256 CUs x 64 lanes per clock)."""
+    c = pkg.Context(0, max_log_domain=10)
+    try:
+        p = c.clock_probe(0.5)
+        assert 1.2 < p["ghz_min"] <= p["ghz"] <= p["ghz_max"] <= 2.45, p
+        assert 0.9 < p["G_compressions_per_s"] * 1e9 * 977 / (256 * 64 * p["ghz"] * 1e9) < 1.02, p
+        with pytest.raises(pkg.BfhipError):
+            c.clock_probe(0.0)
+    finally:
+        c.close()
+
+
 def test_prove_entries_reject_null_arguments(pkg, ctx):
     """Null context / trace / program text: -1 and a message, not a crash."""
     import ctypes
@@ -501,6 +548,7 @@ def test_mailbox_order_does_not_change_the_proof_and_a_late_host_fails_loudly(pk
         try:
             for _ in range(3):
                 assert pkg.prove_brainfuck(code, b"7\n", ctx=c, log_max_rows=21) == want, f"BFHIP_MAILBOX={env}"
+                assert c.last_proof_flags()["mailbox_order"] == (env == "1")       # the forced mode really applied (one proof in flight)
         finally:
             c.close()
     monkeypatch.setenv("BFHIP_MAILBOX", "1")

@@ -172,14 +172,15 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
 
 def test_bench_prints_the_replicas_line_when_the_group_never_comes_back():
     """--group-timeout: a shard group that does not finish in time (here: a limit of 0 s) cannot be interrupted — rank 0 prints the replicas line it measured
-    before the group formed (contract protocol, K steps), flagged with shard_group_error, and every rank leaves with code 0: a multi-GPU run always yields a line."""
+    before the group formed (contract protocol, K steps), flagged with shard_group_error, and every rank leaves with exit code 3 (a process stuck in a collective did
+    not succeed: ADVICE r05) — the launcher still relays rank 0's line: a multi-GPU run always yields a line, and a non-zero code when something hung."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), BFHIP_LIBRARY=TESTHOOKS_LIBRARY, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
                         "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--group-timeout", "0", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
     for f in glob.glob("/dev/shm/bfhip_mock_*"):
         os.remove(f)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode != 0 and "exit code 3" in r.stderr, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
