@@ -249,6 +249,12 @@ int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]);
 /* GPU-side milliseconds this rank's stream spent inside {all-gathers, max-reduces, grouped send-receives} since the group was joined (one
  * HIP-event pair per collective): the communication share of a proof over several GPUs. Synchronises the context's stream. */
 int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]);
+/* Per-collective latency of this rank since the group was joined (or since the last call with reset != 0), for {all-gathers, max-reduces, grouped
+ * send-receives} in that order, 7 numbers each: {count, GPU-side p50, p90, max, host-side p50, p90, max} in microseconds. GPU side = the HIP-event pair
+ * around the collective on its stream (includes waiting for the slowest peer); host side = the time the calling thread spent inside the transport's
+ * call (RCCL: the enqueue). A proof over N GPUs issues ~31 collectives of mostly small payloads: on hardware their latency decides, not their bytes.
+ * Synchronises the context's stream. */
+int32_t bfhip_ctx_group_latency(bfhip_ctx* ctx, int32_t reset, double out_us[21]);
 /* Test entry: joins an RCCL group (unique id, rank, count), runs ONE grouped send-receive on the given blocks and leaves. With the real library
  * the blocks must be device memory. In the test-hooks build of the library (libbfhip_testhooks.so, -DBFHIP_TEST_HOOKS) the environment variable
  * BFHIP_RCCL_LIBRARY names a test double of the RCCL entry points (tests/mock_rccl.c: host-memory blocks, no GPU needed); the default build

@@ -198,6 +198,17 @@ class Context:
         _check(lib().bfhip_ctx_group_times(self._h, out))
         return dict(zip(("all_gather_ms", "max_reduce_ms", "exchange_ms"), [float(v) for v in out]))
 
+    def group_latency(self, reset=False):
+        """bfhip_ctx_group_latency: per kind of collective {count, gpu_us: {p50, p90, max}, host_us: {p50, p90, max}} since the join / the last reset."""
+        out = (ctypes.c_double * 21)()
+        _check(lib().bfhip_ctx_group_latency(self._h, 1 if reset else 0, out))
+        res = {}
+        for k, name in enumerate(("all_gather", "max_reduce", "exchange")):
+            v = [float(x) for x in out[7 * k:7 * k + 7]]
+            res[name] = {"count": int(v[0]), "gpu_us": {"p50": round(v[1], 1), "p90": round(v[2], 1), "max": round(v[3], 1)},
+                         "host_us": {"p50": round(v[4], 1), "p90": round(v[5], 1), "max": round(v[6], 1)}}
+        return res
+
     def group_info(self):
         r, n, t = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_char_p()
         _check(lib().bfhip_ctx_group_info(self._h, ctypes.byref(r), ctypes.byref(n), ctypes.byref(t)))

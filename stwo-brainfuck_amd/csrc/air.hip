@@ -220,6 +220,91 @@ __global__ void __launch_bounds__(256) k_constraints_block(const ConstraintArgs*
     __shared__ uint4 s_abk[256 * 3];
     constraints_block_body<COMP>(*ap, s_abk, blockIdx.x);
 }
+// Paired blocks (r06; full-domain launches only). The previous row of the last logUp column is row ^ M with M a run of HIGH bits: a quad's
+// even elements find theirs in the even elements of ANOTHER quad, its odd elements in the odd elements of a third, and a 16-byte read of either
+// uses half of what it fetches — the column was read three times per launch (cur + 2 x half-used: the 1.28x of profiles/r05_pmc_traffic.json).
+// In half-index terms (e = row >> 1, natural index = bit_rev(e)) even rows step back by one and odd rows forward by one, and a step that only
+// toggles the top bit of e stays at the same offset of the OTHER half of the column: the even rows of the upper half (top bit set) step back onto
+// the even rows of the lower half at the same offset, the odd rows of the lower half step forward onto the odd rows of the upper half. So one
+// workgroup takes the 4096-row block L of the lower half together with the block U = L + n/2: each lane loads a quad of L and the quad of U at the
+// same offset and has, in registers, the previous rows of U's even and L's odd elements for free; only L's even and U's odd elements still fetch a
+// (half-used) quad elsewhere. 2 reads of the column per launch instead of 3, bytes and values unchanged.
+template <int COMP>
+__device__ __forceinline__ void constraints_pair_body(const ConstraintArgs& a, uint4* __restrict__ s_abk, u32 block) {
+    const u32 n = 2u << a.log_size, half = n >> 1;
+    const u32 baseL = block * 4096u;
+#pragma unroll 1
+    for (u32 h = 0; h < 2; h++) {
+        const u32 row = baseL + h * half + threadIdx.x * 16u;
+        GroupEval e(a, row);
+        air_eval<COMP>(e, a.el);
+        const u32 dinv = a.denom_inv[row >> a.log_size];
+        const Q31 A = q_mulm(e.A(), dinv), B = q_mulm(e.B(), dinv), K = q_mulm(e.K, dinv);
+        uint4* o = s_abk + 768u * h + threadIdx.x * 3;
+        o[0] = make_uint4(A.a.a, A.a.b, A.b.a, A.b.b); o[1] = make_uint4(B.a.a, B.a.b, B.b.a, B.b.b); o[2] = make_uint4(K.a.a, K.a.b, K.b.a, K.b.b);
+    }
+    __syncthreads();
+    constexpr int last = 4 * ((COMP == C_PROCESSOR ? 3 : 1) - 1);
+    g_cu32p first = as_global(a.is_first);
+    g_cu32p cur_p[4] = {as_global(a.inter[last].ptr), as_global(a.inter[last + 1].ptr), as_global(a.inter[last + 2].ptr), as_global(a.inter[last + 3].ptr)};
+    g_cu32p acc_p[4] = {as_global(a.acc[0]), as_global(a.acc[1]), as_global(a.acc[2]), as_global(a.acc[3])};
+#pragma unroll 1
+    for (u32 i = 0; i < 4; i++) {
+        const u32 q = i * 256u + threadIdx.x;
+        const u32 rL = baseL + 4u * q, rU = rL + half;
+        uint4 cL[4], cU[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) { cL[w] = ld16(cur_p[w] + rL); cU[w] = ld16(cur_p[w] + rU); }
+        const uint4 tL = ld16(first + rL), tU = ld16(first + rU);
+        // the two steps that leave the pair: L's even elements (back, borrow past the top bit) and U's odd elements (forward, carry past it)
+        const u32 peL = prev_lde_row(rL, a.log_size), peL2 = prev_lde_row(rL + 2, a.log_size);
+        const u32 poU = prev_lde_row(rU + 1, a.log_size), poU3 = prev_lde_row(rU + 3, a.log_size);
+        u32 pvL[4][4], pvU[4][4];                                  // [coordinate][row of the quad]
+        const bool quad_e = (peL & 3u) == 0 && peL2 == peL + 2, quad_o = (poU & 3u) == 1 && poU3 == poU + 2;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (quad_e) { const uint4 pe = ld16(cur_p[w] + peL); pvL[w][0] = pe.x; pvL[w][2] = pe.z; }
+            else { pvL[w][0] = cur_p[w][peL]; pvL[w][2] = cur_p[w][peL2]; }
+            if (quad_o) { const uint4 po = ld16(cur_p[w] + (poU - 1)); pvU[w][1] = po.y; pvU[w][3] = po.w; }
+            else { pvU[w][1] = cur_p[w][poU]; pvU[w][3] = cur_p[w][poU3]; }
+            pvL[w][1] = cU[w].y; pvL[w][3] = cU[w].w;             // odd rows of L step forward onto the odd rows of U, same offset
+            pvU[w][0] = cL[w].x; pvU[w][2] = cL[w].z;             // even rows of U step back onto the even rows of L, same offset
+        }
+#pragma unroll
+        for (u32 h = 0; h < 2; h++) {
+            const u32 r0 = h ? rU : rL;
+            const uint4* sa = s_abk + 768u * h + (q >> 2) * 3;
+            const uint4 a4 = sa[0], b4 = sa[1], k4 = sa[2];
+            const Q31 A = q_make(a4.x, a4.y, a4.z, a4.w), B = q_make(b4.x, b4.y, b4.z, b4.w), K = q_make(k4.x, k4.y, k4.z, k4.w);
+            const uint4 t4 = h ? tU : tL;
+            const u32 t[4] = {t4.x, t4.y, t4.z, t4.w};
+            u32 out[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                u32 x[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint4 c = h ? cU[w] : cL[w];
+                    const u32 cv = r == 0 ? c.x : r == 1 ? c.y : r == 2 ? c.z : c.w;
+                    x[w] = m_sub(cv, h ? pvU[w][r] : pvL[w][r]);
+                }
+                const Q31 v = q_add(q_add(A, q_mulm(B, t[r])), q_mul(K, q_make(x[0], x[1], x[2], x[3])));
+                out[0][r] = v.a.a; out[1][r] = v.a.b; out[2][r] = v.b.a; out[3][r] = v.b.b;
+            }
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint4 o = make_uint4(out[w][0], out[w][1], out[w][2], out[w][3]);
+                if (!a.overwrite) { const uint4 old = ld16(acc_p[w] + r0); o = make_uint4(m_add(old.x, o.x), m_add(old.y, o.y), m_add(old.z, o.z), m_add(old.w, o.w)); }
+                *reinterpret_cast<uint4*>(a.acc[w] + r0) = o;
+            }
+        }
+    }
+}
+template <int COMP>
+__global__ void __launch_bounds__(256) k_constraints_pair(const ConstraintArgs* __restrict__ ap) {
+    __shared__ uint4 s_abk[2 * 256 * 3];
+    constraints_pair_body<COMP>(*ap, s_abk, blockIdx.x);
+}
 
 // ---- all components of a proof in ONE launch ----------------------------------------------------------------------------------------
 // The components are grouped into CLASSES by evaluation-domain size (= one accumulator each). A workgroup belongs to one class and
@@ -234,7 +319,7 @@ __device__ __forceinline__ Q31 constraints_row_value(const ConstraintArgs& a, u3
 }
 #define BF_FOR_EACH_COMPONENT(X) X(C_MEMORY) X(C_INSTRUCTION) X(C_PROGRAM) X(C_PROCESSOR) X(C_JNZ) X(C_JZ) X(C_INPUT) X(C_LEFT) X(C_MINUS) X(C_OUTPUT) X(C_PLUS) X(C_RIGHT) X(C_EOE)
 __global__ void __launch_bounds__(256) k_constraints_batch(const ConstraintBatch* __restrict__ bp, const ConstraintArgs* __restrict__ args) {
-    __shared__ uint4 s_abk[256 * 3];
+    __shared__ uint4 s_abk[2 * 256 * 3];
     const ConstraintBatch& b = *bp;
     u32 ci = 0;
     while (ci + 1 < b.n_classes && b.cls[ci + 1].block0 <= blockIdx.x) ci++;      // uniform: scalar loads
@@ -243,10 +328,18 @@ __global__ void __launch_bounds__(256) k_constraints_batch(const ConstraintBatch
     if (cl.group_rows) {
         for (u32 q = 0; q < cl.n_comps; q++) {
             const ConstraintArgs& a = args[cl.comp[q]];
-            switch (cl.comp[q]) {
-#define X(C) case C: constraints_block_body<C>(a, s_abk, block); break;
-                BF_FOR_EACH_COMPONENT(X)
+            if (cl.group_rows == 32) {                     // paired blocks: 2 x 4096 rows per workgroup (full-domain launches)
+                switch (cl.comp[q]) {
+#define X(C) case C: constraints_pair_body<C>(a, s_abk, block); break;
+                    BF_FOR_EACH_COMPONENT(X)
 #undef X
+                }
+            } else {
+                switch (cl.comp[q]) {
+#define X(C) case C: constraints_block_body<C>(a, s_abk, block); break;
+                    BF_FOR_EACH_COMPONENT(X)
+#undef X
+                }
             }
             __syncthreads();      // s_abk is reused by the next component
         }
@@ -288,7 +381,7 @@ void constraint_batch_init(ConstraintBatch& b, const ConstraintLaunch* launches,
         const ConstraintLaunch& L = launches[cl.comp[0]];
         const u32 rows = L.n_rows ? L.n_rows : 2u << L.log_size;
         cl.block0 = blocks;
-        blocks += cl.group_rows ? (rows + 4095) / 4096 : (rows + 255) / 256;
+        blocks += cl.group_rows == 32 ? rows / 8192 : cl.group_rows ? (rows + 4095) / 4096 : (rows + 255) / 256;
     }
     b.total_blocks = blocks;
 }
@@ -302,12 +395,14 @@ template <int COMP>
 static void launch_c(hipStream_t s, const ConstraintArgs* a, u32 log_size, u32 n_rows, u32 group_rows) {
     u32 n = n_rows ? n_rows : 2u << log_size;
     ProfScope ps(s, "k_constraints", 0);
-    if (group_rows) hipLaunchKernelGGL(k_constraints_block<COMP>, dim3((n + 4095) / 4096), dim3(256), 0, s, a);
+    if (group_rows == 32) hipLaunchKernelGGL(k_constraints_pair<COMP>, dim3(n / 8192), dim3(256), 0, s, a);
+    else if (group_rows) hipLaunchKernelGGL(k_constraints_block<COMP>, dim3((n + 4095) / 4096), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_constraints<COMP>, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
 // 16 = the row-group kernel applies (every main column and every logUp column but the last stored replicated, shift >= 4, the last one
-// full size), 0 = per-row kernel.
+// full size), 32 = the same with two blocks per workgroup (constraints_pair_body: the launch covers the whole domain and the previous rows are
+// read from the column itself), 0 = per-row kernel. BFHIP_CONSTRAINT_PAIRS=0: A/B knob (16 instead of 32; same bytes).
 u32 constraint_group_rows(const ConstraintLaunch& L, int comp) {
     const u32 last = 4 * (n_logup_cols(comp) - 1);
     for (u32 j = 0; j < n_main_cols(comp); j++) if (L.trace[j].shift < LOG_N_LANES) return 0;
@@ -319,7 +414,9 @@ u32 constraint_group_rows(const ConstraintLaunch& L, int comp) {
     // (the suite runs the row-group kernel on small domains too)
     u32 min_log = 21;
     if (const char* v = getenv("BFHIP_CONSTRAINT_GROUP_MIN_LOG")) min_log = (u32)atoi(v);
-    return (min_log < 32 && rows >= (1u << min_log)) ? 16 : 0;
+    if (!(min_log < 32 && rows >= (1u << min_log))) return 0;
+    static const bool pairs = [] { const char* v = getenv("BFHIP_CONSTRAINT_PAIRS"); return !v || v[0] != '0'; }();
+    return (pairs && L.n_rows == 0 && !L.inter_prev[0] && rows >= 8192) ? 32 : 16;      // a pair = block L of the lower half + block U = L + rows / 2
 }
 
 void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size, u32 n_rows, u32 group_rows) {

@@ -246,6 +246,14 @@ int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]) {
     return 0;
     API_CATCH
 }
+int32_t bfhip_ctx_group_latency(bfhip_ctx* ctx, int32_t reset, double out_us[21]) {
+    API_CTX(ctx)
+    if (!out_us) throw HipError("null argument");
+    for (int i = 0; i < 21; i++) out_us[i] = 0.0;
+    if (Comm* m = ctx->c.shard.comm.get()) { ctx->c.sync(); m->latency_us(reinterpret_cast<double(*)[7]>(out_us), reset != 0); }
+    return 0;
+    API_CATCH
+}
 // Test entry (tests/test_abi_and_replicas.py with tests/mock_rccl.c as BFHIP_RCCL_LIBRARY): joins an RCCL group and runs ONE grouped
 // send-receive whose blocks live in HOST memory — RcclComm's bookkeeping (self blocks, zero-byte blocks, several blocks per peer, matching
 // order) driven through the 10 RCCL entry points without a GPU. With the real librccl the pointers must be device memory.

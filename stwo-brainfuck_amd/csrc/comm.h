@@ -42,8 +42,15 @@ struct Comm {
     // have been synchronised. Not recorded for a null stream (host-memory test transport).
     enum { T_ALL_GATHER = 0, T_ALL_REDUCE = 1, T_EXCHANGE = 2 };
     void times_ms(double out[3]);
+    // Per-collective latency since the join (or the last reset): for each kind {count, GPU-side p50 / p90 / max, host-side p50 / p90 / max} in
+    // microseconds — GPU side = the event pair around the collective on its stream (includes waiting for the slowest peer), host side = the time the
+    // calling thread spent inside the transport's call (RCCL: the enqueue). A proof over N GPUs issues ~31 collectives: their LATENCY, not their bytes,
+    // is what the first hardware run has to show. The stream must have been synchronised. reset: forget the history afterwards.
+    void latency_us(double out[3][7], bool reset);
   protected:
     struct TimedOp { hipEvent_t e0, e1; int kind; };
+    static constexpr size_t MAX_LATENCIES = 8192;        // per kind; older entries are dropped
+    std::vector<float> gpu_us_[3], host_us_[3];
     std::vector<TimedOp> pending_;
     std::vector<hipEvent_t> pool_;
     double ms_[3] = {0, 0, 0};
@@ -51,7 +58,7 @@ struct Comm {
     void drain_completed();
     static constexpr size_t MAX_PENDING = 512;
     struct Timed {      // brackets one collective
-        Comm& c; hipStream_t s; hipEvent_t e1 = nullptr;
+        Comm& c; hipStream_t s; hipEvent_t e1 = nullptr; int kind; double t0;
         Timed(Comm& c_, hipStream_t s_, int kind);
         ~Timed();
     };

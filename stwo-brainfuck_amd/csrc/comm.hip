@@ -8,6 +8,7 @@
 #include <atomic>
 #include <mutex>
 #include <cstdlib>
+#include <algorithm>
 
 namespace bf {
 
@@ -28,7 +29,12 @@ void Comm::drain_completed() {
     size_t done = 0;
     while (done < pending_.size() && hipEventQuery(pending_[done].e1) == hipSuccess) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, pending_[done].e0, pending_[done].e1) == hipSuccess) ms_[pending_[done].kind] += ms;
+        if (hipEventElapsedTime(&ms, pending_[done].e0, pending_[done].e1) == hipSuccess) {
+            ms_[pending_[done].kind] += ms;
+            auto& v = gpu_us_[pending_[done].kind];
+            if (v.size() >= MAX_LATENCIES) v.erase(v.begin(), v.begin() + (long)(MAX_LATENCIES / 2));
+            v.push_back(ms * 1e3f);
+        }
         pool_.push_back(pending_[done].e0); pool_.push_back(pending_[done].e1);
         done++;
     }
@@ -37,7 +43,8 @@ void Comm::drain_completed() {
     // a stream that is never synchronised between collectives (not how the prover runs) must not grow the list without bound either
     while (pending_.size() > MAX_PENDING) { pool_.push_back(pending_.front().e0); pool_.push_back(pending_.front().e1); pending_.erase(pending_.begin()); }
 }
-Comm::Timed::Timed(Comm& c_, hipStream_t s_, int kind) : c(c_), s(s_) {
+static double host_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+Comm::Timed::Timed(Comm& c_, hipStream_t s_, int kind_) : c(c_), s(s_), kind(kind_), t0(host_now_us()) {
     if (!s) return;
     c.drain_completed();
     hipEvent_t e0 = c.timing_event(), e1_ = nullptr;
@@ -46,15 +53,40 @@ Comm::Timed::Timed(Comm& c_, hipStream_t s_, int kind) : c(c_), s(s_) {
     e1 = e1_;
     c.pending_.push_back({e0, e1, kind});
 }
-Comm::Timed::~Timed() { if (e1) (void)hipEventRecord(e1, s); }
+Comm::Timed::~Timed() {
+    if (e1) (void)hipEventRecord(e1, s);
+    auto& v = c.host_us_[kind];
+    if (v.size() >= MAX_LATENCIES) v.erase(v.begin(), v.begin() + (long)(MAX_LATENCIES / 2));
+    v.push_back((float)(host_now_us() - t0));
+}
 void Comm::times_ms(double out[3]) {
     for (auto& t : pending_) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) ms_[t.kind] += ms;
+        if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+            ms_[t.kind] += ms;
+            auto& v = gpu_us_[t.kind];
+            if (v.size() >= MAX_LATENCIES) v.erase(v.begin(), v.begin() + (long)(MAX_LATENCIES / 2));
+            v.push_back(ms * 1e3f);
+        }
         pool_.push_back(t.e0); pool_.push_back(t.e1);
     }
     pending_.clear();
     for (int k = 0; k < 3; k++) out[k] = ms_[k];
+}
+void Comm::latency_us(double out[3][7], bool reset) {
+    double tmp[3];
+    times_ms(tmp);                       // folds the pairs still pending (the stream has been synchronised)
+    auto stats = [](std::vector<float> v, double* o) {      // by value: sorted copy
+        if (v.empty()) { o[0] = o[1] = o[2] = 0.0; return; }
+        std::sort(v.begin(), v.end());
+        o[0] = v[v.size() / 2]; o[1] = v[(v.size() * 9) / 10 < v.size() ? (v.size() * 9) / 10 : v.size() - 1]; o[2] = v.back();
+    };
+    for (int k = 0; k < 3; k++) {
+        out[k][0] = (double)gpu_us_[k].size();
+        stats(gpu_us_[k], &out[k][1]);
+        stats(host_us_[k], &out[k][4]);
+        if (reset) { gpu_us_[k].clear(); host_us_[k].clear(); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------

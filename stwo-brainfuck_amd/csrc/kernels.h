@@ -173,7 +173,7 @@ struct ConstraintLaunch {
 };
 // `d_args` points to a ConstraintLaunch staged in device memory.
 // n_rows: the launch's row count when d_args->n_rows != 0 (host copy of the same value), else 0
-// group_rows: constraint_group_rows() of the host copy of *d_args (0: one lane per row; 16: one AIR evaluation per group of 16 rows whose
+// group_rows: constraint_group_rows() of the host copy of *d_args (0: one lane per row; 32: as 16 with two 4096-row blocks per workgroup; 16: one AIR evaluation per group of 16 rows whose
 // replicated columns share a stored cell)
 void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* d_args, u32 log_size, u32 n_rows = 0, u32 group_rows = 0);
 u32 constraint_group_rows(const ConstraintLaunch& L, int comp);

@@ -27,6 +27,7 @@ def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False, overlap=0)
                 ctxs[rank].set_overlap(overlap)
             proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr, with_transcript=with_transcript)
             stats[rank] = ctxs[rank].group_stats()
+            stats[rank]["latency"] = ctxs[rank].group_latency()
         except Exception as e:      # the other ranks run into the rendezvous timeout of the library
             errors.append(e)
 
@@ -58,6 +59,11 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
     assert oracle.verify(single, lmr)[0]
     for st in _prove_sharded.last_stats:     # the work really was divided: trees hashed share-wise, columns cut into row ranges, samples reduced
         assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
+        # bfhip_ctx_group_latency: one GPU-side and one host-side duration per collective, per kind (what the first real N-GPU run reads off)
+        lat = st["latency"]
+        assert [lat[k]["count"] for k in ("all_gather", "max_reduce", "exchange")] == [st["all_gathers"], st["max_reduces"], st["exchanges"]], (lat, st)
+        for k in lat:
+            assert 0 < lat[k]["gpu_us"]["p50"] <= lat[k]["gpu_us"]["p90"] <= lat[k]["gpu_us"]["max"] and 0 < lat[k]["host_us"]["p50"] <= lat[k]["host_us"]["max"], lat
 
 
 @pytest.mark.parametrize("count", [2, 4, 8])

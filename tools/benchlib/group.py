@@ -132,6 +132,7 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
     def start_group_events():
         ctx.sync()                                   # group_times() wants a drained stream
         comm_before.update(ctx.group_times())
+        ctx.group_latency(reset=True)                # the histogram covers the timed proofs only
         start_events()
 
     comm_ms, group = {}, None
@@ -142,12 +143,9 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
         comm_ms = {k: (comm_after[k] - comm_before.get(k, 0.0)) / args.steps for k in comm_after}
         group = {"transport": ctx.group_info()[2], "per_proof_rank0": {k: round(v / (args.warmup + args.steps), 1) for k, v in ctx.group_stats().items()},
                  "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()}}
-        lat = getattr(ctx, "group_latency", None)
-        if lat is not None:
-            try:
-                group["collective_latency_us_rank0"] = lat()      # per kind: count, p50, p90, max of the GPU-side duration of every collective since the join
-            except Exception as e:
-                group["collective_latency_us_rank0"] = {"error": repr(e)}
+        # per kind of collective: count, p50 / p90 / max of the GPU-side duration and of the host-side call time over the timed proofs — "RCCL call
+        # latency x ~31 collectives per proof" beside the bytes (the first real N-GPU run has to show which of the two decides)
+        group["collective_latency_us_rank0"] = ctx.group_latency()
         out.update(dt=dt, proof=proof, phases=phases)
         ok = True
     except Exception as e:
