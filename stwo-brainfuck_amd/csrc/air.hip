@@ -416,7 +416,9 @@ u32 constraint_group_rows(const ConstraintLaunch& L, int comp) {
     if (const char* v = getenv("BFHIP_CONSTRAINT_GROUP_MIN_LOG")) min_log = (u32)atoi(v);
     if (!(min_log < 32 && rows >= (1u << min_log))) return 0;
     static const bool pairs = [] { const char* v = getenv("BFHIP_CONSTRAINT_PAIRS"); return !v || v[0] != '0'; }();
-    return (pairs && L.n_rows == 0 && !L.inter_prev[0] && rows >= 8192) ? 32 : 16;      // a pair = block L of the lower half + block U = L + rows / 2
+    // a pair = block L of the lower half + block U = L + rows / 2. From 2^24 rows up (8 x the row-group threshold): measured on fib19 (2^25 rows) the
+    // launch drops 799 -> 729 us (profiles/r06_constraint_pairs_ab.txt); at 2^23 rows the halved number of workgroups costs what the bytes save
+    return (pairs && L.n_rows == 0 && !L.inter_prev[0] && rows >= 8192 && min_log < 28 && rows >= (8u << min_log)) ? 32 : 16;
 }
 
 void eval_constraints(hipStream_t stream, int comp, const ConstraintLaunch* a, u32 log_size, u32 n_rows, u32 group_rows) {

@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r04 [part ...]'      parts: bench roofline trace inflight pmc clock fft poseidon shard latency misc   (default: all)
 # Writes into gpurun_out/<round>/ ; copy what should be judged into profiles/.
 set -u
-R=${1:-r04}; shift || true
+R=${1:-r06}; shift || true
 PARTS=${*:-bench roofline trace inflight pmc clock fft poseidon shard latency misc}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
@@ -39,13 +39,14 @@ done
 fi
 
 if has inflight; then
-# 2c. proofs in flight at the metric's own size: un-profiled ms per proof for 1 / 2 / 3 in flight, then the kernel trace of 2 in flight: how much of the
-#     time launches of BOTH queues are in flight (one proof's single-workgroup chains under the other's kernels)
-for w in 22 20 fib19; do for k in 1 2 3; do python3 "$ROOT/tools/inflight_profile.py" $w $k --rounds 8; done; done > "$OUT/${R}_inflight.jsonl" 2>/dev/null
-for k in 1 2; do
-  rm -rf /tmp/prof_if; $RP --kernel-trace --output-format csv -d /tmp/prof_if -- python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 6 --min-seconds 0 > "$OUT/inflight${k}_under_rocprof.json" 2>/dev/null
-  python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_if) --window 0.35:0.80 > "$OUT/${R}_2p22_inflight${k}_timeline_gaps.txt" 2>&1
-done
+# 2c. proofs in flight behind ONE caller thread (r06: the library's pool, bfhip_prove_batch): un-profiled ms per proof for pools of 1 / 2 / 3 sub-contexts and
+#     the three ways the pool treats the preprocessed tree, at the metric's size, 2^20 rows and fib19; beside it the round-5 pattern (k Python threads over k
+#     full contexts) at 2^22 rows; then the kernel trace of a pool of 2: how much of the time launches of BOTH proofs are in flight
+( python3 "$ROOT/tools/pool_rate.py" 22 --in-flight 1,2,3 --preprocessed 0,1,2; python3 "$ROOT/tools/pool_rate.py" 20 --in-flight 2,3 --preprocessed 0,1 --batch 24;
+  python3 "$ROOT/tools/pool_rate.py" fib19 --in-flight 2,3 --preprocessed 0,1 --batch 6; python3 "$ROOT/tools/pool_rate.py" 24 --in-flight 2,3 --preprocessed 1 --batch 6 ) > "$OUT/${R}_pool_rate.jsonl" 2>/dev/null
+for k in 1 2 3; do python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 8; done > "$OUT/${R}_inflight_threads.jsonl" 2>/dev/null
+rm -rf /tmp/prof_pool; $RP --kernel-trace --output-format csv -d /tmp/prof_pool -- python3 "$ROOT/tools/pool_rate.py" 22 --child 2,1 --batch 12 --batches 3 > "$OUT/pool2_under_rocprof.json" 2>/dev/null
+python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_pool) --window 0.55:0.90 > "$OUT/${R}_2p22_pool2_timeline_gaps.txt" 2>&1
 fi
 
 if has trace; then
