@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--shard", action="store_true", help="(default for N > 1 since round 5; kept for old command lines) the N ranks prove ONE trace together")
     ap.add_argument("--replicas", action="store_true", help="N > 1: headline = N independent proofs (weak scaling) instead of ONE proof over the shard group (strong scaling, default)")
     ap.add_argument("--no-extra-stages", action="store_true", help="N > 1: only the headline workload over the group, not the 2^24-row synthetic trace (configs 3/4) and the 2^26-row Poseidon252 trace (config 5)")
+    ap.add_argument("--group-inflight", type=int, default=1, help="N > 1: after the headline, K proofs in flight over the shard group (K contexts and host threads per rank, K communicators): "
+                    "strong_scaling.workloads.fib19_K_in_flight. Default 1 = off (two communicators driven concurrently are unmeasured with librccl itself)")
     ap.add_argument("--group-timeout", type=int, default=900, help="N > 1: seconds the shard group's headline part (join, timed proofs) and, separately, its extra stages may take; after that rank 0 prints "
                     "what was measured before (the replicas line / the strong-scaling line without the extra stages) and every rank leaves with exit code 3 (a collective that never returns cannot be interrupted)")
     ap.add_argument("--rccl-child-probe", action="store_true", help="N > 1: also run the group stages in child processes (one per rank, RCCL) before the ranks touch their GPUs (debugging a transport that takes the main process down)")
@@ -244,8 +246,11 @@ def main():
                         "parity_checked": parity_checked, **g["group"]}
                 rows = {"fib19": head}
                 for nm, st in g["extra_stages"].items():
-                    rows[nm] = ({k: st[k] for k in ("ms_per_proof", "n1_ms_per_proof", "speedup_vs_n1", "comm_share_of_proof", "identical_to_n1", "cells_per_s", "proof_sha256",
-                                                   "verified", "comm_ms_per_proof_rank0", "error", "n1_error") if k in st} if isinstance(st, dict) else {"error": st})
+                    rows[nm] = ({k: st[k] for k in ("ms_per_proof", "n1_ms_per_proof", "speedup_vs_n1", "comm_share_of_proof", "identical_to_n1", "cells_per_s", "proof_sha256", "verified",
+                                                   "comm_ms_per_proof_rank0", "error", "n1_error", "in_flight", "what", "proofs_timed", "identical_to_the_headline_proof",
+                                                   "ms_per_proof_one_in_flight", "gain_vs_one_in_flight") if k in st} if isinstance(st, dict) else {"error": st})
+                    if "ms_per_proof" in rows[nm] and "in_flight" in rows[nm]:
+                        rows[nm]["speedup_vs_n1"] = round(g["n1"]["ms_per_proof"] / rows[nm]["ms_per_proof"], 3)
                 if extras_error:
                     rows["extra_stages_error"] = extras_error
                 out["strong_scaling"] = {"n_gpus": world, "what": "ONE proof over all N GPUs (shard group, RCCL, one process per GPU); n1 = the same proof by rank 0 alone on its GPU, the other ranks idle, timed in this run",

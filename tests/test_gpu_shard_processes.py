@@ -153,7 +153,7 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BFHIP_RCCL_LIBRARY=build_ipc_double(), BFHIP_LIBRARY=TESTHOOKS_LIBRARY, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0", "--steps", "3", "--warmup", "1",
-                        "--no-extra-stages", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "900"], env=env, capture_output=True, text=True, timeout=1000)
+                        "--no-extra-stages", "--group-inflight", "2", "--no-local-probe", "--no-cpu-baseline", "--launch-timeout", "900"], env=env, capture_output=True, text=True, timeout=1000)
     for f in glob.glob("/dev/shm/bfhip_mock_*"):
         os.remove(f)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -168,6 +168,15 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     assert line["replicas"]["scaling"] == "weak" and line["replicas"]["value"] > 0
     assert line["config"]["ranks_started_by"].startswith("bench.py itself")
     assert abs(line["value"] - line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6      # one proof's cells, not N times
+    # r06: the one-GPU reference is rank 0 ALONE (the others idle at a barrier), the replicas' slowest-rank time rides beside it; per-collective latency
+    # histogram of the timed proofs (count, GPU-side and host-side p50 / p90 / max per kind) next to the bytes
+    assert "rank 0 alone" in head["n1_what"] and line["roofline"]["frac_rocprof"] is None and "share" in line["roofline"]["frac_rocprof_source"]
+    lat = head["collective_latency_us_rank0"]
+    assert lat["all_gather"]["count"] >= 3 * 4 and lat["exchange"]["count"] >= 3 * 2 and lat["all_gather"]["gpu_us"]["p50"] > 0 and lat["all_gather"]["host_us"]["max"] > 0, lat
+    # --group-inflight 2: two shard groups proving at the same time (two contexts, host threads and communicators per rank), every proof the one-GPU bytes
+    two = line["strong_scaling"]["workloads"]["fib19_2_in_flight"]
+    assert two["in_flight"] == 2 and two["identical_to_the_headline_proof"] is True and two["proofs_timed"] == 6 and two["ms_per_proof"] > 0 and "error" not in two, two
+    assert abs(two["gain_vs_one_in_flight"] - head["ms_per_proof"] / two["ms_per_proof"]) < 0.01
 
 
 def test_bench_prints_the_replicas_line_when_the_group_never_comes_back():

@@ -8,7 +8,7 @@ import threading
 import time
 
 from .shard import probe_run_stages
-from .workloads import sweep_program, want_digest
+from .workloads import FIB19, sweep_program, want_digest
 
 
 class Ranks:
@@ -170,17 +170,17 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
         out["group_rep"] = profile_report(lib, ctx)             # the dominant kernel of the TIMED group proofs (this rank's share)
         lib.bfhip_profile_enable(ctx._h, 0)
 
-    # ---- BASELINE configs 3/4 literal (synthetic 2^24-row trace) and 5 (2^26 rows, Poseidon252) over a second group, each with its one-GPU time. Under a
-    # watchdog of their own that still emits the strong-scaling line measured above (r06, ADVICE r05: the headline watchdog used to discard it).
-    if args.no_extra_stages:
+    # ---- after the headline: two proofs in flight over the shard group (on request), then BASELINE configs 3/4 literal (synthetic 2^24-row trace) and 5
+    # (2^26 rows, Poseidon252) over a second group, each with its one-GPU time. Under a watchdog of their own that still emits the strong-scaling line
+    # measured above (r06, ADVICE r05: the headline watchdog used to discard it).
+    if args.no_extra_stages and args.group_inflight < 2:
         return out
-    R.note("extra stages: 2^24-row trace (configs 3/4), 2^26-row Poseidon252 trace (config 5)")
     extra = out["extra_stages"]
 
     def extras_never_came_back():
         if rank == 0:
-            emit_partial(out, f"the extra stages did not finish within {args.group_timeout} s and could not be interrupted; the headline above was measured before them; exit code 3")
-        print(f"bench.py[rank {rank}/{world}] the extra stages did not come back within {args.group_timeout} s: leaving with exit code 3", file=sys.stderr, flush=True)
+            emit_partial(out, f"the stages after the headline did not finish within {args.group_timeout} s and could not be interrupted; the headline above was measured before them; exit code 3")
+        print(f"bench.py[rank {rank}/{world}] the stages after the headline did not come back within {args.group_timeout} s: leaving with exit code 3", file=sys.stderr, flush=True)
         if rank != 0:
             time.sleep(2.0)
         os._exit(3)
@@ -188,32 +188,110 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
     watchdog2 = threading.Timer(args.group_timeout, extras_never_came_back)
     watchdog2.daemon = True
     watchdog2.start()
-    big = None
-    try:
-        big = pkg.Context(device, max_log_domain=28)
-        ok = True
-    except Exception as e:
-        ok = False
-        extra["error"] = f"rank {rank}: creating the 2^28 context failed: {e!r}"
-    # agreed BEFORE anyone enters share_unique_id's broadcast: a rank whose context creation failed must not skip a collective the others are in
-    if R.agree(ok):
+    if args.group_inflight >= 2:
+        R.note(f"{args.group_inflight} proofs in flight over the shard group")
+        extra["fib19_%d_in_flight" % args.group_inflight] = group_inflight(args, R, pkg, ctx, trace, device, join_group, hashlib.sha256(out["proof"]).hexdigest(), out["dt"] / args.steps * 1e3)
+    if not args.no_extra_stages:
+        R.note("extra stages: 2^24-row trace (configs 3/4), 2^26-row Poseidon252 trace (config 5)")
+        big = None
         try:
-            stages = [("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, None), ("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, None)]
-            join_group(big)
-            probe_run_stages(pkg, [big], stages, {"stages": extra}, lambda: None, rank == 0, ref_device=device, max_log=28)
+            big = pkg.Context(device, max_log_domain=28)
             ok = True
         except Exception as e:
             ok = False
-            extra["error"] = f"rank {rank}: {e!r}"
-        if not R.agree(ok):
-            extra.setdefault("error", "a stage failed on another rank")
-    else:
-        extra.setdefault("error", "creating the 2^28 context failed on another rank")
-    if big is not None:
-        try:
-            big.leave_group()
-        except Exception:
-            pass
-        big.close()
+            extra["error"] = f"rank {rank}: creating the 2^28 context failed: {e!r}"
+        # agreed BEFORE anyone enters share_unique_id's broadcast: a rank whose context creation failed must not skip a collective the others are in
+        if R.agree(ok):
+            try:
+                stages = [("trace_2p24_blake2s", sweep_program(24), 24, (0, 0, 0, 0), 1, 3, None), ("trace_2p26_poseidon252", sweep_program(26), 26, (0, 0, 0, 1), 1, 1, None)]
+                join_group(big)
+                probe_run_stages(pkg, [big], stages, {"stages": extra}, lambda: None, rank == 0, ref_device=device, max_log=28)
+                ok = True
+            except Exception as e:
+                ok = False
+                extra["error"] = f"rank {rank}: {e!r}"
+            if not R.agree(ok):
+                extra.setdefault("error", "a stage failed on another rank")
+        else:
+            extra.setdefault("error", "creating the 2^28 context failed on another rank")
+        if big is not None:
+            try:
+                big.leave_group()
+            except Exception:
+                pass
+            big.close()
     watchdog2.cancel()
     return out
+
+
+def group_inflight(args, R, pkg, ctx, trace, device, join_group, want_sha, ms_one_in_flight):
+    """--group-inflight K: K proofs in flight over the shard group — every rank drives K contexts (K host threads), context j of every rank forms group j
+    (its own communicator), and the K groups prove the bench workload at the same time: the share of a sharded proof that every rank repeats (tree tops, the
+    FRI small end: S = 3.3 of 29 ms in the one-GPU projection) and the waits inside the collectives of one group are filled by the
+    other group's divided work. ms_per_proof = wall time / (K x proofs per group). Opt-in: two communicators driven concurrently from two threads are
+    exercised here through the process-per-rank double (tests/mock_rccl_ipc.cpp); with librccl itself this is unmeasured."""
+    k = args.group_inflight
+    row = {"in_flight": k, "what": f"{k} shard groups at the same time, one context and one host thread per group and rank; ms_per_proof = wall time / proofs completed"}
+    ctxs, traces, ok = [ctx], [trace], True
+    try:
+        for _ in range(k - 1):
+            c2 = pkg.Context(device, max_log_domain=args.log_max_rows + 2)
+            ctxs.append(c2)
+            traces.append(pkg.Trace(c2, FIB19, b""))
+    except Exception as e:
+        ok, row["error"] = False, f"rank {R.rank}: {e!r}"
+    if R.agree(ok):
+        joined = []
+        try:
+            for c in ctxs:                      # the same order on every rank: one unique id per group over the timing channel
+                join_group(c)
+                joined.append(c)
+            ok = True
+        except Exception as e:
+            ok, row["error"] = False, f"rank {R.rank}: joining group {len(joined)} failed: {e!r}"
+        if R.agree(ok):
+            res, errs = [None] * k, []
+
+            def run(j, n):
+                try:
+                    for _ in range(n):
+                        res[j] = traces[j].prove(args.log_max_rows)[0]
+                    ctxs[j].sync()
+                except Exception as e:
+                    errs.append(repr(e))
+
+            def wave(n):
+                th = [threading.Thread(target=run, args=(j, n)) for j in range(k)]
+                [t.start() for t in th]; [t.join() for t in th]
+
+            wave(1)                             # warm-up (the second context's arena, the groups' first collectives)
+            R.barrier()
+            t0 = time.perf_counter()
+            wave(args.steps)
+            dt = R.over_ranks(time.perf_counter() - t0, "max") if not errs else 0.0
+            ok = not errs
+            if errs:
+                row["error"] = f"rank {R.rank}: " + "; ".join(errs)
+            if R.agree(ok):
+                ms = dt / (k * args.steps) * 1e3
+                shas = [hashlib.sha256(p).hexdigest() for p in res]
+                row.update(ms_per_proof=round(ms, 3), cells_per_s=trace.cells / (ms * 1e-3), proofs_timed=k * args.steps, proof_sha256=shas[0],
+                           identical_to_the_headline_proof=all(s == want_sha for s in shas), ms_per_proof_one_in_flight=round(ms_one_in_flight, 3),
+                           gain_vs_one_in_flight=round(ms_one_in_flight / ms, 3), transport=ctxs[0].group_info()[2])
+            else:
+                row.setdefault("error", "a proof failed on another rank")
+        else:
+            row.setdefault("error", "joining a group failed on another rank")
+        for c in joined:
+            try:
+                c.leave_group()
+            except Exception:
+                pass
+    else:
+        row.setdefault("error", "creating the extra contexts failed on another rank")
+    for t2, c2 in zip(traces[1:], ctxs[1:]):
+        try:
+            t2.close(); c2.close()
+        except Exception:
+            pass
+    return row
