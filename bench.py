@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--shard", action="store_true", help="(default for N > 1 since round 5; kept for old command lines) the N ranks prove ONE trace together")
     ap.add_argument("--replicas", action="store_true", help="N > 1: headline = N independent proofs (weak scaling) instead of ONE proof over the shard group (strong scaling, default)")
     ap.add_argument("--no-extra-stages", action="store_true", help="N > 1: only the headline workload over the group, not the 2^24-row synthetic trace (configs 3/4) and the 2^26-row Poseidon252 trace (config 5)")
+    ap.add_argument("--shard-policy", type=int, default=-1, choices=[-1, 0, 1], help="N > 1: bfhip_ctx_set_shard_policy of every rank's contexts: 0 = exchange columns -> rows (column-sharded transforms), 1 = replicate "
+                    "the transforms (only hashing / quotients / folds divided), -1 = automatic (default: replicate for a group of two ranks on different GPUs)")
     ap.add_argument("--group-inflight", type=int, default=1, help="N > 1: after the headline, K proofs in flight over the shard group (K contexts and host threads per rank, K communicators): "
                     "strong_scaling.workloads.fib19_K_in_flight. Default 1 = off (two communicators driven concurrently are unmeasured with librccl itself)")
     ap.add_argument("--group-timeout", type=int, default=900, help="N > 1: seconds the shard group's headline part (join, timed proofs) and, separately, its extra stages may take; after that rank 0 prints "

@@ -218,7 +218,8 @@ int32_t bfhip_prove_brainfuck(bfhip_ctx* ctx, const char* code, const uint8_t* i
 void bfhip_free_host(void* p);
 /* What the last COMPLETED proof of this context actually did (0 before the first): bit 0 = it ran in the mailbox order (forcing mode 1 does not
  * guarantee it: one proof per GPU holds that order at a time, see bfhip_ctx_set_sync_policy), bit 1 = it took the context's kept preprocessed tree
- * (bfhip_ctx_reuse_preprocessed), bit 2 = it took a pool's shared preprocessed tree (bfhip_pool_set_preprocessed). Tests and tools read it so that
+ * (bfhip_ctx_reuse_preprocessed), bit 2 = it took a pool's shared preprocessed tree (bfhip_pool_set_preprocessed), bit 3 = shard group: the transforms were replicated
+ * (bfhip_ctx_set_shard_policy). Tests and tools read it so that
  * a setting that silently did not apply is visible. */
 int32_t bfhip_ctx_last_proof_flags(bfhip_ctx* ctx, uint32_t* flags);
 /* ---- one proof over several GPUs (shard group) ------------------------------------------------------------------------------------------
@@ -244,6 +245,15 @@ int32_t bfhip_ctx_join_local_group(bfhip_ctx* ctx, bfhip_local_group* group, uin
 int32_t bfhip_rccl_unique_id(uint8_t id[128]);
 int32_t bfhip_ctx_join_rccl_group(bfhip_ctx* ctx, const uint8_t id[128], uint32_t rank, uint32_t count);
 int32_t bfhip_ctx_leave_group(bfhip_ctx* ctx);
+/* How a shard group divides a proof (every rank of a group the same value; takes effect at the next proof; byte-identical proofs either way):
+ *   0  exchange: the transforms are column-sharded and one grouped send-receive per tree cuts the LDE columns into row ranges (the default of rounds 2-5;
+ *      1.03 / 0.84 / 0.72 GB per fib19 proof and rank at 2 / 4 / 8 ranks, over N - 1 xGMI links per GPU);
+ *   1  replicate the transforms: every rank interpolates and extends every column and evaluates the constraints on every row itself (the transforms are
+ *      20 % of a proof), and ONLY the Merkle hashing, the quotient rows and the FRI folds are divided by row range — no column -> row exchange at all,
+ *      what travels is the per-tree all-gather of 256 nodes per rank and the max-reduces;
+ *  -1  automatic (default): 1 for a group of two ranks on different GPUs (their exchange would cross ONE xGMI link: 13.5 ms at 76 GB/s against 5.6 ms of
+ *      transforms), 0 otherwise. Unmeasured on multi-GPU hardware: DESIGN.md section 7 has the arithmetic. */
+int32_t bfhip_ctx_set_shard_policy(bfhip_ctx* ctx, int32_t policy);
 /* Since the group was joined: out = {all-gathers, max-reduces, grouped send-receives, payload bytes this rank sent to other ranks}. */
 int32_t bfhip_ctx_group_stats(bfhip_ctx* ctx, uint64_t out[4]);
 /* GPU-side milliseconds this rank's stream spent inside {all-gathers, max-reduces, grouped send-receives} since the group was joined (one

@@ -151,7 +151,7 @@ class Context:
         """bfhip_ctx_last_proof_flags: {mailbox_order, kept_preprocessed, shared_preprocessed} of the last completed proof."""
         f = ctypes.c_uint32()
         _check(lib().bfhip_ctx_last_proof_flags(self._h, ctypes.byref(f)))
-        return {"mailbox_order": bool(f.value & 1), "kept_preprocessed": bool(f.value & 2), "shared_preprocessed": bool(f.value & 4)}
+        return {"mailbox_order": bool(f.value & 1), "kept_preprocessed": bool(f.value & 2), "shared_preprocessed": bool(f.value & 4), "replicated_transforms": bool(f.value & 8)}
 
     def clock_probe(self, seconds=0.6):
         """bfhip_clock_probe: {ghz (median over workgroups), ghz_min, ghz_max, G_compressions_per_s, launches, ms_per_launch} of a register-only
@@ -181,6 +181,10 @@ class Context:
         if len(unique_id) != 128:
             raise BfhipError("an RCCL unique id has 128 bytes")
         _check(lib().bfhip_ctx_join_rccl_group(self._h, unique_id, rank, count))
+
+    def set_shard_policy(self, policy=-1):
+        """bfhip_ctx_set_shard_policy: -1 automatic, 0 exchange columns -> rows, 1 replicate the transforms (every rank of a group the same)."""
+        _check(lib().bfhip_ctx_set_shard_policy(self._h, int(policy)))
 
     def leave_group(self):
         _check(lib().bfhip_ctx_leave_group(self._h))

@@ -246,6 +246,15 @@ int32_t bfhip_ctx_group_times(bfhip_ctx* ctx, double out_ms[3]) {
     return 0;
     API_CATCH
 }
+int32_t bfhip_ctx_set_shard_policy(bfhip_ctx* ctx, int32_t policy) {
+    API_CTX(ctx)
+    if (policy < -1 || policy > 1) throw HipError("bfhip_ctx_set_shard_policy: -1 = automatic, 0 = exchange columns -> rows, 1 = replicate the transforms");
+    ctx->c.sync();
+    if (policy != ctx->c.shard_policy) preprocessed_cache_invalidate(&ctx->c);
+    ctx->c.shard_policy = policy;
+    return 0;
+    API_CATCH
+}
 int32_t bfhip_ctx_group_latency(bfhip_ctx* ctx, int32_t reset, double out_us[21]) {
     API_CTX(ctx)
     if (!out_us) throw HipError("null argument");

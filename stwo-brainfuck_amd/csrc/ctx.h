@@ -50,6 +50,8 @@ struct Ctx {
     Conventions conv;               // byte-level stwo conventions (bfhip_ctx_set_conventions)
     bool tables_on_gpu = true;      // where the 13 component tables are built (bfhip_ctx_set_table_builder)
     ShardGroup shard;
+    int shard_policy = -1;          // bfhip_ctx_set_shard_policy: -1 automatic, 0 exchange columns -> rows (column-sharded transforms), 1 replicate the transforms
+    bool shard_replicate = false;   // the decision for the proof in progress (HipProver::prove)
     hipStream_t stream = nullptr;
     // side stream: the trace-independent preprocessed commitment runs here, beside the main-trace phase. Created by the first proof that uses it
     // (ensure_side): a pool worker whose proofs take the pool's shared preprocessed tree never does, and every stream a process creates takes a

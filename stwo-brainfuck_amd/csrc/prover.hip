@@ -106,11 +106,11 @@ struct TraceInput {
 // The kept tree is only valid for the configuration it was built under: LOG_MAX_ROWS, the node-hash convention and the shard group
 // (share-wise layers hold one rank's share only) — any change rebuilds it.
 struct PreprocessedCache {
-    bool enabled = false, valid = false; u32 lmr = 0, node_conv = 0, channel = 0, shard_rank = 0, shard_count = 1; DTree tree; Arena keep;
+    bool enabled = false, valid = false, replicate = false; u32 lmr = 0, node_conv = 0, channel = 0, shard_rank = 0, shard_count = 1; DTree tree; Arena keep;
     bool matches(const Ctx& c, u32 log_max_rows) const {
         // the hasher is (merkle_channel, merkle_node_hash): a Blake2s tree must never serve a Poseidon252 proof or the reverse
         return enabled && valid && lmr == log_max_rows && node_conv == c.conv.merkle_node_hash && channel == c.conv.merkle_channel &&
-               shard_rank == c.shard.rank && shard_count == c.shard.count;
+               shard_rank == c.shard.rank && shard_count == c.shard.count && replicate == (c.shard.count > 1 && c.shard_replicate);
     }
 };
 static std::mutex g_cache_mutex;   // contexts may be driven from different host threads (bench.py --inflight)
@@ -488,6 +488,14 @@ struct HipProver {
     bool sharded() const { return c.shard.count > 1; }
     u32 lc() const { return c.shard.log_count; }
     bool slice_log(u32 log) const { return sharded() && log >= lc() + SLICE_MIN_LOG_PER_RANK; }
+    // Shard policy "replicate the transforms" (bfhip_ctx_set_shard_policy, r06): every rank interpolates and extends EVERY column itself and evaluates the
+    // constraints on every row — no column -> row exchange, no rows -> columns exchange of the composition accumulators — while the Merkle band, the quotient
+    // rows and the FRI folds stay divided by row range through VIRTUALLY sliced columns: DCol::lc is set and the storage is the whole column, so the virtual
+    // base of DCol is the real base. What is exchanged shrinks to the per-tree all-gather of 256 nodes per rank and the max-reduces. For groups whose
+    // exchange would cross ONE xGMI link (N = 2: 1.03 GB per proof and rank at 76 GB/s = 13.5 ms against 5.6 ms of transforms) — DESIGN.md section 7.
+    bool replicate() const { return sharded() && c.shard_replicate; }
+    // does this rank hold the coefficients / compute the LDE of a polynomial with this owner entry?
+    bool transforms_here(u32 owner) const { return owner == OWNER_ALL || owner == c.shard.rank || replicate(); }
     // A 16x-replicated (row-granular, shift = 4) column is cut into row ranges when a rank's range still holds 2^14 STORED words — then every
     // layer it enters lies inside the share-wise Merkle band (merkle_plan) and its rows' constraint / quotient launches are range-restricted.
     bool slice_col(u32 log, u32 shift) const { return sharded() && log >= shift + lc() + SLICE_MIN_LOG_PER_RANK; }
@@ -526,7 +534,12 @@ struct HipProver {
         for (size_t i = 0; i < n; i++) {
             DCol e; e.log_size = t.polys[i].log_size + cfg.log_blowup; e.shift = t.polys[i].shift;
             if (t.owner[i] == OWNER_ALL) { e.ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(e); }
-            else {
+            else if (replicate()) {
+                // virtually sliced: the whole column is here (virtual base = real base), consumers are restricted to this rank's row range by `lc`;
+                // the mask offset -1 of a last logUp column is read from the column itself (prev stays null)
+                e.ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(e);
+                e.lc = lc();
+            } else {
                 if (t.owner[i] == c.shard.rank) {
                     full[i] = e; full[i].ptr = c.alloc_u32(e.stored()); fsrc.push_back(t.polys[i]); fdst.push_back(full[i]);
                     if (with_prev && e.shift == 0) { fullprev[i] = e; fullprev[i].ptr = c.alloc_u32(e.stored()); }
@@ -561,7 +574,7 @@ struct HipProver {
         };
         std::vector<size_t> owned;
         u32 big = 0;
-        for (size_t i = 0; i < n; i++) if (t.owner[i] != OWNER_ALL) { owned.push_back(i); big = std::max(big, t.evals[i].log_size); }
+        for (size_t i = 0; i < n; i++) if (t.owner[i] != OWNER_ALL && !replicate()) { owned.push_back(i); big = std::max(big, t.evals[i].log_size); }
         std::vector<size_t> first_wave, second_wave;
         for (size_t i : owned) (t.evals[i].log_size == big ? first_wave : second_wave).push_back(i);
         // bfhip_ctx_set_overlap bit 2 (shard groups): the largest size class is transformed first and travels on the partner stream while the
@@ -596,7 +609,7 @@ struct HipProver {
             }
         } else {
             fft_cols(false, fsrc, fdst);
-            if (sharded()) exchange_columns(c.stream, owned, nullptr);
+            if (sharded() && !replicate()) exchange_columns(c.stream, owned, nullptr);
         }
         BF_HIP(hipGetLastError());
         t.mk = merkle_commit(t.evals, pinned_root);
@@ -724,7 +737,7 @@ struct HipProver {
         IsFirstCols ifc{}; ifc.log_min = LOG_N_LANES; ifc.log_max = log_max_rows;
         if (log_max_rows - LOG_N_LANES >= 28) throw HipError("log_max_rows too large");
         for (size_t i = 0; i < tree.polys.size(); i++) {
-            if (tree.owner[i] != OWNER_ALL && tree.owner[i] != c.shard.rank) continue;
+            if (!transforms_here(tree.owner[i])) continue;
             DCol& p = tree.polys[i];
             p.ptr = c.alloc_u32(p.stored());
             ifc.ptr[p.log_size - LOG_N_LANES] = p.ptr;
@@ -759,6 +772,9 @@ struct HipProver {
         struct SpinScope { Ctx& c; double saved; ~SpinScope() { c.spin_seconds = saved; } } spin_scope{c, c.spin_seconds};
         if (!c.sync_blocking) c.spin_seconds = 8e-3;      // bfhip_ctx_set_sync_policy(blocking): hosts with more contexts than cores keep the short poll
         c.arena.reset();
+        // shard policy of this proof (every rank of a group resolves it the same way: same setting, same group size, and "spans several GPUs" is a
+        // rendezvous decision): -1 = automatic = replicate the transforms for a group of TWO ranks on different GPUs (one xGMI link would carry 1 GB)
+        c.shard_replicate = sharded() && (c.shard_policy == 1 || (c.shard_policy < 0 && c.shard.count == 2 && c.shard.comm && c.shard.comm->spans_devices()));
         // Mailboxes (mailbox.hip): one process per proof only — a shard group's exchanges are rendezvous points of their own. The ring must
         // not need recycling while a mailbox kernel waits for this thread, so it is recycled here, where nothing of this context is in flight.
         // Not by default under the blocking sync policy either: a mailbox kernel spins on the GPU until this thread posts, and a host that
@@ -871,7 +887,7 @@ struct HipProver {
             // coordinate column keeps, interpolates and extends it, so only the owner has the logUp kernel write it (the others pass a null
             // pointer: no storage, no store); the row-granular columns and the small ones are written and transformed by every rank.
             if (sharded()) trees[2].owner = assign_owners(inter_vals, cfg.log_blowup);
-            kept = [&](size_t i) { return !sharded() || trees[2].owner[i] == OWNER_ALL || trees[2].owner[i] == c.shard.rank; };
+            kept = [&](size_t i) { return !sharded() || transforms_here(trees[2].owner[i]); };
             for (size_t i = 0; i < inter_vals.size(); i++) if (kept(i)) inter_vals[i].ptr = c.alloc_u32(inter_vals[i].stored());
             for (int k = 0; k < N_COMPONENTS; k++) {
                 u32 log = bp.log_sizes[k], log_rows = log - LOG_N_LANES;
@@ -921,7 +937,7 @@ struct HipProver {
                     trees[1].owner = assign_owners(trees[1].polys, cfg.log_blowup);
                     std::vector<DCol> s_mine, p_mine;
                     for (size_t i = 0; i < src.size(); i++) {
-                        if (trees[1].owner[i] != OWNER_ALL && trees[1].owner[i] != c.shard.rank) continue;
+                        if (!transforms_here(trees[1].owner[i])) continue;
                         trees[1].polys[i].ptr = c.alloc_u32(trees[1].polys[i].stored());
                         s_mine.push_back(src[i]); p_mine.push_back(trees[1].polys[i]);
                     }
@@ -964,7 +980,7 @@ struct HipProver {
             trees[0].mk.root = *pinned_root0;
             if (cache.enabled) {
                 cache.tree = trees[0]; cache.lmr = log_max_rows; cache.node_conv = c.conv.merkle_node_hash; cache.channel = c.conv.merkle_channel;
-                cache.shard_rank = c.shard.rank; cache.shard_count = c.shard.count; cache.valid = true;
+                cache.shard_rank = c.shard.rank; cache.shard_count = c.shard.count; cache.replicate = replicate(); cache.valid = true;
             }
         }
         trees[1].mk.root = *pinned_root1;
@@ -1205,7 +1221,7 @@ struct HipProver {
             tm.fri = (now() - t0) - tm.quotients;
         }
 
-        c.last_proof_flags = (mb ? 1u : 0u) | (reuse && !shared ? 2u : 0u) | (shared ? 4u : 0u);
+        c.last_proof_flags = (mb ? 1u : 0u) | (reuse && !shared ? 2u : 0u) | (shared ? 4u : 0u) | (replicate() ? 8u : 0u);
         tm.total = now() - t_start;
         mark("done");
         print_marks();
@@ -1227,7 +1243,7 @@ struct HipProver {
             u32 log = bp.log_sizes[k], eval_log = log + 1;
             // shard group: an accumulator of a row-sharded size holds this rank's row range only (its components' interaction LDE columns
             // have the same size and are row-sharded too)
-            const bool sl = slice_log(eval_log);
+            const bool sl = slice_log(eval_log) && !replicate();      // replicate policy: every rank evaluates every row (0.7 ms of a fib19 proof) instead of exchanging rows -> columns
             if (!cp.have[eval_log]) {
                 cp.acc[eval_log].log_size = eval_log; cp.acc[eval_log].lc = sl ? lc() : 0;
                 for (int w = 0; w < 4; w++) cp.acc[eval_log].c[w] = sl ? alloc_slice(eval_log) : c.alloc_u32(size_t(1) << eval_log);
@@ -1301,8 +1317,8 @@ struct HipProver {
         // transform, no full-size accumulate. Exact field arithmetic: the coefficients are the same.
         // Shard group: the 4 coordinate columns of a row-sharded accumulator are gathered whole on their owners (coordinate w on rank
         // w mod count: rows -> columns, one grouped send-receive per size), which interpolate and merge them; ranks without a coordinate idle.
-        if (!sharded()) {
-            // one process: every size's accumulator is interpolated by the SAME batch of launches (the transforms are independent), then one
+        if (!sharded() || replicate()) {
+            // one process (or a group that replicates the transforms: every accumulator is complete on every rank): every size's accumulator is interpolated by the SAME batch of launches (the transforms are independent), then one
             // launch adds the smaller sizes' coefficients onto the largest size's
             std::vector<DCol> all_vals;
             std::vector<u32> logs;
@@ -1321,6 +1337,8 @@ struct HipProver {
             BF_HIP(hipGetLastError());
             trees[3].polys.assign(all_vals.begin(), all_vals.begin() + 4);
             trees[3].owner.assign(4, OWNER_ALL);
+            // replicate policy: the composition LDE is (virtually) row-sharded like every full-size column — commit_tree keys that on an owner entry
+            if (replicate() && slice_log(all_vals[0].log_size + cfg.log_blowup)) for (int w = 0; w < 4; w++) trees[3].owner[w] = (u32)w % c.shard.count;
             return;
         }
         bool cur_have = false; std::vector<DCol> cur(4);
@@ -1373,7 +1391,7 @@ struct HipProver {
                 for (u32 pt : mask[t][col]) {
                     const u32 ji = sp.n_all++;
                     const u32 owner = trees[t].owner.empty() ? OWNER_ALL : trees[t].owner[col];
-                    if (sharded() && (owner == OWNER_ALL ? ji % c.shard.count : owner) != c.shard.rank) continue;
+                    if (sharded() && ((owner == OWNER_ALL || replicate()) ? ji % c.shard.count : owner) != c.shard.rank) continue;
                     const DCol& p = trees[t].polys[col];
                     EvalJob j{}; j.coeffs = p.ptr; j.log_n = p.log_size - p.shift; j.point = pt; j.factor_shift = p.shift; j.partial_off = sp.partial_off; j.out_idx = ji;
                     sp.partial_off += j.log_n > 12 ? 1u << (j.log_n - 12) : 1u;

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--proofs", type=int, default=1, help="proofs to produce one after the other (the kill test asks for many)")
     ap.add_argument("--conventions", default="0,0,0,0")
+    ap.add_argument("--shard-policy", type=int, default=-1, help="bfhip_ctx_set_shard_policy: -1 automatic (two ranks on different GPUs replicate the transforms), 0 exchange, 1 replicate")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     out = {"rank": rank, "world": world, "pid": os.getpid(), "proofs": []}
@@ -51,6 +52,7 @@ def main():
     rc = 0
     try:
         ctx.set_conventions(*conv)
+        ctx.set_shard_policy(args.shard_policy)
         uid = replicas.share_unique_id(dist, pkg.rccl_unique_id)
         ctx.join_rccl_group(uid, rank, world)
         out["transport"] = ctx.group_info()[2]

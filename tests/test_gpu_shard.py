@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 PROGS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "programs")
 
 
-def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False, overlap=0):
+def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False, overlap=0, policy=None):
     """`count` contexts of this process on the one GPU, one host thread each, joined into a local shard group (bfhip_local_group_*)."""
     group = pkg.LocalGroup(count)
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(count)]
@@ -25,6 +25,8 @@ def _prove_sharded(pkg, code, inp, lmr, count, with_transcript=False, overlap=0)
             assert ctxs[rank].group_info()[:2] == (rank, count)
             if overlap:
                 ctxs[rank].set_overlap(overlap)
+            if policy is not None:
+                ctxs[rank].set_shard_policy(policy)
             proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr, with_transcript=with_transcript)
             stats[rank] = ctxs[rank].group_stats()
             stats[rank]["latency"] = ctxs[rank].group_latency()
@@ -64,6 +66,29 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
         assert [lat[k]["count"] for k in ("all_gather", "max_reduce", "exchange")] == [st["all_gathers"], st["max_reduces"], st["exchanges"]], (lat, st)
         for k in lat:
             assert 0 < lat[k]["gpu_us"]["p50"] <= lat[k]["gpu_us"]["p90"] <= lat[k]["gpu_us"]["max"] and 0 < lat[k]["host_us"]["p50"] <= lat[k]["host_us"]["max"], lat
+
+
+@pytest.mark.with_poseidon
+@pytest.mark.parametrize("count", [2, 4, 8])
+@pytest.mark.parametrize("name,inp,lmr", [("hello_kakarot.bf", b"", 17), ("collatz.bf", b"7\n", 21)])
+def test_replicated_transforms_policy_gives_the_same_proof_without_column_exchanges(pkg, ctx, oracle, name, inp, lmr, count):
+    """bfhip_ctx_set_shard_policy(1): every rank transforms every column and evaluates every constraint row itself; only the Merkle band, the quotient rows and the
+    FRI folds are divided (virtually sliced columns). Same bytes as the one-GPU proof and as the exchanging policy, far fewer bytes on the wire: no column -> row
+    send-receive of a tree, no rows -> columns exchange of the composition accumulators."""
+    code = open(os.path.join(PROGS, name)).read()
+    c1 = pkg.Context(0, max_log_domain=lmr + 2)
+    single = pkg.prove_brainfuck(code, inp, ctx=c1, log_max_rows=lmr)
+    c1.close()
+    exchanged = _prove_sharded(pkg, code, inp, lmr, count, policy=0)
+    st0 = _prove_sharded.last_stats[0]
+    replicated = _prove_sharded(pkg, code, inp, lmr, count, policy=1)
+    st1 = _prove_sharded.last_stats[0]
+    for r, p in enumerate(exchanged + replicated):
+        assert p == single, f"proof {r} differs from the single-GPU proof"
+    assert st1["all_gathers"] == st0["all_gathers"] and st1["max_reduces"] == st0["max_reduces"], (st0, st1)       # the trees' small ends and the reduces are the same
+    assert st1["exchanges"] == 0 and st0["exchanges"] >= 2 and st1["bytes_sent"] < st0["bytes_sent"], (st0, st1)      # what still travels: the trees' 256-node all-gathers and the max-reduces
+    if lmr >= 21 and count == 2:
+        assert st1["bytes_sent"] < st0["bytes_sent"] // 4, (st0, st1)
 
 
 @pytest.mark.parametrize("count", [2, 4, 8])

@@ -40,7 +40,7 @@ def free_port():
     return port
 
 
-def start_ranks(tmp_path, world, program, inp, lmr, proofs=1, extra_env=None, conv=(0, 0, 0, 0)):
+def start_ranks(tmp_path, world, program, inp, lmr, proofs=1, extra_env=None, conv=(0, 0, 0, 0), policy=-1):
     port = free_port()
     procs = []
     for r in range(world):
@@ -49,7 +49,8 @@ def start_ranks(tmp_path, world, program, inp, lmr, proofs=1, extra_env=None, co
         out = str(tmp_path / f"rank{r}.json")
         log = open(str(tmp_path / f"rank{r}.log"), "w")
         p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_worker.py"), "--program", os.path.join(PROGS, program), "--input-hex", inp.hex(),
-                              "--log-max-rows", str(lmr), "--out", out, "--proofs", str(proofs), "--conventions", ",".join(str(v) for v in conv)], env=env, stdout=log, stderr=subprocess.STDOUT)
+                              "--log-max-rows", str(lmr), "--out", out, "--proofs", str(proofs), "--conventions", ",".join(str(v) for v in conv), "--shard-policy", str(policy)],
+                             env=env, stdout=log, stderr=subprocess.STDOUT)
         procs.append((p, out, log))
     return procs
 
@@ -79,8 +80,10 @@ def finish(procs, timeout):
 
 
 @pytest.mark.with_poseidon
-@pytest.mark.parametrize("world", [2, 4])
-def test_process_group_proves_collatz_like_one_gpu(pkg, oracle, conv, tmp_path, world):
+@pytest.mark.parametrize("world,policy", [(2, 0), (2, -1), (4, -1), (4, 1)])
+def test_process_group_proves_collatz_like_one_gpu(pkg, oracle, conv, tmp_path, world, policy):
+    """policy: bfhip_ctx_set_shard_policy. -1 = automatic: a group of TWO ranks of an RCCL transport replicates the transforms (no column -> row exchange over its single
+    link), larger groups exchange; 0 / 1 force either."""
     code, inp, lmr = open(os.path.join(PROGS, "collatz.bf")).read(), b"7\n", 21
     c1 = pkg.Context(0, max_log_domain=lmr + 2)
     try:
@@ -89,14 +92,16 @@ def test_process_group_proves_collatz_like_one_gpu(pkg, oracle, conv, tmp_path, 
         c1.close()
     want, _, _ = oracle.prove(code, inp, log_max_rows=lmr)
     assert single == want
-    res = finish(start_ranks(tmp_path, world, "collatz.bf", inp, lmr, proofs=2, conv=conv), timeout=600)
+    res = finish(start_ranks(tmp_path, world, "collatz.bf", inp, lmr, proofs=2, conv=conv, policy=policy), timeout=600)
+    replicated = policy == 1 or (policy == -1 and world == 2)
     for r, (rc, data, log) in enumerate(res):
         assert rc == 0, (r, rc, data, log)
         assert "BFHIP_RCCL_LIBRARY" in data["transport"], data
         assert data["proofs"] == [hashlib.sha256(single).hexdigest()] * 2, (r, data)
         assert open(str(tmp_path / f"rank{r}.json") + ".proof", "rb").read() == single, f"rank {r}: bytes differ from the single-GPU proof"
         st = data["group_stats"]
-        assert st["all_gathers"] >= 4 and st["exchanges"] >= 2 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
+        assert st["all_gathers"] >= 4 and st["max_reduces"] >= 2 and st["bytes_sent"] > 0, st
+        assert (st["exchanges"] == 0) if replicated else (st["exchanges"] >= 2), (policy, st)
 
 
 @pytest.mark.single_conv
@@ -172,7 +177,9 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     # histogram of the timed proofs (count, GPU-side and host-side p50 / p90 / max per kind) next to the bytes
     assert "rank 0 alone" in head["n1_what"] and line["roofline"]["frac_rocprof"] is None and "share" in line["roofline"]["frac_rocprof_source"]
     lat = head["collective_latency_us_rank0"]
-    assert lat["all_gather"]["count"] >= 3 * 4 and lat["exchange"]["count"] >= 3 * 2 and lat["all_gather"]["gpu_us"]["p50"] > 0 and lat["all_gather"]["host_us"]["max"] > 0, lat
+    assert lat["all_gather"]["count"] >= 3 * 4 and lat["all_gather"]["gpu_us"]["p50"] > 0 and lat["all_gather"]["host_us"]["max"] > 0, lat
+    # two ranks of an RCCL transport: the automatic shard policy replicates the transforms — no column -> row exchange over the pair's single link
+    assert head["shard_policy"] == {"requested": -1, "replicated_transforms": True} and lat["exchange"]["count"] == 0 and head["per_proof_rank0"]["exchanges"] == 0, (head["shard_policy"], lat)
     # --group-inflight 2: two shard groups proving at the same time (two contexts, host threads and communicators per rank), every proof the one-GPU bytes
     two = line["strong_scaling"]["workloads"]["fib19_2_in_flight"]
     assert two["in_flight"] == 2 and two["identical_to_the_headline_proof"] is True and two["proofs_timed"] == 6 and two["ms_per_proof"] > 0 and "error" not in two, two

@@ -65,6 +65,7 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
         # control plane only: rank 0's RCCL unique id reaches the others through torch.distributed; every data-path exchange of the proof
         # is issued by libbfhip itself on the context's stream (RCCL over xGMI, device buffers on both ends)
         dev = R.torch.device("cuda", device) if args.dist_backend == "nccl" else None
+        c.set_shard_policy(args.shard_policy)
         c.join_rccl_group(replicas.share_unique_id(dist, pkg.rccl_unique_id, dev), rank, world)
 
     # ---- first the N independent proofs, one per GPU, under the contract's protocol (W warm-up, barrier, K steps, barrier, MAX over ranks): (a) the
@@ -141,7 +142,8 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
             dt, (proof, phases) = replicas.timed_region(one_step, args.steps, args.warmup, dist=dist, sync_fn=sync, backend_tensor=R.cuda_t, on_timed_start=start_group_events)
         comm_after = ctx.group_times()
         comm_ms = {k: (comm_after[k] - comm_before.get(k, 0.0)) / args.steps for k in comm_after}
-        group = {"transport": ctx.group_info()[2], "per_proof_rank0": {k: round(v / (args.warmup + args.steps), 1) for k, v in ctx.group_stats().items()},
+        group = {"transport": ctx.group_info()[2], "shard_policy": {"requested": args.shard_policy, "replicated_transforms": bool(ctx.last_proof_flags().get("replicated_transforms"))},
+                 "per_proof_rank0": {k: round(v / (args.warmup + args.steps), 1) for k, v in ctx.group_stats().items()},
                  "comm_ms_per_proof_rank0": {k: round(v, 3) for k, v in comm_ms.items()}}
         # per kind of collective: count, p50 / p90 / max of the GPU-side duration and of the host-side call time over the timed proofs — "RCCL call
         # latency x ~31 collectives per proof" beside the bytes (the first real N-GPU run has to show which of the two decides)

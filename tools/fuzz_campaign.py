@@ -34,7 +34,7 @@ def program(seed, cls, bound):
             return code, inp, steps
 
 
-def prove_sharded(pkg, code, inp, lmr, count, conv):
+def prove_sharded(pkg, code, inp, lmr, count, conv, policy=0):
     group = pkg.LocalGroup(count)
     ctxs = [pkg.Context(0, max_log_domain=lmr + 2) for _ in range(count)]
     proofs, errors = [None] * count, []
@@ -43,6 +43,7 @@ def prove_sharded(pkg, code, inp, lmr, count, conv):
         try:
             ctxs[rank].set_conventions(*conv)
             ctxs[rank].join_local_group(group, rank)
+            ctxs[rank].set_shard_policy(policy)
             proofs[rank] = pkg.prove_brainfuck(code, inp, ctx=ctxs[rank], log_max_rows=lmr)
         except Exception as e:
             errors.append(repr(e))
@@ -80,8 +81,11 @@ def persistent(budget, seed):
         # bfhip_ctx_set_overlap: single contexts take any of the intra-proof modes, a group the same mask on every rank (bit 2 = exchanges on the
         # partner stream changes the number of collectives)
         overlap = rng.choice((0, 0, 1, 2, 3)) if count == 1 else rng.choice((0, 0, 4, 4, 7))
+        # bfhip_ctx_set_shard_policy (r06), the same on every rank: 0 exchange columns -> rows, 1 replicate the transforms; it persists on a context, so a later
+        # case re-uses contexts whose kept preprocessed tree was built under the other policy (the cache is keyed on it)
+        policy = rng.choice((0, 1))
         case = {"seed": seed, "class": cls, "conventions": cname, "shard_count": count, "reuse_preprocessed": reuse, "lmr_slack": slack, "gpu_tables": gpu_tables, "via_trace": via_trace,
-                "overlap": overlap}
+                "overlap": overlap, "shard_policy": policy}
         try:
             code, inp, steps = program(seed, cls, bound)
             orc.set_conventions(*conv)
@@ -103,6 +107,7 @@ def persistent(budget, seed):
                         c.join_local_group(group, r)
                     c.set_table_builder(gpu_tables)
                     c.set_overlap(overlap)
+                    c.set_shard_policy(policy)
                     a = pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr)
                     if via_trace:                                                    # second proof: the cached tree (if on), a warm arena,
                         tr = pkg.Trace(c, code, inp)                                 # and the resident-trace entry instead of the one-call entry
@@ -188,7 +193,8 @@ def main():
             if got != want:
                 problems.append("single-context proof differs from the oracle's")
             if count > 1:
-                for r, p in enumerate(prove_sharded(pkg, code, inp, lmr, count, conv)):
+                case["shard_policy"] = seed & 1
+                for r, p in enumerate(prove_sharded(pkg, code, inp, lmr, count, conv, policy=seed & 1)):
                     if p != want:
                         problems.append(f"rank {r} of {count} differs from the oracle's proof")
             if pkg.verify_brainfuck(got, lmr, conv) != (True, ""):

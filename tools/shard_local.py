@@ -14,6 +14,7 @@ FIB19 = open(os.path.join(ROOT, "tests", "golden", "programs", "fib19.bf")).read
 POSEIDON = os.environ.get("SHARD_LOCAL_POSEIDON") == "1"
 SYN_LOG = int(os.environ.get("SHARD_LOCAL_LOG", "0"))
 OVERLAP = int(os.environ.get("SHARD_LOCAL_OVERLAP", "0"))      # bfhip_ctx_set_overlap mask of every rank (4: exchanges on the partner stream)
+POLICY = int(os.environ.get("SHARD_LOCAL_POLICY", "0"))        # bfhip_ctx_set_shard_policy of every rank: 0 exchange columns -> rows, 1 replicate the transforms
 
 
 def run(pkg, n, steps, lmr=24):
@@ -34,6 +35,7 @@ def run(pkg, n, steps, lmr=24):
             ctxs[r].join_local_group(group, r)
             if OVERLAP:
                 ctxs[r].set_overlap(OVERLAP)
+            ctxs[r].set_shard_policy(POLICY)
         traces[r].prove(lmr)
         # the first proof of a context loads code objects (seconds, inside whatever collective comes first): counters and collective times are
         # taken as differences over the timed proofs only
@@ -94,6 +96,7 @@ def main():
         f1 = out[0]["ms_fastest_proof"]; sf = (row["ms_fastest_proof"] - f1) / (n - 1)
         row["from_the_fastest_proofs"] = {"replicated_ms_S": round(sf, 2), "divided_ms_P": round(f1 - sf, 2), "projected_ms_with_one_gpu_per_rank": round(sf + (f1 - sf) / n, 2)}
     print(json.dumps({"workload": (f"synthetic 2^{SYN_LOG}-row trace" if SYN_LOG else "fib19.bf") + (", Poseidon252MerkleChannel" if POSEIDON else ", Blake2sMerkleChannel"),
+                      "shard_policy": "replicate the transforms (1)" if POLICY == 1 else "exchange columns -> rows (0)",
                       "runs": out}, indent=1))
 
 
