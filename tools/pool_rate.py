@@ -56,6 +56,17 @@ def child(what, k, mode, batch, batches, warm):
             secs.append(info["batch_seconds"])
         dt = time.perf_counter() - t0
         shas = {hashlib.sha256(p).hexdigest() for p in proofs}
+        if os.environ.get("POOL_RATE_PROGRAMS") == "1":
+            # host-inclusive: bfhip_prove_batch_brainfuck — VM run, table build and upload of every proof inside its worker, beside the other workers' GPU work
+            progs = [(code, b"")] * batch
+            pool.prove_batch_brainfuck(progs, lmr)
+            t1 = time.perf_counter()
+            for _ in range(batches):
+                pp, _ = pool.prove_batch_brainfuck(progs, lmr)
+            dtp = time.perf_counter() - t1
+            out["from_program_text"] = {"ms_per_proof": round(1e3 * dtp / (batch * batches), 3), "cells_per_s": cells * batch * batches / dtp,
+                                        "identical_to_plain": {hashlib.sha256(p).hexdigest() for p in pp} == {sha1},
+                                        "what": "bfhip_prove_batch_brainfuck: VM + 13 table builders + upload + proof per program, end to end (PCIe inclusive)"}
         out.update(ms_per_proof=round(1e3 * dt / (batch * batches), 3), cells_per_s=cells * batch * batches / dt, cells=cells,
                    batch_ms=[round(1e3 * s, 2) for s in secs], proof_ms_in_batch=round(1e3 * sum(info["seconds"]) / batch, 3),
                    identical_to_plain=shas == {sha1}, proof_sha256=sha1, gain_vs_plain=round(out["plain_ms_per_proof"] / (1e3 * dt / (batch * batches)), 3))

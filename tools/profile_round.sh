@@ -45,6 +45,8 @@ if has inflight; then
 ( python3 "$ROOT/tools/pool_rate.py" 22 --in-flight 1,2,3 --preprocessed 0,1,2; python3 "$ROOT/tools/pool_rate.py" 20 --in-flight 2,3 --preprocessed 0,1 --batch 24;
   python3 "$ROOT/tools/pool_rate.py" fib19 --in-flight 2,3 --preprocessed 0,1 --batch 6; python3 "$ROOT/tools/pool_rate.py" 24 --in-flight 2,3 --preprocessed 1 --batch 6 ) > "$OUT/${R}_pool_rate.jsonl" 2>/dev/null
 for k in 1 2 3; do python3 "$ROOT/tools/inflight_profile.py" 22 $k --rounds 8; done > "$OUT/${R}_inflight_threads.jsonl" 2>/dev/null
+# host-inclusive: batches of PROGRAMS (VM + tables + upload inside the workers) — fib19 and the 2^22-row synthetic program, pools of 1 / 2 / 3
+( POOL_RATE_PROGRAMS=1 python3 "$ROOT/tools/pool_rate.py" fib19 --in-flight 1,2,3 --preprocessed 1 --batch 6 --batches 3; POOL_RATE_PROGRAMS=1 python3 "$ROOT/tools/pool_rate.py" 22 --in-flight 1,3 --preprocessed 1 --batch 12 --batches 3 ) > "$OUT/${R}_pool_rate_programs.jsonl" 2>/dev/null
 rm -rf /tmp/prof_pool; $RP --kernel-trace --output-format csv -d /tmp/prof_pool -- python3 "$ROOT/tools/pool_rate.py" 22 --child 2,1 --batch 12 --batches 3 > "$OUT/pool2_under_rocprof.json" 2>/dev/null
 python3 "$ROOT/tools/timeline_gaps.py" $(kt /tmp/prof_pool) --window 0.55:0.90 > "$OUT/${R}_2p22_pool2_timeline_gaps.txt" 2>&1
 fi
