@@ -107,6 +107,12 @@ def test_a_failing_proof_does_not_take_the_batch_down(pkg, oracle, conv, wanted)
             pool.prove_batch_brainfuck([small[0], (",", b""), small[1]], log_max_rows=LMR)
         assert e.value.info["statuses"] == [0, -1, 0] and [e.value.proofs[0], e.value.proofs[2]] == want[:2]
         assert pool.prove_batch_brainfuck(small, log_max_rows=LMR)[0] == want
+        # a batch the pool cannot even start (LOG_MAX_ROWS beyond the pool's twiddle tree: the builder of the shared preprocessed tree refuses): an error, every
+        # status -1, nothing delivered — and the pool is as usable as before
+        with pytest.raises(pkg.BfhipError, match="twiddle tree too small") as e:
+            pool.prove_batch(traces[:3], log_max_rows=LMR + 4)
+        assert e.value.info["statuses"] == [-1, -1, -1] and e.value.proofs == [None, None, None]
+        assert pool.prove_batch(traces[:3], log_max_rows=LMR)[0] == want
     finally:
         for t in traces:
             t.close()
