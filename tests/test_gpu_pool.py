@@ -44,7 +44,7 @@ def _oracle_proofs(oracle, conv, wanted, programs, lmr):
     return [wanted[key][p] for p in programs]
 
 
-@pytest.mark.parametrize("k,mode", [(1, 1), (2, 0), (2, 1), (3, 1), (3, 2), (4, 0)])
+@pytest.mark.parametrize("k,mode", [(1, 1), (2, 0), (3, 1), (3, 2), (4, 0)])
 def test_every_proof_of_a_mixed_batch_matches_the_oracle(pkg, oracle, conv, wanted, k, mode):
     want = _oracle_proofs(oracle, conv, wanted, MIXED, LMR)
     pool = pkg.Pool(0, n_in_flight=k, max_log_domain=LMR + 2, preprocessed=mode)

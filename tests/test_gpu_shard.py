@@ -68,7 +68,6 @@ def test_shard_group_proof_equals_single_gpu_proof(pkg, ctx, oracle, name, inp, 
             assert 0 < lat[k]["gpu_us"]["p50"] <= lat[k]["gpu_us"]["p90"] <= lat[k]["gpu_us"]["max"] and 0 < lat[k]["host_us"]["p50"] <= lat[k]["host_us"]["max"], lat
 
 
-@pytest.mark.with_poseidon
 @pytest.mark.parametrize("count", [2, 4, 8])
 @pytest.mark.parametrize("name,inp,lmr", [("hello_kakarot.bf", b"", 17), ("collatz.bf", b"7\n", 21)])
 def test_replicated_transforms_policy_gives_the_same_proof_without_column_exchanges(pkg, ctx, oracle, name, inp, lmr, count):

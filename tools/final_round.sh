@@ -1,7 +1,7 @@
 #!/bin/bash
 # Last check of a round on the GPU box: the whole GPU suite, smoke(), then randomized parity campaigns on the final build (gpurun_out/<round>/).
 set -u
-R=${1:-r04}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
+R=${1:-r06}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/$R; mkdir -p $OUT
 timeout 2400 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_final.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $OUT/pytest_final.log | tail -1
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 cd /tmp
