@@ -56,8 +56,11 @@ def main():
           f"(un-profiled line: {ro['avg_launch_us']}) -> {comp * OPS / (ms_p * 1e-3) / VALU_PEAK:.3f} of the VALU peak under the profiler")
     pr = last_json_line(P("bench_under_rocprof.json"))["roofline"]
     print(f"   the profiled run's own HIP events: average launch {pr['avg_launch_us']} us, frac {pr['frac']}  (must agree with the CSV)")
-    print(f"HBM traffic per launch by the counters {ro.get('traffic')} B vs algorithmic {ro['hbm']['algorithmic_bytes_per_launch']} B = "
-          f"{(ro.get('traffic') or 0) / ro['hbm']['algorithmic_bytes_per_launch']:.3f}x")
+    traffic = ro.get("traffic")
+    if traffic is None and os.path.exists(P("pmc_traffic.json")):      # the line was printed before the round's counter passes were committed: read them directly
+        traffic = json.load(open(P("pmc_traffic.json"))).get(ro["kernel"], {}).get("hbm_bytes_per_launch")
+    print(f"HBM traffic per launch by the counters {traffic} B vs algorithmic {ro['hbm']['algorithmic_bytes_per_launch']} B = "
+          f"{(traffic or 0) / ro['hbm']['algorithmic_bytes_per_launch']:.3f}x")
     mp = b["metric_point"]
     print(f"metric point (2^22 rows): {mp['ms_per_proof']} ms per proof = {mp['value']:.3e} cells/s; sweep {[(r['log_domain_rows'], r['ms_per_proof']) for r in b['sweep']]}")
     pl = b.get("pipelined") or {}
