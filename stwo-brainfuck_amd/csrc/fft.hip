@@ -19,6 +19,9 @@
 #include <stdexcept>
 #include <algorithm>
 #include <vector>
+#include <mutex>
+#include <set>
+#include <string>
 
 namespace bf {
 
@@ -705,6 +708,16 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
         }
 }
 
+// BFHIP_FFT_PROF_DETAIL=1 (tools/fft_inproof.py): the profiler's record of an FFT launch carries its shape — "name/b<workgroups>/g<size groups>" — so that
+// the in-proof launches can be priced one by one (butterflies and bytes per launch against its time) instead of per kernel name.
+static const char* fft_prof_name(const char* base, const FftLaunch& L) {
+    static const bool detail = [] { const char* v = getenv("BFHIP_FFT_PROF_DETAIL"); return v && v[0] == '1'; }();
+    if (!detail) return base;
+    static std::mutex mu; static std::set<std::string> names;
+    std::lock_guard<std::mutex> g(mu);
+    return names.insert(std::string(base) + "/b" + std::to_string(L.total_blocks) + "/g" + std::to_string(L.ngroups)).first->c_str();
+}
+
 void fft_run(hipStream_t stream, const FftPlan& plan) {
     if (plan.launches.empty()) return;
     if (!plan.d_groups) throw std::runtime_error("fft_run: the plan's group table has not been staged");
@@ -714,38 +727,38 @@ void fft_run(hipStream_t stream, const FftPlan& plan) {
         const dim3 grid(L.total_blocks);
         switch (L.kind) {
             case K_TILE12: {
-                ProfScope ps(stream, inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_tile12<true>" : "k_fft_tile12<false>", L), L.bytes, L.alg, false, L.bfly);
                 static const u32 generic = [] { const char* v = getenv("BFHIP_FFT_TILE12_GENERIC"); return (v && v[0] == '1') ? 1u : 0u; }();
                 if (inverse) hipLaunchKernelGGL(k_fft_tile12<true>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
                 else hipLaunchKernelGGL(k_fft_tile12<false>, grid, dim3(256), 0, stream, g, L.ngroups, generic);
                 break; }
             case K_STRIDED5: {
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_strided7<false, 5>), grid, dim3(128), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED6: {
-                ProfScope ps(stream, inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_strided7<true>" : "k_fft_strided7<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_strided7<true, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_strided7<false, 6>), grid, dim3(256), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K8: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 8, 5>), grid, dim3(256), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K9: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 9, 5>), grid, dim3(512), 0, stream, g, L.ngroups);
                 break; }
             case K_STRIDED_K10: {
-                ProfScope ps(stream, inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_stridedK<true>" : "k_fft_stridedK<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL((k_fft_stridedK<true, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL((k_fft_stridedK<false, 10, 4>), grid, dim3(512), 0, stream, g, L.ngroups);
                 break; }
             case K_PASS: {
-                ProfScope ps(stream, inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L.bytes, L.alg, false, L.bfly);
+                ProfScope ps(stream, fft_prof_name(inverse ? "k_fft_pass<true>" : "k_fft_pass<false>", L), L.bytes, L.alg, false, L.bfly);
                 if (inverse) hipLaunchKernelGGL(k_fft_pass<true>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
                 else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
                 break; }
