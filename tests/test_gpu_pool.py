@@ -152,6 +152,35 @@ def test_pool_proofs_equal_single_context_proofs_at_2p20_rows(pkg, conv):
 
 
 @pytest.mark.single_conv
+def test_pool_under_the_blocking_sync_policy_and_with_settings_per_sub_context(pkg, oracle, conv, wanted):
+    """What a deployment with more waiting threads than cores sets: bfhip_ctx_set_sync_policy(sub-context, blocking) — the workers sleep in their waits (and
+    the automatic mailbox order switches itself off). Same bytes. A sub-context whose conventions were changed individually does not match the batch's shared
+    preprocessed tree and commits its own (its proofs then follow ITS conventions)."""
+    want = _oracle_proofs(oracle, conv, wanted, MIXED[:4], LMR)
+    pool = pkg.Pool(0, n_in_flight=3, max_log_domain=LMR + 2)
+    traces = []
+    try:
+        for i in range(3):
+            pool.ctx(i).set_sync_policy(True)
+        traces = [pkg.Trace(pool.ctx(0), c, i) for c, i in MIXED[:4]]
+        for _ in range(2):
+            proofs, _ = pool.prove_batch(traces * 2, log_max_rows=LMR)
+            assert proofs == want * 2
+        assert not any(pool.ctx(i).last_proof_flags()["mailbox_order"] for i in range(3))
+        # one worker on its own: the RFC 7693 node hash on sub-context 2 only -> its proofs are that convention's, the others' the pool's
+        pool.ctx(2).set_conventions(1, 0, 0, 0)
+        proofs, _ = pool.prove_batch(traces * 3, log_max_rows=LMR)
+        ok_default = [p == want[i % 4] for i, p in enumerate(proofs)]
+        rfc = [pkg.verify_brainfuck(p, LMR, (1, 0, 0, 0))[0] for p in proofs]
+        assert all(a != b for a, b in zip(ok_default, rfc)) and any(rfc) and any(ok_default), (ok_default, rfc)      # every proof is exactly one of the two kinds
+        assert pool.ctx(2).last_proof_flags()["shared_preprocessed"] is False and pool.ctx(0).last_proof_flags()["shared_preprocessed"] is True
+    finally:
+        for t in traces:
+            t.close()
+        pool.close()
+
+
+@pytest.mark.single_conv
 def test_sub_contexts_share_the_twiddle_tree(pkg, conv):
     pool = pkg.Pool(0, n_in_flight=3, max_log_domain=22)
     try:
