@@ -258,6 +258,7 @@ def main():
                 out["strong_scaling"] = {"n_gpus": world, "what": "ONE proof over all N GPUs (shard group, RCCL, one process per GPU); n1 = the same proof by rank 0 alone on its GPU, the other ranks idle, timed in this run",
                                          "transport": g["group"]["transport"], "workloads": rows}
                 out["replicas"] = g["replica_line"]
+                out["replicas_pool"] = g.get("replicas_pool")      # node throughput at the metric's size: a pool of 3 per GPU, one caller thread per rank
             if shard_probe_result is not None:
                 # the same stages by ONE process driving all N GPUs over the in-process transport (peer copies), and on request the RCCL child probes
                 out["shard_group_single_process"] = shard_probe_result.get("single_process")

@@ -184,6 +184,9 @@ def test_bench_launches_its_own_ranks_and_headlines_the_shard_group(tmp_path):
     assert lat["all_gather"]["count"] >= 3 * 4 and lat["all_gather"]["gpu_us"]["p50"] > 0 and lat["all_gather"]["host_us"]["max"] > 0, lat
     # two ranks of an RCCL transport: the automatic shard policy replicates the transforms — no column -> row exchange over the pair's single link
     assert head["shard_policy"] == {"requested": -1, "replicated_transforms": True} and lat["exchange"]["count"] == 0 and head["per_proof_rank0"]["exchanges"] == 0, (head["shard_policy"], lat)
+    # a pool of 3 per rank at the metric's size, all ranks at once: the node's deployable throughput (weak scaling; here both pools share ONE GPU)
+    rp = line["replicas_pool"]
+    assert "error" not in rp and rp["value"] > 0 and rp["in_flight_per_gpu"] == 3 and len(rp["proof_sha256"]) == 64 and abs(rp["value"] - 2 * rp["cells_per_s_per_gpu"]) / rp["value"] < 1e-3, rp
     # --group-inflight 2: two shard groups proving at the same time (two contexts, host threads and communicators per rank), every proof the one-GPU bytes
     two = line["strong_scaling"]["workloads"]["fib19_2_in_flight"]
     assert two["in_flight"] == 2 and two["identical_to_the_headline_proof"] is True and two["proofs_timed"] == 6 and two["ms_per_proof"] > 0 and "error" not in two, two

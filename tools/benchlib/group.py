@@ -94,6 +94,10 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
                  "note": "rank 0 alone on its GPU, every other rank idle at a barrier (same process, same context as the group's proofs)",
                  "replicas_ms_per_proof_slowest_rank": replica_line["ms_per_step"]}
 
+    # ---- deployable node throughput at the metric's size: a pool of 3 per GPU (bfhip_prove_batch from one caller thread per rank), all ranks at the same time, no
+    # data-path collective — weak scaling of what INTEGRATION.md section 4b deploys. Never `value`; a failure costs only this field.
+    out["replicas_pool"] = replicas_pool(args, R, pkg, device)
+
     def group_never_came_back():
         # the group's part has not finished within --group-timeout: a collective that cannot be interrupted from here (a hung bootstrap, a wedged queue).
         # Rank 0 prints the replicas line and every rank leaves — with a NON-ZERO code (r06, ADVICE r05: a process that has touched the GPU and is stuck
@@ -224,6 +228,48 @@ def run(args, R, pkg, replicas, ctx, trace, device, conv, one_step, sync, start_
             big.close()
     watchdog2.cancel()
     return out
+
+
+def replicas_pool(args, R, pkg, device, log=22, k=3, batch=12, batches=3):
+    """Every rank proves batches of the synthetic 2^22-row trace (the metric's size) through its own pool of k sub-contexts; barrier, timed batches, barrier, MAX
+    over ranks; value = cells of all ranks / time."""
+    row = {"what": f"N pools of {k} (one per GPU, one caller thread each): batches of {batch} proofs of the synthetic 2^{log}-row trace, all ranks at once, no data-path collective",
+           "in_flight_per_gpu": k, "scaling": "weak"}
+    pool = tr = None
+    ok, dt, cells, sha = True, 0.0, 0, None
+    try:
+        pool = pkg.Pool(device, n_in_flight=k, max_log_domain=log + 2)
+        tr = pkg.Trace(pool.ctx(0), sweep_program(log), b"")
+        traces, cells = [tr] * batch, tr.cells
+        pool.prove_batch(traces, log, want_json=False)
+    except Exception as e:
+        ok, row["error"] = False, f"rank {R.rank}: {e!r}"
+    if R.agree(ok):
+        try:
+            R.barrier()
+            t0 = time.perf_counter()
+            for _ in range(batches):
+                pool.prove_batch(traces, log, want_json=False)
+            dt = time.perf_counter() - t0
+            sha = hashlib.sha256(pool.prove_batch(traces[:1], log)[0][0]).hexdigest()
+        except Exception as e:
+            ok, row["error"] = False, f"rank {R.rank}: {e!r}"
+        dt = R.over_ranks(dt, "max")
+        if R.agree(ok) and dt > 0:
+            total = R.over_ranks(cells * batch * batches, "sum")
+            row.update(value=total / dt, unit="trace cells/s", ms_per_proof_per_gpu=round(dt / (batch * batches) * 1e3, 3), cells_per_s_per_gpu=round(total / dt / R.world), proof_sha256=sha)
+        else:
+            row.setdefault("error", "a batch failed on another rank")
+    else:
+        row.setdefault("error", "creating the pool failed on another rank")
+    try:
+        if tr is not None:
+            tr.close()
+        if pool is not None:
+            pool.close()
+    except Exception:
+        pass
+    return row
 
 
 def group_inflight(args, R, pkg, ctx, trace, device, join_group, want_sha, ms_one_in_flight):
