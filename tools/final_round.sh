@@ -8,3 +8,4 @@ cd /tmp
 timeout 600 python3 $ROOT/tools/fuzz_campaign.py 360 44000 fresh > $OUT/${R}_fuzz_final_fresh.json 2> $OUT/fuzz_fresh.err; echo "fuzz fresh rc=$?"
 timeout 600 python3 $ROOT/tools/fuzz_campaign.py 360 45000 persistent > $OUT/${R}_fuzz_final_persistent.json 2> $OUT/fuzz_pers.err; echo "fuzz persistent rc=$?"
 BFHIP_MAILBOX=1 timeout 400 python3 $ROOT/tools/fuzz_campaign.py 180 46000 fresh > $OUT/${R}_fuzz_final_mailbox_on.json 2> $OUT/fuzz_mb.err; echo "fuzz mailbox rc=$?"
+timeout 500 python3 $ROOT/tools/fuzz_campaign.py 300 47000 pool > $OUT/${R}_fuzz_final_pool.json 2> $OUT/fuzz_pool.err; echo "fuzz pool rc=$?"

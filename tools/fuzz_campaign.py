@@ -3,7 +3,7 @@
 seeded random Brainfuck programs of four size classes, every convention set (Poseidon252 on the smaller classes — its CPU oracle is slow),
 proved (a) by the CPU oracle, (b) by one context, (c) by a local shard group of 2/4/8 contexts. All proofs of one case must be the
 same bytes and both verifiers must accept them. Prints one JSON summary; exit code 1 on any mismatch.
-Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000] [fresh|persistent] [xl case every n-th = 11]
+Usage: python tools/fuzz_campaign.py [seconds=600] [first_seed=10000] [fresh|persistent|pool] [xl case every n-th = 11]
 persistent: ONE set of 8 long-lived contexts instead of fresh ones per case — between cases they join and leave groups of changing size,
 switch conventions, toggle the preprocessed-tree cache and prove with LOG_MAX_ROWS above the trace's need (state carried across proofs:
 arena, caches, staging ring, group membership)."""
@@ -157,11 +157,77 @@ def persistent(budget, seed):
     return 0 if summary["ok"] else 1
 
 
+def pool_campaign(budget, seed):
+    """r06: random BATCHES through long-lived pools (bfhip_pool_*): pools of 1..4 sub-contexts that live for the whole campaign, every batch 2..8 random programs of the
+    small / medium classes (one LOG_MAX_ROWS per batch = the largest need + slack), handed over as resident traces or as program text, under a convention set and a
+    preprocessed mode that change from batch to batch on the SAME pool (shared-tree invalidation, kept trees across batches, workers re-using their sub-contexts).
+    Every proof of every batch must be the CPU oracle's bytes."""
+    pkg = load_package()
+    orc = Oracle()
+    orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
+    convs = [c for c in CONVENTIONS.items() if c[0] != "poseidon"] + [("poseidon", CONVENTIONS["poseidon"])]
+    MAXLOG = 19
+    pools = {k: pkg.Pool(0, n_in_flight=k, max_log_domain=MAXLOG + 2) for k in (1, 2, 3, 4)}
+    summary = {"mode": "pool", "seconds": budget, "first_seed": seed, "batches": 0, "proofs": 0, "by_pool_size": {}, "by_preprocessed_mode": {}, "by_conventions": {}, "via_program_text": 0, "failures": []}
+    t_end = time.time() + budget
+    rng = random.Random(seed)
+    while time.time() < t_end:
+        k = rng.choice((1, 2, 2, 3, 3, 4))
+        mode = rng.choice((0, 1, 1, 2))
+        cname, conv = convs[rng.randrange(len(convs) - 1)] if rng.random() < 0.9 else convs[-1]
+        via_text = rng.random() < 0.4
+        n = rng.randint(2, 8)
+        case = {"seed": seed, "pool": k, "preprocessed": mode, "conventions": cname, "n": n, "via_program_text": via_text}
+        try:
+            progs = []
+            for _ in range(n):
+                cls, bound = CLASSES[0] if (cname == "poseidon" or rng.random() < 0.6) else CLASSES[1]
+                code, inp, _ = program(seed, cls, bound)
+                progs.append((code, inp)); seed += 1
+            orc.set_conventions(*conv)
+            lmr = max(max(max(orc.log_sizes(c, i)[0]) for c, i in progs), 8) + rng.choice((0, 0, 1))
+            if lmr > MAXLOG:
+                continue
+            want = [orc.prove(c, i, log_max_rows=lmr)[0] for c, i in progs]
+            pool = pools[k]
+            pool.set_conventions(*conv)
+            pool.set_preprocessed(mode)
+            if via_text:
+                got, _ = pool.prove_batch_brainfuck(progs, log_max_rows=lmr)
+            else:
+                traces = [pkg.Trace(pool.ctx(rng.randrange(k)), c, i) for c, i in progs]
+                try:
+                    got, _ = pool.prove_batch(traces, log_max_rows=lmr)
+                finally:
+                    for t in traces:
+                        t.close()
+            bad = [i for i in range(n) if got[i] != want[i]]
+            if bad:
+                case["problems"] = [f"proofs {bad} of the batch differ from the oracle's"]; case["codes"] = [progs[i][0] for i in bad]
+                summary["failures"].append(case)
+            summary["proofs"] += n
+        except Exception as e:
+            case["problems"] = [repr(e)]
+            summary["failures"].append(case)
+        summary["batches"] += 1
+        summary["via_program_text"] += int(via_text)
+        for key, v in (("by_pool_size", str(k)), ("by_preprocessed_mode", str(mode)), ("by_conventions", cname)):
+            summary[key][v] = summary[key].get(v, 0) + 1
+    for p in pools.values():
+        p.close()
+    summary["last_seed"] = seed - 1
+    summary["ok"] = not summary["failures"]
+    print(json.dumps(summary, indent=1))
+    return 0 if summary["ok"] else 1
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
     if len(sys.argv) > 3 and sys.argv[3] == "persistent":
         return persistent(budget, seed)
+    if len(sys.argv) > 3 and sys.argv[3] == "pool":
+        return pool_campaign(budget, seed)
     pkg = load_package()
     orc = Oracle()
     orc.L.orc_set_threads(min(64, len(os.sched_getaffinity(0))))
