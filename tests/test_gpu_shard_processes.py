@@ -212,6 +212,23 @@ def test_bench_prints_the_replicas_line_when_the_group_never_comes_back():
     assert abs(line["value"] - 2 * line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6      # two proofs per step: one per rank
 
 
+def test_bench_replicas_headline_and_python_threads_in_flight():
+    """The two other shapes of the line: `--gpus 2 --replicas` (N independent proofs, weak scaling, no group is formed) and `--inflight 2` at N = 1 (two contexts and host
+    threads per step: the round-5 pattern, kept for comparison with the pool)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--replicas", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--launch-timeout", "600"], env=env, capture_output=True, text=True, timeout=700)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["parity_checked"] is True and "strong_scaling" not in line and "shard_group_error" not in line
+    assert abs(line["value"] - 2 * line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6 and line["config"]["parallelism"] == "replicas"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--inflight", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-sweep"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 1 and line["config"]["proofs_in_flight_per_gpu"] == 2 and line["roofline"] is None and line["parity_checked"] is True
+    assert abs(line["value"] - 2 * line["config"]["cells_per_proof"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
