@@ -555,33 +555,44 @@ __global__ void __launch_bounds__((1 << (K + CL)) / 32) k_fft_stridedK(const Pas
     }
 }
 
-// Tiny transforms (log <= 5): one thread per column, straight loops over registers/local memory. Only the handful of
-// 16..32-cell columns of empty sub-component tables take this route.
+// Tiny transforms (log <= 5: the 16..32-cell columns of empty sub-component tables, end_of_execution, and their row-granular forms down to ONE cell): one LANE per
+// cell, 64 >> log columns per wave, the butterflies as lane exchanges (__shfl_xor) — a launch of six such kernels per proof used to cost 13-15 us each (one thread
+// per column looping over a 32-word array in scratch memory: a latency chain), r06: the whole transform is five dependent exchanges behind one round of loads.
 template <bool INV>
-__global__ void k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
+__global__ void __launch_bounds__(64) k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
     const BlockOfGroup bg = find_group(groups, ngroups);
     const PassArgs a = groups[bg.g];
-    u32 col = bg.tile * blockDim.x + threadIdx.x;
-    if (col >= a.ncols) return;
-    u32 n = 1u << a.log;
-    u32 v[32];
-    for (u32 i = 0; i < n; i++) v[i] = a.src[col][i & a.src_mask];
-    for (u32 jj = 0; jj < a.k; jj++) {
-        u32 j = INV ? jj : a.k - 1 - jj;
-        u32 dist = 1u << j;
-        for (u32 b = 0; b < n / 2; b++) {
-            u32 i0 = ((b >> j) << (j + 1)) | (b & (dist - 1));
-            u32 h = b >> j, tw;
+    const u32 n = 1u << a.log, lane = threadIdx.x, i = lane & (n - 1), col = bg.tile * (64u >> a.log) + (lane >> a.log);
+    const bool act = col < a.ncols;
+    u32 v = act ? a.src[col][i & a.src_mask] : 0u;
+    // this cell's twiddle in every layer (pair block h = i >> (j + 1)): independent loads, one round trip
+    u32 tw[5];
+#pragma unroll
+    for (u32 j = 0; j < 5; j++) {
+        tw[j] = 1u;
+        if (j < a.k) {
+            const u32 h = i >> (j + 1);
             if (a.circle && j == 0) {
                 const u32* l0 = layer_table(a, 1);
-                u32 x = l0[(h >> 2) * 2], y = l0[(h >> 2) * 2 + 1], sel = h & 3;
-                tw = sel == 0 ? y : sel == 1 ? m_neg(y) : sel == 2 ? m_neg(x) : x;
-            } else tw = layer_table(a, j)[h];
-            if (INV) { u32 v0 = v[i0], v1 = v[i0 + dist]; v[i0] = m_add(v0, v1); v[i0 + dist] = m_mul(m_sub(v0, v1), tw); }
-            else { u32 v0 = v[i0], v1 = m_mul(v[i0 + dist], tw); v[i0] = m_add(v0, v1); v[i0 + dist] = m_sub(v0, v1); }
+                const u32 x = l0[(h >> 2) * 2], y = l0[(h >> 2) * 2 + 1], sel = h & 3;
+                tw[j] = sel == 0 ? y : sel == 1 ? m_neg(y) : sel == 2 ? m_neg(x) : x;
+            } else tw[j] = layer_table(a, j)[h];
         }
     }
-    for (u32 i = 0; i < n; i++) a.dst[col][i] = INV ? m_mul(v[i], a.scale) : v[i];
+#pragma unroll
+    for (u32 jj = 0; jj < 5; jj++) {
+        if (jj >= a.k) break;                                         // uniform
+        const u32 j = INV ? jj : a.k - 1 - jj;
+        const u32 other = (u32)__shfl_xor((int)v, 1 << j);           // every lane of the wave takes part (inactive columns carry zeros)
+        const bool hi = (i >> j) & 1u;
+        const u32 x = hi ? other : v, y = hi ? v : other;            // (v0, v1) of this cell's butterfly; both lanes of a pair compute the product
+        u32 t = 0;
+#pragma unroll
+        for (u32 q = 0; q < 5; q++) if (q == j) t = tw[q];
+        if (INV) v = hi ? m_mul(m_sub(x, y), t) : m_add(x, y);
+        else { const u32 w = m_mul(y, t); v = hi ? m_sub(x, w) : m_add(x, w); }
+    }
+    if (act) a.dst[col][i] = INV ? m_mul(v, a.scale) : v;
 }
 
 // Host-side pass planner. Inverse: contiguous pass first then strided passes upward; forward: mirror image.
@@ -605,7 +616,7 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
         if (log <= 5) {
             a.dst = job.d_dst; a.src = job.d_src; a.src_mask = (1u << src_log) - 1; a.lo = 0; a.k = nl;
             a.scale = inverse ? m_inv(1u << log) : 1;
-            a.grid_x = (ncols + 63) / 64; a.cols_per_block = 1;
+            a.grid_x = (ncols + (64u >> log) - 1) / (64u >> log); a.cols_per_block = 1;      // k_fft_tiny: a lane per cell, 64 >> log columns per wave
             items.push_back({0, K_TINY, a, 0.0, 0.0});
             max_np = std::max(max_np, 1);
             continue;
