@@ -103,7 +103,11 @@ void is_first_coeffs(hipStream_t stream, const IsFirstCols& a, const u32* itw, u
 // groups[g].block0 <= b < groups[g + 1].block0 and is its (tile, column block) = ((b - block0) % grid_x, (b - block0) / grid_x). The 13
 // components of a proof have ~10 distinct sizes: one launch per pass and kernel kind instead of one per size.
 // ---------------------------------------------------------------------------------------------------------------------
+// kernel kinds of a launch. PassArgs::kind != 0 marks a group that rides in ANOTHER kind's launch: the single-pass transforms of 2^6..2^11 cells (K_PASS) and the tiny
+// ones (K_TINY) of a plan join its contiguous-tile launch (r06: a proof issued ~24 separate 5-18 us launches for them, each a latency chain on an otherwise idle GPU)
+enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_STRIDED_K8 = 5, K_STRIDED_K9 = 6, K_STRIDED_K10 = 7, K_KINDS = 8 };
 struct BlockOfGroup { u32 g, tile, by; };
+template <bool INV> __device__ __forceinline__ void fft_tiny_body(const PassArgs& a, const BlockOfGroup& bg);      // defined with k_fft_tiny below
 __device__ __forceinline__ BlockOfGroup find_group(const PassArgs* __restrict__ groups, u32 ngroups) {
     u32 g = 0;
     while (g + 1 < ngroups && groups[g + 1].block0 <= blockIdx.x) g++;      // uniform: scalar loads
@@ -119,12 +123,9 @@ __device__ __forceinline__ const u32* layer_table(const PassArgs& a, u32 layer) 
     return a.tw + (a.tw_total - 2 * len);
 }
 
+// s_val, s_tw: TILE words each (s_tw: per-layer twiddle segments of this tile, packed)
 template <bool INV>
-__global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __restrict__ groups, u32 ngroups) {
-    const BlockOfGroup bg = find_group(groups, ngroups);
-    const PassArgs a = groups[bg.g];
-    __shared__ u32 s_val[TILE];
-    __shared__ u32 s_tw[TILE];  // per-layer twiddle segments of this tile, packed
+__device__ __forceinline__ void fft_pass_body(const PassArgs& a, const BlockOfGroup& bg, u32* __restrict__ s_val, u32* __restrict__ s_tw) {
     const u32 t = threadIdx.x;
     const u32 lo = a.lo, k = a.k;
     const u32 c = lo == 0 ? 0 : CHUNK_LOG;
@@ -212,6 +213,15 @@ __global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __rest
             st16(dst + gidx, v);
         }
     }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(FFT_THREADS) k_fft_pass(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
+    __shared__ u32 s_val[TILE];
+    __shared__ u32 s_tw[TILE];
+    fft_pass_body<INV>(a, bg, s_val, s_tw);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -385,6 +395,9 @@ __global__ void __launch_bounds__(256) k_fft_tile12(const PassArgs* __restrict__
     const PassArgs a = groups[bg.g];
     __shared__ __attribute__((aligned(16))) u32 s_val[4096 + 4 * 64];
     __shared__ u32 s_tw[4096];
+    // guests of this launch (fft_plan): small single-pass transforms and tiny ones, in the same LDS (4096 words each suffice)
+    if (a.kind == K_PASS) { fft_pass_body<INV>(a, bg, s_val, s_tw); return; }
+    if (a.kind == K_TINY) { fft_tiny_body<INV>(a, bg); return; }
     const u32 k = generic ? 0u : a.k;                  // generic: A/B knob (BFHIP_FFT_TILE12_GENERIC=1), same bytes
     if (k == 12) fft_tile12_body<INV, 12>(a, bg, s_val, s_tw);
     else if (k == 11) fft_tile12_body<INV, 11>(a, bg, s_val, s_tw);
@@ -559,10 +572,9 @@ __global__ void __launch_bounds__((1 << (K + CL)) / 32) k_fft_stridedK(const Pas
 // cell, 64 >> log columns per wave, the butterflies as lane exchanges (__shfl_xor) — a launch of six such kernels per proof used to cost 13-15 us each (one thread
 // per column looping over a 32-word array in scratch memory: a latency chain), r06: the whole transform is five dependent exchanges behind one round of loads.
 template <bool INV>
-__global__ void __launch_bounds__(64) k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
-    const BlockOfGroup bg = find_group(groups, ngroups);
-    const PassArgs a = groups[bg.g];
-    const u32 n = 1u << a.log, lane = threadIdx.x, i = lane & (n - 1), col = bg.tile * (64u >> a.log) + (lane >> a.log);
+__device__ __forceinline__ void fft_tiny_body(const PassArgs& a, const BlockOfGroup& bg) {
+    const u32 n = 1u << a.log, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, i = lane & (n - 1);
+    const u32 col = (bg.tile * (blockDim.x >> 6) + wave) * (64u >> a.log) + (lane >> a.log);
     const bool act = col < a.ncols;
     u32 v = act ? a.src[col][i & a.src_mask] : 0u;
     // this cell's twiddle in every layer (pair block h = i >> (j + 1)): independent loads, one round trip
@@ -594,15 +606,20 @@ __global__ void __launch_bounds__(64) k_fft_tiny(const PassArgs* __restrict__ gr
     }
     if (act) a.dst[col][i] = INV ? m_mul(v, a.scale) : v;
 }
+template <bool INV>
+__global__ void __launch_bounds__(256) k_fft_tiny(const PassArgs* __restrict__ groups, u32 ngroups) {
+    const BlockOfGroup bg = find_group(groups, ngroups);
+    const PassArgs a = groups[bg.g];
+    fft_tiny_body<INV>(a, bg);
+}
 
 // Host-side pass planner. Inverse: contiguous pass first then strided passes upward; forward: mirror image.
 // fft_plan lays out the passes of every job (one job = the columns of one size and storage); the pass a job executes pi-th goes into
 // the launch (pi, kernel kind), so a batch of jobs costs at most (passes of the largest job) x (kinds in use) launches.
-enum { K_TILE12 = 0, K_STRIDED5 = 1, K_STRIDED6 = 2, K_PASS = 3, K_TINY = 4, K_STRIDED_K8 = 5, K_STRIDED_K9 = 6, K_STRIDED_K10 = 7, K_KINDS = 8 };
 
 void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, const u32* tw, const u32* itw, u32 tw_root_log) {
     plan.inverse = inverse; plan.groups.clear(); plan.launches.clear(); plan.d_groups = nullptr;
-    struct Item { int pi, kind; PassArgs a; double bytes, alg; double bfly() const { return 0.5 * a.ncols * (double)(1u << a.log) * a.k; } };      // butterflies of the pass
+    struct Item { int pi, kind; PassArgs a; double bytes, alg; bool single = false; double bfly() const { return 0.5 * a.ncols * (double)(1u << a.log) * a.k; } };      // butterflies of the pass
     std::vector<Item> items;
     int max_np = 0;
     for (size_t ji = 0; ji < njobs; ji++) {
@@ -616,8 +633,8 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
         if (log <= 5) {
             a.dst = job.d_dst; a.src = job.d_src; a.src_mask = (1u << src_log) - 1; a.lo = 0; a.k = nl;
             a.scale = inverse ? m_inv(1u << log) : 1;
-            a.grid_x = (ncols + (64u >> log) - 1) / (64u >> log); a.cols_per_block = 1;      // k_fft_tiny: a lane per cell, 64 >> log columns per wave
-            items.push_back({0, K_TINY, a, 0.0, 0.0});
+            a.grid_x = (ncols + (256u >> log) - 1) / (256u >> log); a.cols_per_block = 1;      // k_fft_tiny: a lane per cell, 64 >> log columns per wave, 4 waves per workgroup
+            items.push_back({0, K_TINY, a, 0.0, 0.0, true});
             max_np = std::max(max_np, 1);
             continue;
         }
@@ -699,8 +716,18 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
             while ((u64)ntiles * ((ncols + cpb - 1) / cpb) > 8192 && cpb < ncols) cpb *= 2;
             a.cols_per_block = cpb;
             PassArgs b = a; b.grid_x = ntiles; b.block0 = (ncols + cpb - 1) / cpb;
-            items.push_back({pi, K_PASS, b, 8.0 * ncols * (double)(1u << log), alg});
+            items.push_back({pi, K_PASS, b, 8.0 * ncols * (double)(1u << log), alg, np == 1 && log < (u32)TILE_LOG});
         }
+    }
+    // The small fry rides along: single-pass transforms of < 2^12 cells and the tiny ones touch columns of their own, so they can join ANY launch of the plan — the
+    // first contiguous-tile launch takes them as guest groups (PassArgs::kind). BFHIP_FFT_FUSE_SMALL=0: A/B knob (separate launches as before; same bytes).
+    {
+        static const bool fuse = [] { const char* v = getenv("BFHIP_FFT_FUSE_SMALL"); return !v || v[0] != '0'; }();
+        int host_pi = -1;
+        for (auto& it : items) if (it.kind == K_TILE12 && (host_pi < 0 || it.pi < host_pi)) host_pi = it.pi;
+        if (fuse && host_pi >= 0)
+            for (auto& it : items)
+                if (it.single && (it.kind == K_PASS || it.kind == K_TINY)) { it.a.kind = (u32)it.kind; it.kind = K_TILE12; it.pi = host_pi; }
     }
     for (int pi = 0; pi < max_np; pi++)
         for (int kind = 0; kind < K_KINDS; kind++) {
@@ -709,7 +736,7 @@ void fft_plan(FftPlan& plan, bool inverse, const FftJob* jobs, size_t njobs, con
             for (auto& it : items) {
                 if (it.pi != pi || it.kind != kind) continue;
                 PassArgs a = it.a;
-                const u32 gy = kind == K_TINY ? 1u : a.block0;
+                const u32 gy = (kind == K_TINY || a.kind == K_TINY) ? 1u : a.block0;
                 a.block0 = blocks; blocks += a.grid_x * gy;
                 plan.groups.push_back(a);
                 L.bytes += it.bytes; L.alg += it.alg; L.bfly += it.bfly();
@@ -774,8 +801,8 @@ void fft_run(hipStream_t stream, const FftPlan& plan) {
                 else hipLaunchKernelGGL(k_fft_pass<false>, grid, dim3(FFT_THREADS), 0, stream, g, L.ngroups);
                 break; }
             default:
-                if (inverse) hipLaunchKernelGGL(k_fft_tiny<true>, grid, dim3(64), 0, stream, g, L.ngroups);
-                else hipLaunchKernelGGL(k_fft_tiny<false>, grid, dim3(64), 0, stream, g, L.ngroups);
+                if (inverse) hipLaunchKernelGGL(k_fft_tiny<true>, grid, dim3(256), 0, stream, g, L.ngroups);
+                else hipLaunchKernelGGL(k_fft_tiny<false>, grid, dim3(256), 0, stream, g, L.ngroups);
         }
     }
 }

@@ -91,6 +91,7 @@ struct PassArgs {
     u32 tw_total;             // 2^R
     const u32* tw;            // twiddle (forward) or inverse-twiddle (inverse) layered buffer
     u32 block0, grid_x;       // first workgroup of this group within its launch; tiles per column block
+    u32 kind;                 // 0: the launch's own kernel; else the kind (fft.hip: K_PASS, K_TINY) of a small transform that rides in a contiguous-tile launch
 };
 struct FftLaunch { int kind; u32 first_group, ngroups, total_blocks; double bytes, alg, bfly; };
 // fft_plan: host-side layout of every pass of every job; the caller copies plan.groups to device memory the stream can read (the
