@@ -372,6 +372,13 @@ int32_t bfhip_profile_report(bfhip_ctx* ctx, char** json);
  * devices of one model differ by up to 12 % on compute-bound loops, and a line that only knows the nominal clock cannot tell a slow device from a
  * slow kernel. Never part of a proof. */
 int32_t bfhip_clock_probe(bfhip_ctx* ctx, double seconds, double out[6]);
+/* The same question under the REAL dominant kernel: k_merkle_layer itself (an inner layer of 2^log_nodes nodes, 16 <= log_nodes <= 26, over pseudo-random hashes: VALU plus its memory traffic) is
+ * launched back to back for `seconds` while a one-wave sampler on the context's other stream stamps the shader-cycle counter against the 100 MHz counter from before the
+ * first launch until the host stops it — no stamp executes in the kernel itself. out = {GHz the device held under that mix, 10^9 compressions/s of the kernel on this shape,
+ * launches, us per launch, 1 if the sampler spanned the window (0: it ran into its own bound and the clock is not to be trusted), seconds the sampler covered}. A device can
+ * hold its clock under the register-only loop of bfhip_clock_probe and still be slow in a proof (measured, r06): probing the proof's own largest layer shape (log_nodes 25:
+ * 3 GiB of hashes in flight) is what tells. Uses 96 B x 2^log_nodes of device memory for the duration of the call. Never part of a proof. */
+int32_t bfhip_clock_probe_mix(bfhip_ctx* ctx, double seconds, uint32_t log_nodes, double out[6]);
 
 #ifdef __cplusplus
 }

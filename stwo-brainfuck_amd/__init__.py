@@ -160,6 +160,15 @@ class Context:
         _check(lib().bfhip_clock_probe(self._h, ctypes.c_double(seconds), out))
         return dict(zip(("ghz", "ghz_min", "ghz_max", "G_compressions_per_s", "launches", "ms_per_launch"), [float(v) for v in out]))
 
+    def clock_probe_mix(self, seconds=0.5, log_nodes=22):
+        """bfhip_clock_probe_mix: {ghz, G_compressions_per_s, launches, us_per_launch, sampler_spanned_the_window, sampler_seconds} — the clock held under the REAL
+        Merkle kernel (sidecar sampler) and that kernel's rate on an inner layer of 2^log_nodes nodes."""
+        out = (ctypes.c_double * 6)()
+        _check(lib().bfhip_clock_probe_mix(self._h, ctypes.c_double(seconds), int(log_nodes), out))
+        d = dict(zip(("ghz", "G_compressions_per_s", "launches", "us_per_launch", "sampler_spanned_the_window", "sampler_seconds"), [float(v) for v in out]))
+        d["sampler_spanned_the_window"] = bool(d["sampler_spanned_the_window"])
+        return d
+
     def memory(self):
         """bfhip_ctx_memory: {arena_reserved, arena_peak, twiddles, arena_in_use} in bytes."""
         out = (ctypes.c_uint64 * 4)()

@@ -182,6 +182,67 @@ int32_t bfhip_clock_probe(bfhip_ctx* ctx, double seconds, double out[6]) {
     API_CATCH
 }
 
+// Diagnostic: the clock the device holds under the REAL Merkle kernel (VALU + its memory traffic), and that kernel's rate on a fixed shape.
+int32_t bfhip_clock_probe_mix(bfhip_ctx* ctx, double seconds, uint32_t log_nodes, double out[6]) {
+    API_CTX(ctx)
+    if (!out) throw HipError("null argument");
+    if (!(seconds > 0.0) || seconds > 10.0) throw HipError("bfhip_clock_probe_mix: seconds must be in (0, 10]");
+    Ctx& c = ctx->c;
+    c.ensure_side();
+    c.sync();
+    BF_HIP(hipStreamSynchronize(c.stream2));
+    if (log_nodes < 16 || log_nodes > 26) throw HipError("bfhip_clock_probe_mix: log_nodes must be in [16, 26]");
+    const u32 log = log_nodes;                            // an inner layer of 2^log nodes without columns: one compression per node, 96 B of traffic per node
+    const size_t prev_words = (size_t(2) << log) * 8, out_words = (size_t(1) << log) * 8;
+    u32 *d_prev = nullptr, *d_out = nullptr; uint4* d_stamp = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    u32* stop = reinterpret_cast<u32*>(c.h_small + 3456);     // a pinned word between the flag and stamp slots (unused by proofs)
+    uint4 st[2] = {};
+    u64 launches = 0; float ms = 0.f;
+    try {
+        BF_HIP(hipMalloc((void**)&d_prev, prev_words * sizeof(u32)));
+        BF_HIP(hipMalloc((void**)&d_out, out_words * sizeof(u32)));
+        BF_HIP(hipMalloc((void**)&d_stamp, 2 * sizeof(uint4)));
+        BF_HIP(hipEventCreate(&e0)); BF_HIP(hipEventCreate(&e1));
+        fill_mix(c.stream, d_prev, prev_words);
+        for (int k = 0; k < 8; k++) merkle_layer(c.stream, d_out, d_prev, nullptr, 0, log, 0.0, 0, 0, 0);      // warm
+        BF_HIP(hipGetLastError());
+        c.sync();
+        __atomic_store_n(stop, 0u, __ATOMIC_RELEASE);
+        // the sampler first (it is resident before the wide launches arrive), bounded by 4 x the window whatever happens
+        clock_sampler_launch(c.stream2, d_stamp, c.small_alias(stop), (unsigned long long)(seconds * 4.0 * 1e8));
+        BF_HIP(hipEventRecord(e0, c.stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            for (int k = 0; k < (log >= 24 ? 4 : 32); k++) { merkle_layer(c.stream, d_out, d_prev, nullptr, 0, log, 0.0, 0, 0, 0); launches++; }
+            BF_HIP(hipGetLastError());
+            c.sync();
+        }
+        BF_HIP(hipEventRecord(e1, c.stream));
+        c.sync();
+        __atomic_store_n(stop, 1u, __ATOMIC_RELEASE);
+        BF_HIP(hipStreamSynchronize(c.stream2));
+        BF_HIP(hipMemcpy(st, d_stamp, sizeof st, hipMemcpyDeviceToHost));
+        BF_HIP(hipEventElapsedTime(&ms, e0, e1));
+    } catch (...) {
+        __atomic_store_n(stop, 1u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(c.stream2);
+        (void)hipFree(d_prev); (void)hipFree(d_out); (void)hipFree(d_stamp); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+        throw;
+    }
+    (void)hipFree(d_prev); (void)hipFree(d_out); (void)hipFree(d_stamp); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double cyc = (double)(((u64)st[0].y << 32) | st[0].x), ticks = (double)(((u64)st[0].w << 32) | st[0].z);
+    const double comp = (double)launches * (double)(size_t(1) << log);
+    out[0] = ticks > 0 ? cyc / ticks * 0.1 : 0.0;                    // GHz under the real kernel's mix
+    out[1] = ms > 0 ? comp / (ms * 1e-3) / 1e9 : 0.0;                // G compressions/s of k_merkle_layer on this shape (includes the host's sync gaps: 32 launches per sync)
+    out[2] = (double)launches;
+    out[3] = ms > 0 ? ms / (double)launches * 1e3 : 0.0;             // us per launch
+    out[4] = (double)st[1].x;                                        // 1: the sampler was stopped by the host (it spanned the window); 0: it ran into its own bound
+    out[5] = ticks * 1e-8;                                           // seconds the sampler covered
+    return 0;
+    API_CATCH
+}
+
 int32_t bfhip_ctx_create(int32_t device_id, uint32_t max_log_domain, bfhip_ctx** out) {
     API_TRY
     if (!out) throw HipError("null argument");

@@ -152,6 +152,9 @@ void fri_layer(hipStream_t stream, const FriLayerArgs& a);
 void grind_span(hipStream_t stream, const u32* d_digest, u64 base, u32 span, u32 pow_bits, unsigned long long* d_best, u32 mix_u64_conv);
 // diagnostic (bfhip_clock_probe): register-only Blake2s loop, per-workgroup {d s_memtime, d s_memrealtime} stamps
 void clock_probe_launch(hipStream_t stream, uint4* d_stamps, u32* d_sink, u32 blocks, u32 iters);
+// diagnostic (bfhip_clock_probe_mix): a one-wave clock sampler that runs beside the real Merkle kernel; pseudo-random fill of its input layer
+void clock_sampler_launch(hipStream_t stream, uint4* d_out, const u32* d_stop_alias, unsigned long long max_ticks);
+void fill_mix(hipStream_t stream, u32* p, size_t n);
 // Blake2sChannel::mix_root(root) + draw_felt() on the device. d_chan = digest[8] || n_sent; d_alpha8 receives alpha[4] || alpha^2[4],
 // d_root_copy a copy of the root.
 void channel_mix_root_draw(hipStream_t stream, u32* d_chan, const u32* d_root, u32* d_alpha8, u32* d_root_copy);

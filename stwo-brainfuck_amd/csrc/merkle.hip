@@ -776,6 +776,33 @@ __global__ void __launch_bounds__(256) k_clock_probe(uint4* __restrict__ stamps,
     sink[tid] = acc;
     if (threadIdx.x == 0) stamps[blockIdx.x] = uint4{(u32)(c1 - c0), (u32)((c1 - c0) >> 32), (u32)(r1 - r0), (u32)((r1 - r0) >> 32)};
 }
+// Sidecar of bfhip_clock_probe_mix: ONE wave that sleeps beside the real Merkle kernel (launched on the context's other stream) and stamps the shader-cycle counter
+// against the 100 MHz counter when it starts and when the host raises `*stop` (pinned memory) — or after max_ticks of the 100 MHz counter, whichever comes first. The
+// clock domain is the chip's, so the quotient is the clock the device holds under the REAL kernel's mix of VALU and memory traffic, with no stamp in the kernel itself.
+__global__ void k_clock_sampler(uint4* __restrict__ out, const volatile u32* __restrict__ stop, unsigned long long max_ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    u32 stopped = 0;
+    while (r1 - r0 < max_ticks) {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+        if (*stop) { stopped = 1; break; }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = uint4{(u32)(c1 - c0), (u32)((c1 - c0) >> 32), (u32)(r1 - r0), (u32)((r1 - r0) >> 32)};
+    out[1] = uint4{stopped, 0u, 0u, 0u};
+}
+void clock_sampler_launch(hipStream_t stream, uint4* d_out, const u32* d_stop_alias, unsigned long long max_ticks) {
+    hipLaunchKernelGGL(k_clock_sampler, dim3(1), dim3(64), 0, stream, d_out, d_stop_alias, max_ticks);
+}
+// pseudo-random fill of a hash layer (the probe hashes "random data": the clock a device holds depends on the operands)
+__global__ void k_fill_mix(u32* __restrict__ p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { u32 x = (u32)i * 0x9E3779B9u + 0x7F4A7C15u; x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15; p[i] = x; }
+}
+void fill_mix(hipStream_t stream, u32* p, size_t n) { hipLaunchKernelGGL(k_fill_mix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, n); }
 void clock_probe_launch(hipStream_t stream, uint4* d_stamps, u32* d_sink, u32 blocks, u32 iters) {
     hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, stream, d_stamps, d_sink, iters);
 }

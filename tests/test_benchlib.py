@@ -27,14 +27,26 @@ def test_dominant_roofline_is_the_valu_roofline_of_the_merkle_kernel():
 
 def test_sustained_clock_fields():
     class Ctx:
-        def __init__(self, ghz): self.ghz = ghz
-        def clock_probe(self, seconds): return {"ghz": self.ghz, "ghz_min": self.ghz - 0.03, "ghz_max": self.ghz + 0.01, "G_compressions_per_s": 39.9 * self.ghz / 2.4, "launches": 200, "ms_per_launch": 2.6}
+        def __init__(self, ghz, mix_ghz=None, mix_rate=35.8, spanned=True):
+            self.ghz, self.mix_ghz, self.mix_rate, self.spanned = ghz, mix_ghz or ghz, mix_rate, spanned
+        def clock_probe(self, seconds): return {"ghz": self.ghz, "ghz_min": self.ghz - 0.03, "ghz_max": self.ghz + 0.01, "G_compressions_per_s": 39.9 * self.ghz / 2.4, "launches": 32, "ms_per_launch": 27.0}
+        def clock_probe_mix(self, seconds, log_nodes=22): return {"ghz": self.mix_ghz, "G_compressions_per_s": self.mix_rate, "launches": 4288.0, "us_per_launch": 117.0, "sampler_spanned_the_window": self.spanned, "sampler_seconds": 0.5}
     base = {"bound": "valu", "achieved": 32.75, "frac": 0.833}
-    slow = roofline.add_sustained_clock(dict(base), Ctx(2.19))            # round 5's driver box, as it would read now
+    slow = roofline.add_sustained_clock(dict(base), Ctx(2.19, mix_rate=32.0))            # a device that holds 2.19 GHz under both probes
     assert slow["sustained_clock_ghz"] == 2.19 and abs(slow["frac_at_sustained_clock"] - 0.833 * 2.4 / 2.19) < 2e-3 and slow["clock_probe"]["device_is_slow"] is True
+    assert "clock" in slow["clock_probe"]["device_is_slow_because"]
     fast = roofline.add_sustained_clock(dict(base, achieved=35.85, frac=0.9117), Ctx(2.386))
-    assert fast["clock_probe"]["device_is_slow"] is False and abs(fast["frac_at_sustained_clock"] - 0.9117 * 2.4 / 2.386) < 2e-3
+    assert fast["clock_probe"]["device_is_slow"] is False and fast["clock_probe"]["device_is_slow_because"] is None and abs(fast["frac_at_sustained_clock"] - 0.9117 * 2.4 / 2.386) < 2e-3
     assert 0.99 < fast["clock_probe"]["probe_frac_at_its_clock"] < 1.0           # 39.9 G compressions/s x 977 ops at 2.4 GHz = 0.991 of the issue slots
+    # round 6's second kind of slow box: both clocks hold, the REAL kernel is 6 % slower on the fixed shape
+    mem = roofline.add_sustained_clock(dict(base, achieved=33.6, frac=0.8554), Ctx(2.392, mix_ghz=2.168, mix_rate=33.53))
+    assert mem["sustained_clock_ghz"] == 2.168 and mem["clock_probe"]["device_is_slow"] is True and "real HBM traffic" in mem["clock_probe"]["device_is_slow_because"]
+    assert mem["clock_probe"]["merkle_kernel"]["vs_builder_boxes"] == round(33.53 / 35.8, 4) and abs(mem["frac_at_sustained_clock"] - 0.8554 * 2.4 / 2.168) < 2e-3
+    ok = roofline.add_sustained_clock(dict(base, achieved=36.0, frac=0.9156), Ctx(2.398, mix_ghz=2.317, mix_rate=36.15))      # the fastest box seen: the two fractions at their clocks agree (0.947)
+    assert ok["clock_probe"]["device_is_slow"] is False and abs(ok["frac_at_sustained_clock"] - mem["frac_at_sustained_clock"]) < 0.01
+    # the sampler that did not span its window is not trusted: the register-only clock stands
+    ns = roofline.add_sustained_clock(dict(base), Ctx(2.38, mix_ghz=1.0, spanned=False))
+    assert ns["sustained_clock_ghz"] == 2.38
     class Broken:
         def clock_probe(self, seconds): raise RuntimeError("no probe")
     b = roofline.add_sustained_clock(dict(base), Broken())                      # the probe must never cost the line

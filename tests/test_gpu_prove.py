@@ -466,7 +466,10 @@ def test_bench_line_is_self_explaining(tmp_path):
     assert 1.5 < rf["sustained_clock_ghz"] <= 2.45, rf.get("clock_probe")
     assert abs(rf["frac_at_sustained_clock"] - rf["frac"] * 2.4 / rf["sustained_clock_ghz"]) < 2e-3 and 0.6 < rf["frac_at_sustained_clock"] < 1.02
     cp = rf["clock_probe"]
-    assert cp["ghz_min"] <= rf["sustained_clock_ghz"] <= cp["ghz_max"] and 0.9 < cp["probe_frac_at_its_clock"] < 1.02, cp      # the register-only loop issues at its clock's peak
+    assert 0.9 < cp["probe_frac_at_its_clock"] < 1.02 and cp["register_only"]["ghz_min"] <= cp["register_only"]["ghz"] <= cp["register_only"]["ghz_max"], cp      # the register-only loop issues at its clock's peak
+    mk = cp["merkle_kernel"]                                                   # the real kernel on a fixed shape beside a one-wave clock sampler
+    assert mk["sampler_spanned_the_window"] is True and rf["sustained_clock_ghz"] == mk["ghz"] and 0.8 < mk["frac_of_nominal_valu_peak"] < 1.0 and 0.85 < mk["vs_builder_boxes"] < 1.1, mk
+    assert isinstance(cp["device_is_slow"], bool) and (cp["device_is_slow_because"] is None) == (not cp["device_is_slow"])
     cfg = d["config"]
     mp = cfg["metric_point"]
     assert set(mp) == {"rows", "ms_per_proof", "cells_per_s", "sha256", "verified"} and mp["rows"] == "2^22" and mp["verified"] is True and len(mp["sha256"]) == 64
@@ -487,13 +490,18 @@ def test_bench_line_is_self_explaining(tmp_path):
 def test_clock_probe_reads_a_plausible_sustained_clock(pkg):
     """bfhip_clock_probe: d(s_memtime) / d(s_memrealtime) x 100 MHz around a register-only Blake2s loop. The clock lies between the part's floor under load
     and its 2.4 GHz maximum, and at that clock the loop issues at the integer-VALU peak (977 lane-ops per compression, 256 CUs x 64 lanes per clock)."""
-    c = pkg.Context(0, max_log_domain=10)
+    c = pkg.Context(0, max_log_domain=14)
     try:
         p = c.clock_probe(0.5)
         assert 1.2 < p["ghz_min"] <= p["ghz"] <= p["ghz_max"] <= 2.45, p
         assert 0.9 < p["G_compressions_per_s"] * 1e9 * 977 / (256 * 64 * p["ghz"] * 1e9) < 1.02, p
         with pytest.raises(pkg.BfhipError):
             c.clock_probe(0.0)
+        # the same under the real Merkle kernel: a one-wave sampler on the other stream spans the window of back-to-back k_merkle_layer launches
+        m = c.clock_probe_mix(0.3)
+        assert m["sampler_spanned_the_window"] is True and 0.25 < m["sampler_seconds"] < 1.0 and 1.2 < m["ghz"] <= 2.45 and m["launches"] >= 64, m
+        assert 0.8 < m["G_compressions_per_s"] * 1e9 * 977 / (256 * 64 * 2.4e9) < 1.0, m
+        assert pkg.prove_brainfuck("+++>,<[>+.<-]", b"\x01", ctx=c, log_max_rows=12) is not None        # the context proves as before (the probe's pinned word and side stream are its own)
     finally:
         c.close()
 
