@@ -19,7 +19,7 @@ if has bench; then
 # 1. headline bench line (roofline measured live with HIP events, CPU baseline on the host cores)
 python3 "$ROOT/bench.py" > "$OUT/bench.log" 2>&1; grep '^{"metric"' "$OUT/bench.log" | tail -1 > "$OUT/${R}_bench.json"
 # 2. same command under rocprofv3 --kernel-trace --stats (per-kernel average durations must agree with the roofline object)
-rm -rf /tmp/prof_stats; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon > "$OUT/bench_under_rocprof.log" 2>&1
+rm -rf /tmp/prof_stats; $RP --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-sweep --no-poseidon --no-clock-probe > "$OUT/bench_under_rocprof.log" 2>&1
 grep '^{"metric"' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/${R}_bench_under_rocprof.json"
 cp $(ls /tmp/prof_stats/*/*kernel_stats.csv | head -1) "$OUT/${R}_bench_kernel_stats.csv"
 fi
@@ -31,7 +31,7 @@ if has roofline; then
 for ss in 1 0; do
   tag=$([ $ss = 1 ] && echo single_stream || echo two_streams)
   BFHIP_SINGLE_STREAM=$ss python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-sweep --no-poseidon --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > "$OUT/${R}_roofline_${tag}_events.json"
-  rm -rf /tmp/prof_rf; BFHIP_SINGLE_STREAM=$ss $RP --kernel-trace --stats --output-format csv -d /tmp/prof_rf -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-sweep --no-poseidon --no-cpu-baseline > "$OUT/roofline_${tag}_under_rocprof.log" 2>&1
+  rm -rf /tmp/prof_rf; BFHIP_SINGLE_STREAM=$ss $RP --kernel-trace --stats --output-format csv -d /tmp/prof_rf -- python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-sweep --no-poseidon --no-cpu-baseline --no-clock-probe > "$OUT/roofline_${tag}_under_rocprof.log" 2>&1      # no probe: its k_merkle_layer launches would join the CSV's average
   grep '^{"metric"' "$OUT/roofline_${tag}_under_rocprof.log" | tail -1 > "$OUT/${R}_roofline_${tag}_under_rocprof.json"
   cp $(ls /tmp/prof_rf/*/*kernel_stats.csv | head -1) "$OUT/${R}_roofline_${tag}_kernel_stats.csv"
   python3 "$ROOT/tools/merkle_launches.py" $(kt /tmp/prof_rf) > "$OUT/${R}_roofline_${tag}_merkle_launches.txt" 2>&1
