@@ -90,6 +90,44 @@ def test_replicated_transforms_policy_gives_the_same_proof_without_column_exchan
         assert st1["bytes_sent"] < st0["bytes_sent"] // 4, (st0, st1)
 
 
+@pytest.mark.single_conv
+def test_two_shard_groups_prove_at_the_same_time(pkg, oracle):
+    """bench.py --group-inflight 2 in one process: TWO shard groups of two ranks each (four contexts, four host threads, one GPU), proving different programs at the same
+    time, one group exchanging columns -> rows, the other replicating the transforms. Their collectives interleave on the device; every rank of either group must
+    return its own program's one-GPU bytes, several proofs in a row."""
+    progs = [(open(os.path.join(PROGS, "collatz.bf")).read(), b"7\n", 21), (open(os.path.join(PROGS, "hello_kakarot.bf")).read(), b"", 17)]
+    want = []
+    for code, inp, lmr in progs:
+        c1 = pkg.Context(0, max_log_domain=lmr + 2)
+        want.append(pkg.prove_brainfuck(code, inp, ctx=c1, log_max_rows=lmr))
+        c1.close()
+    groups = [pkg.LocalGroup(2), pkg.LocalGroup(2)]
+    ctxs = [[pkg.Context(0, max_log_domain=progs[g][2] + 2) for _ in range(2)] for g in range(2)]
+    got, errors = [[[], []], [[], []]], []
+
+    def run(g, r):
+        try:
+            c = ctxs[g][r]
+            c.join_local_group(groups[g], r)
+            c.set_shard_policy(g)                       # group 0 exchanges, group 1 replicates
+            code, inp, lmr = progs[g]
+            for _ in range(4):
+                got[g][r].append(pkg.prove_brainfuck(code, inp, ctx=c, log_max_rows=lmr))
+        except Exception as e:
+            errors.append((g, r, repr(e)))
+
+    th = [threading.Thread(target=run, args=(g, r)) for g in range(2) for r in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for g in range(2):
+        for c in ctxs[g]:
+            c.leave_group(); c.close()
+        groups[g].close()
+    assert not errors, errors
+    for g in range(2):
+        for r in range(2):
+            assert got[g][r] == [want[g]] * 4, f"group {g} rank {r}"
+
+
 @pytest.mark.parametrize("count", [2, 4, 8])
 def test_exchange_on_the_partner_stream_does_not_change_the_proof(pkg, oracle, count):
     """bfhip_ctx_set_overlap bit 2: the column -> row send-receive of a tree's largest size class runs on the partner stream while the smaller
